@@ -1,0 +1,95 @@
+"""Architecture records for the EVA02 towers on the CLIPSelf hot path.
+
+The numbers mirror the reference's JSON model configs
+(reference: src/open_clip/eva_clip/model_configs/EVA02-CLIP-B-16.json,
+EVA02-CLIP-L-14-336.json) and the wiring in
+src/open_clip/eva_clip/model.py:92-131 (``_build_vision_tower``) and
+src/open_clip/eva_clip/eva_vit_model.py:396-470.
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, asdict
+from pathlib import Path
+
+
+@dataclass(frozen=True)
+class TowerCfg:
+    name: str
+    embed_dim: int          # E: CLIP embedding width (head output)
+    image_size: int         # native square input
+    patch_size: int
+    width: int              # C
+    layers: int             # L
+    head_width: int = 64
+    mlp_ratio: float = 2.6667
+    pt_hw_seq_len: int = 16  # RoPE pre-training grid (rope.py:96-142)
+    ln_eps: float = 1e-6     # eva_clip/model.py:123
+    # text tower census only (state-dict compat; never executed on the hot path)
+    text_width: int = 512
+    text_heads: int = 8
+    text_layers: int = 12
+    text_context: int = 77
+    text_vocab: int = 49408
+
+    @property
+    def heads(self) -> int:
+        return self.width // self.head_width
+
+    @property
+    def hidden(self) -> int:
+        # eva_vit_model.py:274  int(dim * mlp_ratio)
+        return int(self.width * self.mlp_ratio)
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch_size
+
+    @property
+    def tokens(self) -> int:
+        return self.grid * self.grid + 1
+
+    def grid_for(self, image_hw: int) -> int:
+        return image_hw // self.patch_size
+
+
+_CFG_DIR = Path(__file__).parent / "open_clip" / "model_configs"
+
+
+def _from_json(name: str, blob: dict) -> TowerCfg:
+    v, t = blob["vision_cfg"], blob["text_cfg"]
+    for flag in ("rope", "naiveswiglu", "subln", "intp_freq"):
+        if not v.get(flag, False):
+            raise NotImplementedError(
+                f"{name}: only the EVA02 (rope+swiglu+subln) tower family is on the hot path")
+    return TowerCfg(
+        name=name, embed_dim=blob["embed_dim"], image_size=v["image_size"],
+        patch_size=v["patch_size"], width=v["width"], layers=v["layers"],
+        head_width=v.get("head_width", 64), mlp_ratio=v.get("mlp_ratio", 4.0),
+        pt_hw_seq_len=v.get("pt_hw_seq_len", 16),
+        text_width=t["width"], text_heads=t["heads"], text_layers=t["layers"],
+        text_context=t.get("context_length", 77), text_vocab=t.get("vocab_size", 49408))
+
+
+def list_models():
+    return sorted(p.stem for p in _CFG_DIR.glob("*.json"))
+
+
+def get_tower_cfg(model_name: str) -> TowerCfg:
+    model_name = model_name.replace("/", "-")
+    path = _CFG_DIR / f"{model_name}.json"
+    if not path.exists():
+        raise RuntimeError(f"Model config for {model_name} not found; available models {list_models()}.")
+    return _from_json(model_name, json.loads(path.read_text()))
+
+
+def tiny_cfg() -> TowerCfg:
+    """The small EVA02-shaped tower (head dim 64 like both shipped towers) used for full-tensor golden vectors
+    (SURVEY.md Appendix B item 9)."""
+    return TowerCfg(name="EVA02-tiny-test", embed_dim=64, image_size=32, patch_size=8,
+                    width=128, layers=2, head_width=64, mlp_ratio=2.0,
+                    text_width=32, text_heads=2, text_layers=1)
+
+
+def cfg_dict(cfg: TowerCfg) -> dict:
+    return asdict(cfg)
