@@ -1,0 +1,456 @@
+// Multi-head self-attention (head dim 64, no mask, no dropout) with the EVA02 2-D RoPE applied on load, for the
+// CLIPSelf teacher/student towers -- forward and the student's backward.  gfx950, MFMA 32x32x16 bf16.
+//
+// Reference semantics (src/open_clip/eva_clip/eva_vit_model.py:181-243, rope.py:25-29,148-164):
+//   q,k,v = split heads of [B*N, 3C];  q,k tokens 1.. rotated:  y = t*cos + rotate_half(t)*sin  (CLS token passed through)
+//   o = softmax(q k^T * d^-0.5) v,  written back token-major [B*N, C].
+//
+// Layout/algorithm (MI355X-first):
+//   * one 512-thread workgroup (8 waves) per (image, head, 256-query group); each wave owns 32 queries.
+//   * "swapped" products: S^T[key,query] = K . Q^T, so every lane owns ONE query column and the softmax row
+//     reductions are in-register (+ one cross-half shuffle); P^T accumulator registers feed the next MFMA as the
+//     B operand with no cross-lane movement because the contraction slots are *defined* by the accumulator layout
+//     (slot (half,j) <-> key (j&3) + 8*(j>>2) + 4*half) and the A operand (V^T / K^T rows) is read in that order.
+//   * K (roped) is staged once per workgroup into LDS as [key][64] with a 16-byte-chunk XOR swizzle
+//     (conflict-free ds_read_b128), V as V^T [64][keys+4] (8-byte reads, odd dword stride -> conflict free).
+//   * keys are consumed in chunks of CH*32 with an online softmax, so any sequence length works; for the
+//     14x14(+CLS) grid a single chunk of 224 covers all 197 keys and no rescale is ever taken.
+#include "cs_common.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+    return z;
+}
+
+// rotate 8 consecutive head-dim values (4 interleaved pairs) by the table rows at cs/sn (fp32, 8 entries each)
+__device__ __forceinline__ void rope8(U128& v, const float* __restrict__ cs, const float* __restrict__ sn) {
+    const float4 c0 = *(const float4*)cs, c1 = *(const float4*)(cs + 4);
+    const float4 s0 = *(const float4*)sn, s1 = *(const float4*)(sn + 4);
+    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x0 = bf2f(v.e[2 * j]), x1 = bf2f(v.e[2 * j + 1]);
+        v.e[2 * j] = f2bf(x0 * c[2 * j] - x1 * s[2 * j]);
+        v.e[2 * j + 1] = f2bf(x1 * c[2 * j + 1] + x0 * s[2 * j + 1]);
+    }
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int c2) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = f2bf(a[c2 * 8 + j]);
+    return r;
+}
+
+// A operand rows from a transposed [64][ld] bf16 image: slots (half,j) <-> column base + (j&3) + 8*(j>>2) + 4*half
+__device__ __forceinline__ bf16x8 load_t_frag(const __bf16* t, int ld, int d, int base, int hf) {
+    U64 lo, hi;
+    lo.u = *(const uint2*)(t + d * ld + base + 4 * hf);
+    hi.u = *(const uint2*)(t + d * ld + base + 8 + 4 * hf);
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { r[j] = lo.e[j]; r[4 + j] = hi.e[j]; }
+    return r;
+}
+
+struct AttnArgs {
+    const __bf16* qkv;     // [B*N, ldqkv]: q | k | v, each C = H*64 wide
+    const __bf16* dout;    // bwd: dO [B*N, ldo]
+    const float* cos_t;    // [N-1, 64]
+    const float* sin_t;
+    const float* lse_in;   // bwd: [B*H, N]
+    const float* dsum;     // bwd: rowsum(dO*O) [B*H, N]
+    __bf16* out;           // fwd: O [B*N, ldo] ; bwd: dqkv [B*N, ldqkv]
+    float* lse_out;        // fwd (nullable)
+    int Ntok, H, ldqkv, ldo;
+    float scale;
+};
+
+// stage `rows` token rows (tok0..) of one head column block into a swizzled [rows][64] LDS tile (+ optional transposed copy)
+template <int CHK, bool ROPE, bool WITH_T>
+__device__ __forceinline__ void stage_rows(const __bf16* __restrict__ src, size_t rowbase, int ld, int coloff, int tok0, int Ntok,
+                                           const float* cos_t, const float* sin_t, char* tile, __bf16* tile_t, int ldt, int tid) {
+    for (int idx = tid; idx < CHK * 8; idx += 512) {
+        const int r = idx >> 3, c = idx & 7, tok = tok0 + r;
+        U128 v;
+        if (tok < Ntok) {
+            v.u = *(const uint4*)(src + (rowbase + tok) * ld + coloff + c * 8);
+            if (ROPE && tok > 0) rope8(v, cos_t + (size_t)(tok - 1) * HD + c * 8, sin_t + (size_t)(tok - 1) * HD + c * 8);
+        } else {
+            v.u = make_uint4(0, 0, 0, 0);
+        }
+        if (tile) *(uint4*)(tile + r * 128 + ((c ^ (r & 7)) << 4)) = v.u;
+        if (WITH_T) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile_t[(c * 8 + e) * ldt + r] = v.e[e];
+        }
+    }
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int ks, int hf) {
+    return *(const bf16x8*)(tile + row * 128 + ((((ks << 1) + hf) ^ (row & 7)) << 4));
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int CH>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int CHK = CH * 32, VLD = CHK + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kl = smem;
+    __bf16* Vt = (__bf16*)(smem + CHK * 128);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int C = p.H * HD;
+    const size_t rowbase = (size_t)b * p.Ntok;
+    const int q = blockIdx.x * 256 + wave * 32 + l31;
+    const int qc = min(q, p.Ntok - 1);
+    const bool wave_active = (blockIdx.x * 256 + wave * 32) < p.Ntok;
+    const float sl2 = p.scale * LOG2E;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int d0 = ks * 16 + hf * 8;
+        U128 t;
+        t.u = *(const uint4*)(p.qkv + (rowbase + qc) * p.ldqkv + h * HD + d0);
+        if (qc > 0) rope8(t, p.cos_t + (size_t)(qc - 1) * HD + d0, p.sin_t + (size_t)(qc - 1) * HD + d0);
+        qf[ks] = t.h;
+    }
+
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[2] = {zero16(), zero16()};
+
+    for (int key0 = 0; key0 < p.Ntok; key0 += CHK) {
+        __syncthreads();
+        stage_rows<CHK, true, false>(p.qkv, rowbase, p.ldqkv, C + h * HD, key0, p.Ntok, p.cos_t, p.sin_t, Kl, nullptr, 0, tid);
+        stage_rows<CHK, false, true>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0, p.Ntok, nullptr, nullptr, nullptr, Vt, VLD, tid);
+        __syncthreads();
+        if (!wave_active) continue;
+
+        f32x16 s[CH];
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+            s[t] = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Kl, t * 32 + l31, ks, hf), qf[ks], s[t], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < CH; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = key0 + t * 32 + mfma32_row(e, lane);
+                if (key >= p.Ntok) s[t][e] = -INFINITY;
+                mx = fmaxf(mx, s[t][e]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = exp2f((m - m_new) * sl2);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < CH; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = exp2f((s[t][e] - m_new) * sl2);
+                s[t][e] = pv;
+                rs += pv;
+            }
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = m_new;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+#pragma unroll
+        for (int t = 0; t < CH; ++t)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const bf16x8 pb = pack8(s[t], c2);
+                const int base = t * 32 + c2 * 16;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_t_frag(Vt, VLD, dt * 32 + l31, base, hf), pb, o[dt], 0, 0, 0);
+            }
+    }
+
+    if (wave_active && q < p.Ntok) {
+        const float inv = 1.f / l;
+        __bf16* orow = p.out + (rowbase + q) * p.ldo + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                U64 t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t.e[i] = f2bf(o[dt][g4 * 4 + i] * inv);
+                *(uint2*)(orow + dt * 32 + g4 * 8 + hf * 4) = t.u;
+            }
+        if (p.lse_out && hf == 0) p.lse_out[(size_t)bh * p.Ntok + q] = m * p.scale + logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// dsum[b,h,n] = sum_d dO[b,n,h,d] * O[b,n,h,d]
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const __bf16* __restrict__ o, const __bf16* __restrict__ dout, float* __restrict__ dsum,
+                                                            int B, int Ntok, int H, int ldo) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (row, head, chunk of 8)
+    const long total = (long)B * Ntok * H * 8;
+    float s = 0.f;
+    long row = 0; int h = 0;
+    const bool ok = idx < total;
+    if (ok) {
+        const int c = (int)(idx & 7);
+        h = (int)((idx >> 3) % H);
+        row = (idx >> 3) / H;
+        U128 a, g;
+        a.u = *(const uint4*)(o + row * ldo + h * HD + c * 8);
+        g.u = *(const uint4*)(dout + row * ldo + h * HD + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += bf2f(a.e[e]) * bf2f(g.e[e]);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (ok && (idx & 7) == 0) {
+        const long b = row / Ntok, n = row - b * Ntok;
+        dsum[((size_t)b * H + h) * Ntok + n] = s;
+    }
+}
+
+// inverse rotation of an accumulator tile pair (lane = token, registers = head-dim) + bf16 store, 8 bytes per 4 dims
+__device__ __forceinline__ void store_grad_tile(const f32x16 (&g)[2], __bf16* dst, bool rope, const float* cs, const float* sn, int hf) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = dt * 32 + g4 * 8 + hf * 4;
+            float v[4] = {g[dt][g4 * 4], g[dt][g4 * 4 + 1], g[dt][g4 * 4 + 2], g[dt][g4 * 4 + 3]};
+            if (rope) {
+                const float4 c = *(const float4*)(cs + d), s = *(const float4*)(sn + d);
+                const float a0 = v[0] * c.x + v[1] * s.y, a1 = v[1] * c.y - v[0] * s.x;
+                const float a2 = v[2] * c.z + v[3] * s.w, a3 = v[3] * c.w - v[2] * s.z;
+                v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
+            }
+            U64 t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t.e[i] = f2bf(v[i]);
+            *(uint2*)(dst + d) = t.u;
+        }
+}
+
+// dQ: wave = 32 queries, loops over key chunks.  dS^T = P^T o (dP^T - D) * scale ; dQ^T += K^T . dS^T
+template <int CH>
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnArgs p) {
+    constexpr int CHK = CH * 32, VLD = CHK + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kl = smem;
+    char* Vl = smem + CHK * 128;
+    __bf16* Kt = (__bf16*)(smem + 2 * CHK * 128);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int C = p.H * HD;
+    const size_t rowbase = (size_t)b * p.Ntok;
+    const int q = blockIdx.x * 256 + wave * 32 + l31;
+    const int qc = min(q, p.Ntok - 1);
+    const bool wave_active = (blockIdx.x * 256 + wave * 32) < p.Ntok;
+    const float sl2 = p.scale * LOG2E;
+
+    bf16x8 qf[4], dof[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int d0 = ks * 16 + hf * 8;
+        U128 t;
+        t.u = *(const uint4*)(p.qkv + (rowbase + qc) * p.ldqkv + h * HD + d0);
+        if (qc > 0) rope8(t, p.cos_t + (size_t)(qc - 1) * HD + d0, p.sin_t + (size_t)(qc - 1) * HD + d0);
+        qf[ks] = t.h;
+        t.u = *(const uint4*)(p.dout + (rowbase + qc) * p.ldo + h * HD + d0);
+        dof[ks] = t.h;
+    }
+    const float lse2 = p.lse_in[(size_t)bh * p.Ntok + qc] * LOG2E;
+    const float dq_sum = p.dsum[(size_t)bh * p.Ntok + qc];
+    f32x16 dq[2] = {zero16(), zero16()};
+
+    for (int key0 = 0; key0 < p.Ntok; key0 += CHK) {
+        __syncthreads();
+        stage_rows<CHK, true, true>(p.qkv, rowbase, p.ldqkv, C + h * HD, key0, p.Ntok, p.cos_t, p.sin_t, Kl, Kt, VLD, tid);
+        stage_rows<CHK, false, false>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0, p.Ntok, nullptr, nullptr, Vl, nullptr, 0, tid);
+        __syncthreads();
+        if (!wave_active) continue;
+#pragma nounroll
+        for (int t = 0; t < CH; ++t) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Kl, t * 32 + l31, ks, hf), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Vl, t * 32 + l31, ks, hf), dof[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = key0 + t * 32 + mfma32_row(e, lane);
+                const float pv = key < p.Ntok ? exp2f(s[e] * sl2 - lse2) : 0.f;
+                s[e] = pv * (dp[e] - dq_sum) * p.scale;
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const bf16x8 db = pack8(s, c2);
+                const int base = t * 32 + c2 * 16;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_t_frag(Kt, VLD, dt * 32 + l31, base, hf), db, dq[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (wave_active && q < p.Ntok) {
+        const size_t pos = (size_t)(q > 0 ? q - 1 : 0) * HD;
+        store_grad_tile(dq, p.out + (rowbase + q) * p.ldqkv + h * HD, q > 0, p.cos_t + pos, p.sin_t + pos, hf);
+    }
+}
+
+// dK, dV: wave = 32 keys, loops over query chunks.  S = Q K^T (lane = key, registers = queries)
+//   dV^T += dO^T . P ;  dK^T += Q^T . dS
+template <int CH>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs p) {
+    constexpr int CHQ = CH * 32, VLD = CHQ + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ql = smem;
+    char* Gl = smem + CHQ * 128;
+    __bf16* Qt = (__bf16*)(smem + 2 * CHQ * 128);
+    __bf16* Gt = Qt + HD * VLD;
+    float* lse_s = (float*)(Gt + HD * VLD);
+    float* dsum_s = lse_s + CHQ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int C = p.H * HD;
+    const size_t rowbase = (size_t)b * p.Ntok;
+    const int key = blockIdx.x * 256 + wave * 32 + l31;
+    const int kc = min(key, p.Ntok - 1);
+    const bool wave_active = (blockIdx.x * 256 + wave * 32) < p.Ntok;
+    const float sl2 = p.scale * LOG2E;
+
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int d0 = ks * 16 + hf * 8;
+        U128 t;
+        t.u = *(const uint4*)(p.qkv + (rowbase + kc) * p.ldqkv + C + h * HD + d0);
+        if (kc > 0) rope8(t, p.cos_t + (size_t)(kc - 1) * HD + d0, p.sin_t + (size_t)(kc - 1) * HD + d0);
+        kf[ks] = t.h;
+        t.u = *(const uint4*)(p.qkv + (rowbase + kc) * p.ldqkv + 2 * C + h * HD + d0);
+        vf[ks] = t.h;
+    }
+    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+
+    for (int q0 = 0; q0 < p.Ntok; q0 += CHQ) {
+        __syncthreads();
+        stage_rows<CHQ, true, true>(p.qkv, rowbase, p.ldqkv, h * HD, q0, p.Ntok, p.cos_t, p.sin_t, Ql, Qt, VLD, tid);
+        stage_rows<CHQ, false, true>(p.dout, rowbase, p.ldo, h * HD, q0, p.Ntok, nullptr, nullptr, Gl, Gt, VLD, tid);
+        for (int i = tid; i < CHQ; i += 512) {
+            const int qi = q0 + i;
+            lse_s[i] = qi < p.Ntok ? p.lse_in[(size_t)bh * p.Ntok + qi] * LOG2E : INFINITY;   // +inf -> P = 0 for padded queries
+            dsum_s[i] = qi < p.Ntok ? p.dsum[(size_t)bh * p.Ntok + qi] : 0.f;
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+#pragma nounroll
+        for (int t = 0; t < CH; ++t) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Ql, t * 32 + l31, ks, hf), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Gl, t * 32 + l31, ks, hf), vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qi = t * 32 + mfma32_row(e, lane);
+                const float pv = key < p.Ntok ? exp2f(s[e] * sl2 - lse_s[qi]) : 0.f;
+                s[e] = pv;
+                dp[e] = pv * (dp[e] - dsum_s[qi]) * p.scale;
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const bf16x8 pb = pack8(s, c2), db = pack8(dp, c2);
+                const int base = t * 32 + c2 * 16;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_t_frag(Gt, VLD, dt * 32 + l31, base, hf), pb, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_t_frag(Qt, VLD, dt * 32 + l31, base, hf), db, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (wave_active && key < p.Ntok) {
+        const size_t pos = (size_t)(key > 0 ? key - 1 : 0) * HD;
+        __bf16* row = p.out + (rowbase + key) * p.ldqkv + h * HD;
+        store_grad_tile(dk, row + C, key > 0, p.cos_t + pos, p.sin_t + pos, hf);
+        store_grad_tile(dv, row + 2 * C, false, nullptr, nullptr, hf);
+    }
+}
+
+template <typename K>
+void set_lds(K kernel, size_t bytes) { (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
+
+int check_common(const char* who, int B, int Ntok, int H, int ldqkv, int ldo) {
+    CS_CHECK_ARG(B > 0 && Ntok > 1 && H > 0, "%s: bad shape B=%d N=%d H=%d", who, B, Ntok, H);
+    CS_CHECK_ARG(ldqkv % 8 == 0 && ldo % 8 == 0 && ldqkv >= 3 * H * HD && ldo >= H * HD, "%s: bad leading dimensions", who);
+    return 0;
+}
+
+}  // namespace
+
+// C ABI ------------------------------------------------------------------------------------------
+// qkv [B*N, ldqkv] bf16 (q|k|v, un-rotated, bias already added); cos/sin [(N-1), 64] f32; out [B*N, ldo] bf16;
+// lse [B*H, N] f32 or null.  Head dim fixed at 64 (both EVA02 towers).
+extern "C" int cs_attn_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* out, float* lse, int B, int Ntok, int H,
+                           int ldqkv, int ldo, float scale, hipStream_t stream) {
+    if (check_common("cs_attn_fwd", B, Ntok, H, ldqkv, ldo)) return -1;
+    AttnArgs a{};
+    a.qkv = (const __bf16*)qkv; a.cos_t = cos_t; a.sin_t = sin_t; a.out = (__bf16*)out; a.lse_out = lse;
+    a.Ntok = Ntok; a.H = H; a.ldqkv = ldqkv; a.ldo = ldo; a.scale = scale;
+    dim3 grid((Ntok + 255) / 256, B * H), block(512);
+    constexpr int CH = 7;
+    const size_t lds = (size_t)CH * 32 * 128 + (size_t)HD * (CH * 32 + 4) * 2;
+    static bool once = (set_lds(attn_fwd_kernel<CH>, lds), true);
+    (void)once;
+    hipLaunchKernelGGL((attn_fwd_kernel<CH>), grid, block, lds, stream, a);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t cs_attn_bwd_workspace(int B, int Ntok, int H) { return (size_t)B * H * Ntok * sizeof(float); }
+
+// o, dout [B*N, ldo] bf16; lse from the forward; dqkv [B*N, ldqkv] bf16 receives d(q|k|v) w.r.t. the *un-rotated* q,k.
+extern "C" int cs_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* cos_t, const float* sin_t,
+                           void* dqkv, void* workspace, int B, int Ntok, int H, int ldqkv, int ldo, float scale, hipStream_t stream) {
+    if (check_common("cs_attn_bwd", B, Ntok, H, ldqkv, ldo)) return -1;
+    CS_CHECK_ARG(workspace != nullptr && lse != nullptr, "cs_attn_bwd: workspace and lse are required");
+    float* dsum = (float*)workspace;
+    const long total = (long)B * Ntok * H * 8;
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, stream, (const __bf16*)o, (const __bf16*)dout, dsum, B, Ntok, H, ldo);
+    CS_LAUNCH_CHECK();
+    AttnArgs a{};
+    a.qkv = (const __bf16*)qkv; a.dout = (const __bf16*)dout; a.cos_t = cos_t; a.sin_t = sin_t; a.lse_in = lse; a.dsum = dsum;
+    a.out = (__bf16*)dqkv; a.Ntok = Ntok; a.H = H; a.ldqkv = ldqkv; a.ldo = ldo; a.scale = scale;
+    dim3 grid((Ntok + 255) / 256, B * H), block(512);
+    constexpr int CH = 7;
+    constexpr int CHK = CH * 32, VLD = CHK + 4;
+    const size_t lds_dq = (size_t)2 * CHK * 128 + (size_t)HD * VLD * 2;
+    const size_t lds_dkv = (size_t)2 * CHK * 128 + (size_t)2 * HD * VLD * 2 + (size_t)2 * CHK * sizeof(float);
+    static bool once = (set_lds(attn_bwd_dq_kernel<CH>, lds_dq), set_lds(attn_bwd_dkv_kernel<CH>, lds_dkv), true);
+    (void)once;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<CH>), grid, block, lds_dq, stream, a);
+    CS_LAUNCH_CHECK();
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<CH>), grid, block, lds_dkv, stream, a);
+    CS_LAUNCH_CHECK();
+    return 0;
+}

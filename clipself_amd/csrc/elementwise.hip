@@ -1,0 +1,188 @@
+// HBM-bound helper kernels of the CLIPSelf step: SiLU*mul (fwd/bwd), f32->bf16 cast, padded bf16 transpose,
+// column sums (bias gradients), patch im2row, CLS-row fill.  All vectorised to 16-byte accesses per lane.
+#include "cs_common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+
+// h[m, j] = silu(x12[m, j]) * x12[m, Hd + j]        (reference: SwiGLU.forward, eva_vit_model.py:99-101)
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const __bf16* __restrict__ x12, long ldx, __bf16* __restrict__ h, long ldh,
+                                                         int M, int Hd) {
+    const int vec_per_row = Hd >> 3;
+    const long total = (long)M * vec_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / vec_per_row), j = (int)(i - (long)m * vec_per_row) * 8;
+        U128 a, b, o;
+        a.u = *(const uint4*)(x12 + (size_t)m * ldx + j);
+        b.u = *(const uint4*)(x12 + (size_t)m * ldx + Hd + j);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.e[e] = f2bf(silu_f(bf2f(a.e[e])) * bf2f(b.e[e]));
+        *(uint4*)(h + (size_t)m * ldh + j) = o.u;
+    }
+}
+
+// dx1 = dh * x2 * (sig + x1*sig*(1-sig)) ; dx2 = dh * silu(x1)
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const __bf16* __restrict__ dh, long lddh, const __bf16* __restrict__ x12, long ldx,
+                                                         __bf16* __restrict__ dx12, long lddx, int M, int Hd) {
+    const int vec_per_row = Hd >> 3;
+    const long total = (long)M * vec_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / vec_per_row), j = (int)(i - (long)m * vec_per_row) * 8;
+        U128 a, b, g, o1, o2;
+        a.u = *(const uint4*)(x12 + (size_t)m * ldx + j);
+        b.u = *(const uint4*)(x12 + (size_t)m * ldx + Hd + j);
+        g.u = *(const uint4*)(dh + (size_t)m * lddh + j);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x1 = bf2f(a.e[e]), x2 = bf2f(b.e[e]), d = bf2f(g.e[e]);
+            const float sig = 1.f / (1.f + __expf(-x1));
+            o1.e[e] = f2bf(d * x2 * (sig + x1 * sig * (1.f - sig)));
+            o2.e[e] = f2bf(d * x1 * sig);
+        }
+        *(uint4*)(dx12 + (size_t)m * lddx + j) = o1.u;
+        *(uint4*)(dx12 + (size_t)m * lddx + Hd + j) = o2.u;
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, long n8) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const float4 a = *(const float4*)(x + i * 8), b = *(const float4*)(x + i * 8 + 4);
+        U128 o;
+        o.e[0] = f2bf(a.x); o.e[1] = f2bf(a.y); o.e[2] = f2bf(a.z); o.e[3] = f2bf(a.w);
+        o.e[4] = f2bf(b.x); o.e[5] = f2bf(b.y); o.e[6] = f2bf(b.z); o.e[7] = f2bf(b.w);
+        *(uint4*)(y + i * 8) = o.u;
+    }
+}
+
+// out[c, r] = in[r, c] for r < R, 0 for R <= r < ld_out.  64x64 tiles through LDS (+1 dword pad), bf16.
+// Used to build the contraction-major operands of the weight-gradient GEMMs and the transposed weight shadows.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const __bf16* __restrict__ in, long ld_in, __bf16* __restrict__ out,
+                                                             long ld_out, int R, int Cc) {
+    __shared__ uint16_t tile[64][66];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;    // ty 0..3
+    const uint16_t* src = (const uint16_t*)in;
+    uint16_t* dst = (uint16_t*)out;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty * 16 + i, c = c0 + tx;
+        tile[ty * 16 + i][tx] = (r < R && c < Cc) ? src[(size_t)r * ld_in + c] : (uint16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty * 16 + i, r = r0 + tx;
+        if (c < Cc && r < ld_out) dst[(size_t)c * ld_out + r] = tile[tx][ty * 16 + i];
+    }
+}
+
+// out[n] (+)= sum_m x[m, n]   (bias gradients; bf16 in, f32 out).  grid.x tiles columns by 256*... each thread one
+// column pair, grid.y splits rows; partial sums combined with hardware float atomics (out pre-zeroed by the step).
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ x, long ldx, float* __restrict__ out, int M, int N,
+                                                          int rows_per_block) {
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (n >= N) return;
+    const int m_begin = blockIdx.y * rows_per_block, m_end = min(M, m_begin + rows_per_block);
+    float s0 = 0.f, s1 = 0.f;
+    for (int m = m_begin; m < m_end; ++m) {
+        const uint32_t v = *(const uint32_t*)(x + (size_t)m * ldx + n);
+        s0 += __uint_as_float(v << 16);
+        s1 += __uint_as_float(v & 0xffff0000u);
+    }
+    unsafeAtomicAdd(out + n, s0);
+    if (n + 1 < N) unsafeAtomicAdd(out + n + 1, s1);
+}
+
+// im2row for the patch-embed conv as a GEMM (reference: nn.Conv2d(3,C,p,stride=p), eva_vit_model.py:348,355).
+// out[(b*g*g + py*g + px), (c*p + iy)*p + ix] = img[b, c, py*p + iy, px*p + ix]      ((c,iy,ix) = conv-weight order)
+template <typename TI>
+__global__ __launch_bounds__(256) void im2row_kernel(const TI* __restrict__ img, __bf16* __restrict__ out, int B, int S, int p, int g, int ldo) {
+    const int segs = p / 8;                         // 8-pixel segments per patch row (16-byte bf16 stores)
+    const long total = (long)B * g * g * 3 * p * segs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long t = i;
+        const int sg = (int)(t % segs); t /= segs;
+        const int iy = (int)(t % p); t /= p;
+        const int c = (int)(t % 3); t /= 3;
+        const int px = (int)(t % g); t /= g;
+        const int py = (int)(t % g); t /= g;
+        const int b = (int)t;
+        const TI* s = img + (((size_t)b * 3 + c) * S + (py * p + iy)) * S + px * p + sg * 8;
+        U128 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.e[e] = f2bf((float)s[e]);
+        const size_t row = ((size_t)b * g + py) * g + px;
+        *(uint4*)(out + row * ldo + (c * p + iy) * p + sg * 8) = o.u;
+    }
+}
+
+// x[b, 0, :] = cls + pos[0, :]   (eva_vit_model.py:540-543)
+__global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos, int B, int Ntok, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * C) return;
+    const int b = (int)(i / C), c = (int)(i - (long)b * C);
+    x[(size_t)b * Ntok * C + c] = cls[c] + pos[c];
+}
+
+inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
+    long g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+// C ABI ------------------------------------------------------------------------------------------
+extern "C" int cs_swiglu_fwd(const void* x12, long ldx, void* h, long ldh, int M, int Hd, hipStream_t stream) {
+    CS_CHECK_ARG(Hd % 8 == 0 && ldx % 8 == 0 && ldh % 8 == 0 && M > 0, "cs_swiglu_fwd: Hd/ld must be multiples of 8");
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for((long)M * (Hd / 8))), dim3(256), 0, stream, (const __bf16*)x12, ldx, (__bf16*)h, ldh, M, Hd);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cs_swiglu_bwd(const void* dh, long lddh, const void* x12, long ldx, void* dx12, long lddx, int M, int Hd, hipStream_t stream) {
+    CS_CHECK_ARG(Hd % 8 == 0 && ldx % 8 == 0 && lddh % 8 == 0 && lddx % 8 == 0 && M > 0, "cs_swiglu_bwd: Hd/ld must be multiples of 8");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((long)M * (Hd / 8))), dim3(256), 0, stream, (const __bf16*)dh, lddh, (const __bf16*)x12, ldx,
+                       (__bf16*)dx12, lddx, M, Hd);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cs_cast_f32_bf16(const float* x, void* y, long n, hipStream_t stream) {
+    CS_CHECK_ARG(n > 0 && n % 8 == 0, "cs_cast_f32_bf16: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, x, (__bf16*)y, n / 8);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cs_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int Cc, hipStream_t stream) {
+    CS_CHECK_ARG(R > 0 && Cc > 0 && ld_out >= R, "cs_transpose_bf16: bad shape R=%d C=%d ld_out=%ld", R, Cc, ld_out);
+    dim3 grid((Cc + 63) / 64, (int)((ld_out + 63) / 64));
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, stream, (const __bf16*)in, ld_in, (__bf16*)out, ld_out, R, Cc);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cs_colsum_bf16(const void* x, long ldx, float* out, int M, int N, hipStream_t stream) {
+    CS_CHECK_ARG(M > 0 && N > 0 && N % 2 == 0 && ldx % 2 == 0, "cs_colsum_bf16: N and ldx must be even");
+    const int rows_per_block = 128;
+    dim3 grid((N / 2 + 255) / 256, (M + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, stream, (const __bf16*)x, ldx, out, M, N, rows_per_block);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+// img_dtype: 0 = f32, 1 = bf16
+extern "C" int cs_im2row(const void* img, int img_dtype, void* out, int B, int S, int p, int ldo, hipStream_t stream) {
+    CS_CHECK_ARG(p % 8 == 0 && S % p == 0 && B > 0, "cs_im2row: patch size must be a multiple of 8 and divide S (p=%d S=%d)", p, S);
+    const int g = S / p;
+    const long total = (long)B * g * g * 3 * p * (p / 8);
+    if (img_dtype == 0)
+        hipLaunchKernelGGL((im2row_kernel<float>), dim3(grid_for(total)), dim3(256), 0, stream, (const float*)img, (__bf16*)out, B, S, p, g, ldo);
+    else
+        hipLaunchKernelGGL((im2row_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, stream, (const __bf16*)img, (__bf16*)out, B, S, p, g, ldo);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cs_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok, int C, hipStream_t stream) {
+    CS_CHECK_ARG(B > 0, "cs_cls_row: empty batch");
+    hipLaunchKernelGGL(cls_row_kernel, dim3((int)(((long)B * C + 255) / 256)), dim3(256), 0, stream, x, cls, pos, B, Ntok, C);
+    CS_LAUNCH_CHECK();
+    return 0;
+}

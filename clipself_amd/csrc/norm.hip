@@ -1,0 +1,304 @@
+// LayerNorm (fwd/bwd) and row L2-normalise (fwd/bwd) -- HBM-bound row kernels, one 64-lane wave per
+// row, 16-byte (fp32) / 8-byte (bf16) vector accesses, wave-shuffle reductions, fp32 statistics.
+//
+// Reference semantics: LayerNorm(eps=1e-6, biased variance)
+//   src/open_clip/eva_clip/transformer.py:52-58, eva_clip/model.py:123 (norm1, norm2, inner_attn_ln,
+//   ffn_ln, final norm: eva_vit_model.py:306-307,218,102,616) and F.normalize(dim=-1, eps=1e-12)
+//   (eva_vit_model.py:620).
+#include "cs_common.h"
+
+namespace {
+
+constexpr int MAXC = 3072;  // vec4 groups per lane NG in {4,8,12} -> C <= 1024 / 2048 / 3072
+constexpr int ROWS_PER_WG = 4;
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
+template <> struct Vec4<__bf16> {
+    static __device__ __forceinline__ void load(const __bf16* p, float (&v)[4]) {
+        U64 t; t.u = *(const uint2*)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = bf2f(t.e[i]);
+    }
+};
+__device__ __forceinline__ void store_bf16x4(__bf16* p, const float (&v)[4]) {
+    U64 t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.e[i] = f2bf(v[i]);
+    *(uint2*)p = t.u;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename TX, int MAXG>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, __bf16* __restrict__ y, long ldy,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const TX* xr = x + (size_t)row * ldx;
+    const int ng = (C + 255) >> 8;
+    float v[MAXG][4];
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        const int c = (g * 64 + lane) * 4;
+        if (g < ng && c < C) {
+            Vec4<TX>::load(xr + c, v[g]);
+            s += (v[g][0] + v[g][1]) + (v[g][2] + v[g][3]);
+        } else {
+            v[g][0] = v[g][1] = v[g][2] = v[g][3] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        const int c = (g * 64 + lane) * 4;
+        if (g < ng && c < C) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float d = v[g][i] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    __bf16* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        const int c = (g * 64 + lane) * 4;
+        if (g < ng && c < C) {
+            const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+            float o[4] = {(v[g][0] - mean) * rstd * ga.x + be.x, (v[g][1] - mean) * rstd * ga.y + be.y,
+                          (v[g][2] - mean) * rstd * ga.z + be.z, (v[g][3] - mean) * rstd * ga.w + be.w};
+            store_bf16x4(yr + c, o);
+        }
+    }
+    if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// dx modes
+enum { DX_BF16 = 0, DX_F32_ASSIGN = 1, DX_F32_ACCUM = 2 };
+
+// Backward.  One wave per row, grid-stride over rows; per-lane partial dgamma/dbeta are reduced across the
+// workgroup's waves in LDS and written as one partial row per workgroup; ln_param_reduce sums them.
+template <typename TX, int DXMODE, int MAXG>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, long lddy, const TX* __restrict__ x, long ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, void* __restrict__ dx, long lddx,
+                                                     float* __restrict__ part, int M, int C) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = (float*)smem_raw;                 // [3 waves][2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ng = (C + 255) >> 8;
+    float dg[MAXG][4], db[MAXG][4], ga[MAXG][4];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        const int c = (g * 64 + lane) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dg[g][i] = 0.f; db[g][i] = 0.f; ga[g][i] = 0.f; }
+        if (g < ng && c < C) { const float4 t = *(const float4*)(gamma + c); ga[g][0] = t.x; ga[g][1] = t.y; ga[g][2] = t.z; ga[g][3] = t.w; }
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float xh[MAXG][4], gy[MAXG][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            const int c = (g * 64 + lane) * 4;
+            if (g < ng && c < C) {
+                float xv[4], dv[4];
+                Vec4<TX>::load(x + (size_t)row * ldx + c, xv);
+                Vec4<__bf16>::load(dy + (size_t)row * lddy + c, dv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xh[g][i] = (xv[i] - mean) * rstd;
+                    gy[g][i] = dv[i] * ga[g][i];
+                    s1 += gy[g][i];
+                    s2 += gy[g][i] * xh[g][i];
+                    dg[g][i] += dv[i] * xh[g][i];
+                    db[g][i] += dv[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { xh[g][i] = 0.f; gy[g][i] = 0.f; }
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            const int c = (g * 64 + lane) * 4;
+            if (g < ng && c < C) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = rstd * (gy[g][i] - m1 - xh[g][i] * m2);
+                if (DXMODE == DX_BF16) {
+                    store_bf16x4((__bf16*)dx + (size_t)row * lddx + c, o);
+                } else {
+                    float* p = (float*)dx + (size_t)row * lddx + c;
+                    if (DXMODE == DX_F32_ACCUM) {
+                        const float4 t = *(const float4*)p;
+                        o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+                    }
+                    *(float4*)p = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    }
+    if (part == nullptr) return;
+    // cross-wave reduction of dgamma/dbeta: waves 1..3 publish, wave 0 sums (fixed order -> deterministic)
+    if (wave > 0) {
+        float* mine = red + (size_t)(wave - 1) * 2 * C;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            const int c = (g * 64 + lane) * 4;
+            if (g < ng && c < C) {
+                *(float4*)(mine + c) = make_float4(dg[g][0], dg[g][1], dg[g][2], dg[g][3]);
+                *(float4*)(mine + C + c) = make_float4(db[g][0], db[g][1], db[g][2], db[g][3]);
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* outp = part + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            const int c = (g * 64 + lane) * 4;
+            if (g < ng && c < C) {
+                float a[4] = {dg[g][0], dg[g][1], dg[g][2], dg[g][3]};
+                float b[4] = {db[g][0], db[g][1], db[g][2], db[g][3]};
+                for (int w = 0; w < 3; ++w) {
+                    const float4 t = *(const float4*)(red + (size_t)w * 2 * C + c);
+                    const float4 u = *(const float4*)(red + (size_t)w * 2 * C + C + c);
+                    a[0] += t.x; a[1] += t.y; a[2] += t.z; a[3] += t.w;
+                    b[0] += u.x; b[1] += u.y; b[2] += u.z; b[3] += u.w;
+                }
+                *(float4*)(outp + c) = make_float4(a[0], a[1], a[2], a[3]);
+                *(float4*)(outp + C + c) = make_float4(b[0], b[1], b[2], b[3]);
+            }
+        }
+    }
+}
+
+// part [nparts][2][C] -> dgamma[C] (+=), dbeta[C] (+=)
+__global__ void ln_param_reduce_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * C) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * 2 * C + c];
+    float* dst = c < C ? dgamma + c : dbeta + (c - C);
+    *dst = accumulate ? *dst + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = x / max(||x||, eps) per row (fp32 in, fp32 out); inv_norm saved for the backward.
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ inv_out, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) { const float4 t = *(const float4*)(xr + c); s += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w; }
+    const float inv = 1.f / fmaxf(sqrtf(wave_sum(s)), eps);
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 t = *(const float4*)(xr + c);
+        *(float4*)(y + (size_t)row * C + c) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    }
+    if (lane == 0 && inv_out) inv_out[row] = inv;
+}
+
+// dx = (dy - y * <y,dy>) * inv_norm  -> bf16 (GEMM operand for the head dgrad)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ inv, __bf16* __restrict__ dx, int M, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* yr = y + (size_t)row * C;
+    const float* gr = dy + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 a = *(const float4*)(yr + c), b = *(const float4*)(gr + c);
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    const float dot = wave_sum(s), iv = inv[row];
+    for (int c = lane * 4; c < C; c += 256) {
+        const float4 a = *(const float4*)(yr + c), b = *(const float4*)(gr + c);
+        float o[4] = {(b.x - a.x * dot) * iv, (b.y - a.y * dot) * iv, (b.z - a.z * dot) * iv, (b.w - a.w * dot) * iv};
+        store_bf16x4(dx + (size_t)row * C + c, o);
+    }
+}
+
+}  // namespace
+
+// C ABI ------------------------------------------------------------------------------------------
+// x_dtype: 0 = f32, 1 = bf16.  mean/rstd may be null (teacher, no backward).
+extern "C" int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                                float* mean, float* rstd, int M, int C, float eps, hipStream_t stream) {
+    CS_CHECK_ARG(C % 4 == 0 && C <= MAXC, "cs_layernorm_fwd: C=%d must be a multiple of 4 and <= %d", C, MAXC);
+    CS_CHECK_ARG(M > 0, "cs_layernorm_fwd: empty input");
+    dim3 grid((M + ROWS_PER_WG - 1) / ROWS_PER_WG), block(256);
+#define LNF(TX, NG) hipLaunchKernelGGL((ln_fwd_kernel<TX, NG>), grid, block, 0, stream, (const TX*)x, ldx, gamma, beta, (__bf16*)y, ldy, mean, rstd, M, C, eps)
+    if (x_dtype == 0) { if (C <= 1024) LNF(float, 4); else if (C <= 2048) LNF(float, 8); else LNF(float, 12); }
+    else { if (C <= 1024) LNF(__bf16, 4); else if (C <= 2048) LNF(__bf16, 8); else LNF(__bf16, 12); }
+#undef LNF
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx_mode: 0 = write bf16, 1 = write f32, 2 = accumulate into f32 (residual-gradient stream).
+// dgamma/dbeta may be null (frozen LN); otherwise `workspace` must hold cs_layernorm_bwd_workspace(M,C) bytes.
+extern "C" size_t cs_layernorm_bwd_workspace(int M, int C) {
+    const int nwg = min(1024, (M + 3) / 4);
+    return (size_t)nwg * 2 * C * sizeof(float);
+}
+extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
+                                const float* rstd, void* dx, int dx_mode, long lddx, float* dgamma, float* dbeta,
+                                int accumulate_params, void* workspace, int M, int C, hipStream_t stream) {
+    CS_CHECK_ARG(C % 4 == 0 && C <= MAXC, "cs_layernorm_bwd: C=%d unsupported", C);
+    CS_CHECK_ARG(M > 0, "cs_layernorm_bwd: empty input");
+    CS_CHECK_ARG(dx_mode >= 0 && dx_mode <= 2, "cs_layernorm_bwd: bad dx_mode");
+    CS_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "cs_layernorm_bwd: dgamma/dbeta must both be given or both null");
+    CS_CHECK_ARG(dgamma == nullptr || workspace != nullptr, "cs_layernorm_bwd: workspace required for dgamma/dbeta");
+    const int nwg = min(1024, (M + 3) / 4);
+    float* part = dgamma ? (float*)workspace : nullptr;
+    const size_t lds = (size_t)3 * 2 * C * sizeof(float);
+    dim3 grid(nwg), block(256);
+#define LNB3(TX, MODE, NG)                                                                                                  \
+    do {                                                                                                                    \
+        static bool once = (hipFuncSetAttribute((const void*)ln_bwd_kernel<TX, MODE, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * MAXC * 4), true); \
+        (void)once;                                                                                                         \
+        hipLaunchKernelGGL((ln_bwd_kernel<TX, MODE, NG>), grid, block, lds, stream, (const __bf16*)dy, lddy, (const TX*)x, ldx, gamma, mean, rstd, dx, lddx, part, M, C); \
+    } while (0)
+#define LNB(TX, MODE) do { if (C <= 1024) LNB3(TX, MODE, 4); else if (C <= 2048) LNB3(TX, MODE, 8); else LNB3(TX, MODE, 12); } while (0)
+    if (x_dtype == 0) {
+        if (dx_mode == 0) LNB(float, DX_BF16); else if (dx_mode == 1) LNB(float, DX_F32_ASSIGN); else LNB(float, DX_F32_ACCUM);
+    } else {
+        if (dx_mode == 0) LNB(__bf16, DX_BF16); else if (dx_mode == 1) LNB(__bf16, DX_F32_ASSIGN); else LNB(__bf16, DX_F32_ACCUM);
+    }
+#undef LNB
+#undef LNB3
+    CS_LAUNCH_CHECK();
+    if (dgamma) {
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, part, nwg, C, dgamma, dbeta, accumulate_params);
+        CS_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int cs_l2norm_fwd(const float* x, float* y, float* inv_norm, int M, int C, float eps, hipStream_t stream) {
+    CS_CHECK_ARG(C % 4 == 0 && M > 0, "cs_l2norm_fwd: C must be a multiple of 4");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((M + ROWS_PER_WG - 1) / ROWS_PER_WG), dim3(256), 0, stream, x, y, inv_norm, M, C, eps);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cs_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, void* dx_bf16, int M, int C, hipStream_t stream) {
+    CS_CHECK_ARG(C % 4 == 0 && M > 0, "cs_l2norm_bwd: C must be a multiple of 4");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((M + ROWS_PER_WG - 1) / ROWS_PER_WG), dim3(256), 0, stream, dy, y, inv_norm, (__bf16*)dx_bf16, M, C);
+    CS_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,186 @@
+// RoIAlign(1x1, adaptive sampling, aligned) over the NHWC token map + row-wise cosine distillation loss (fwd/bwd).
+//
+// Reference call sites:
+//   src/open_clip/eva_clip/eva_vit_model.py:625-629,655-664   roi_align(x, boxes*[w,h], (1,1), 1.0, -1, True)[...,0,0]
+//   src/training/clipself.py:42-47                              F.normalize both, 1 - mean(sum(s*t))
+// The RoIAlign arithmetic itself is torchvision's (absent wheel); algorithm restated in oracle/roi_align_ref.py.
+//
+// MI355X layout: the student's token map stays token-major [B, Ntok, E] fp32 exactly as the head GEMM wrote it
+// (channels contiguous -> every sample row is a coalesced E*4-byte read); there is no NCHW view and no
+// .contiguous() copy.  Bilinear weights are separable, so each box first folds its gh x gw sample grid into
+// per-row / per-column weights Wy[h], Wx[w] (sequentially, fixed order -> deterministic) and then touches each
+// map cell at most once:   pooled = sum_{r,c} Wy[r] Wx[c] F[r,c] / max(gh*gw,1).
+#include "cs_common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+constexpr int MAXGRID = 128;   // token grid side limit (1024/8)
+
+// torchvision's per-axis sample handling, float32 like its T=float path
+__device__ void axis_weights(float start, float extent, int grid, int size, float* w /*[size]*/) {
+    for (int i = 0; i < size; ++i) w[i] = 0.f;
+    for (int i = 0; i < grid; ++i) {
+        // un-contracted float32 steps (no FMA), same order as torchvision / the numpy oracle
+        float c = __fadd_rn(start, __fdiv_rn(__fmul_rn((float)i + 0.5f, extent), (float)grid));
+        if (c < -1.0f || c > (float)size) continue;
+        if (c <= 0.f) c = 0.f;
+        int lo = (int)c, hi;
+        if (lo >= size - 1) { hi = lo = size - 1; c = (float)lo; } else { hi = lo + 1; }
+        const float l = __fsub_rn(c, (float)lo);
+        w[lo] += __fsub_rn(1.f, l);
+        w[hi] += l;
+    }
+}
+
+struct RoiGeom { int b, gh, gw; float inv_count; };
+
+__device__ __forceinline__ RoiGeom box_setup(const float* __restrict__ roi, int gh_map, int gw_map, float* Wy, float* Wx, int tid) {
+    // roi = (batch, x0, y0, x1, y1) with coordinates normalised to [0,1]; _denormalize_boxes multiplies by (w, h)
+    const float x0 = __fsub_rn(__fmul_rn(roi[1], (float)gw_map), 0.5f), y0 = __fsub_rn(__fmul_rn(roi[2], (float)gh_map), 0.5f);
+    const float x1 = __fsub_rn(__fmul_rn(roi[3], (float)gw_map), 0.5f), y1 = __fsub_rn(__fmul_rn(roi[4], (float)gh_map), 0.5f);
+    const float rw = __fsub_rn(x1, x0), rh = __fsub_rn(y1, y0);
+    RoiGeom g;
+    g.b = (int)roi[0];
+    g.gh = (int)ceilf(rh);
+    g.gw = (int)ceilf(rw);
+    const int cnt = g.gh * g.gw;
+    g.inv_count = 1.f / (float)(cnt > 1 ? cnt : 1);
+    if (tid == 0) axis_weights(y0, rh, g.gh > 0 ? g.gh : 0, gh_map, Wy);
+    if (tid == 64) axis_weights(x0, rw, g.gw > 0 ? g.gw : 0, gw_map, Wx);
+    return g;
+}
+
+// feat [B, Ntok, E] f32 (token 0 = CLS, skipped), rois [K,5], pooled [K,E] f32
+__global__ __launch_bounds__(256) void roialign_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ rois,
+                                                           float* __restrict__ pooled, int Ntok, int gh_map, int gw_map, int E, int tok_off) {
+    __shared__ float Wy[MAXGRID], Wx[MAXGRID];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const RoiGeom g = box_setup(rois + (size_t)k * 5, gh_map, gw_map, Wy, Wx, tid);
+    __syncthreads();
+    const bool empty = g.gh <= 0 || g.gw <= 0;
+    const float* fb = feat + ((size_t)g.b * Ntok + tok_off) * E;
+    for (int ch = tid * 4; ch < E; ch += 1024) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!empty) {
+            for (int r = 0; r < gh_map; ++r) {
+                const float wy = Wy[r];
+                if (wy == 0.f) continue;
+                for (int c = 0; c < gw_map; ++c) {
+                    const float w = wy * Wx[c];
+                    if (w == 0.f) continue;
+                    const float4 v = *(const float4*)(fb + (size_t)(r * gw_map + c) * E + ch);
+                    acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+                }
+            }
+        }
+        *(float4*)(pooled + (size_t)k * E + ch) = make_float4(acc.x * g.inv_count, acc.y * g.inv_count, acc.z * g.inv_count, acc.w * g.inv_count);
+    }
+}
+
+// dfeat [B, Ntok, E] f32 (pre-zeroed) += scatter of dpooled; overlapping boxes -> hardware float atomics
+__global__ __launch_bounds__(256) void roialign_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ rois,
+                                                           float* __restrict__ dfeat, int Ntok, int gh_map, int gw_map, int E, int tok_off) {
+    __shared__ float Wy[MAXGRID], Wx[MAXGRID];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const RoiGeom g = box_setup(rois + (size_t)k * 5, gh_map, gw_map, Wy, Wx, tid);
+    __syncthreads();
+    if (g.gh <= 0 || g.gw <= 0) return;
+    float* fb = dfeat + ((size_t)g.b * Ntok + tok_off) * E;
+    for (int ch = tid; ch < E; ch += 256) {
+        const float gv = dpooled[(size_t)k * E + ch] * g.inv_count;
+        for (int r = 0; r < gh_map; ++r) {
+            const float wy = Wy[r];
+            if (wy == 0.f) continue;
+            for (int c = 0; c < gw_map; ++c) {
+                const float w = wy * Wx[c];
+                if (w != 0.f) unsafeAtomicAdd(fb + (size_t)(r * gw_map + c) * E + ch, w * gv);
+            }
+        }
+    }
+}
+
+// ---- cosine loss ----------------------------------------------------------------------------
+// per box: cos_k = <s/|s|, t/|t|>  (F.normalize eps 1e-12).  stats[k] = (cos, 1/max(|s|,eps), 1/max(|t|,eps))
+__global__ __launch_bounds__(256) void cosine_rows_kernel(const float* __restrict__ s, const float* __restrict__ t, float* __restrict__ stats,
+                                                          int K, int E) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= K) return;
+    float ss = 0.f, tt = 0.f, st = 0.f;
+    for (int c = lane * 4; c < E; c += 256) {
+        const float4 a = *(const float4*)(s + (size_t)k * E + c), b = *(const float4*)(t + (size_t)k * E + c);
+        ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+        tt += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+        st += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    ss = wave_sum(ss); tt = wave_sum(tt); st = wave_sum(st);
+    const float is = 1.f / fmaxf(sqrtf(ss), 1e-12f), it = 1.f / fmaxf(sqrtf(tt), 1e-12f);
+    if (lane == 0) { stats[k * 3] = st * is * it; stats[k * 3 + 1] = is; stats[k * 3 + 2] = it; }
+}
+
+// loss = weight * (1 - mean_k cos_k); single workgroup, fixed-order tree -> deterministic
+__global__ __launch_bounds__(256) void cosine_reduce_kernel(const float* __restrict__ stats, float* __restrict__ loss, int K, float weight) {
+    __shared__ float part[256];
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) s += stats[k * 3];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = weight * (1.f - part[0] / (float)K);
+}
+
+// d loss / d s_k = -(weight*gscale/K) * (t_hat - cos_k * s_hat) / |s|
+__global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict__ s, const float* __restrict__ t, const float* __restrict__ stats,
+                                                         float* __restrict__ ds, int K, int E, float coef) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)K * E) return;
+    const int k = (int)(i / E);
+    const float cosv = stats[k * 3], is = stats[k * 3 + 1], it = stats[k * 3 + 2];
+    ds[i] = coef * (t[i] * it - cosv * s[i] * is) * is;
+}
+
+}  // namespace
+
+// C ABI ------------------------------------------------------------------------------------------
+// feat: token-major map [B, Ntok, E] f32; the grid occupies tokens tok_off .. tok_off+gh*gw-1 (tok_off = 1 skips CLS).
+// rois [K,5] f32 = (image index, x0, y0, x1, y1) with box coordinates normalised to [0,1] (reference batch contract).
+extern "C" int cs_roialign_fwd(const float* feat, const float* rois, float* pooled, int K, int Ntok, int grid_h, int grid_w, int E,
+                               int tok_off, hipStream_t stream) {
+    CS_CHECK_ARG(grid_h > 0 && grid_w > 0 && grid_h <= MAXGRID && grid_w <= MAXGRID && E % 4 == 0, "cs_roialign_fwd: bad grid/E");
+    CS_CHECK_ARG(tok_off + grid_h * grid_w <= Ntok, "cs_roialign_fwd: grid does not fit the token map");
+    if (K == 0) return 0;
+    hipLaunchKernelGGL(roialign_fwd_kernel, dim3(K), dim3(256), 0, stream, feat, rois, pooled, Ntok, grid_h, grid_w, E, tok_off);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cs_roialign_bwd(const float* dpooled, const float* rois, float* dfeat, int K, int Ntok, int grid_h, int grid_w, int E,
+                               int tok_off, hipStream_t stream) {
+    CS_CHECK_ARG(grid_h > 0 && grid_w > 0 && grid_h <= MAXGRID && grid_w <= MAXGRID, "cs_roialign_bwd: bad grid");
+    CS_CHECK_ARG(tok_off + grid_h * grid_w <= Ntok, "cs_roialign_bwd: grid does not fit the token map");
+    if (K == 0) return 0;
+    hipLaunchKernelGGL(roialign_bwd_kernel, dim3(K), dim3(256), 0, stream, dpooled, rois, dfeat, Ntok, grid_h, grid_w, E, tok_off);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+// stats: workspace [K,3] f32 kept for the backward.
+extern "C" int cs_cosine_loss_fwd(const float* student, const float* teacher, float* stats, float* loss, int K, int E, float weight,
+                                  hipStream_t stream) {
+    CS_CHECK_ARG(K > 0 && E % 4 == 0, "cs_cosine_loss_fwd: need K > 0 and E %% 4 == 0");
+    hipLaunchKernelGGL(cosine_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, student, teacher, stats, K, E);
+    CS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cosine_reduce_kernel, dim3(1), dim3(256), 0, stream, stats, loss, K, weight);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cs_cosine_loss_bwd(const float* student, const float* teacher, const float* stats, float* dstudent, int K, int E,
+                                  float weight, float grad_scale, hipStream_t stream) {
+    CS_CHECK_ARG(K > 0, "cs_cosine_loss_bwd: K must be positive");
+    const float coef = -weight * grad_scale / (float)K;
+    hipLaunchKernelGGL(cosine_bwd_kernel, dim3((int)(((long)K * E + 255) / 256)), dim3(256), 0, stream, student, teacher, stats, dstudent, K, E, coef);
+    CS_LAUNCH_CHECK();
+    return 0;
+}

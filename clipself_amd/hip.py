@@ -1,0 +1,245 @@
+"""ctypes binding of the C-ABI kernel library (include/clipself_hip.h) + a thin tensor-level wrapper.
+
+PyTorch is used here only as plumbing: device allocation (`torch.empty(device='cuda')`), the current HIP stream
+and `torch.distributed`.  Every op below is one call into libclipself_hip.so with raw device pointers.
+
+There is NO fallback: if the library is missing or a tensor is not on the GPU the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import torch
+
+_CSRC = Path(__file__).resolve().parent / "csrc"
+_LIB_PATH = _CSRC / "libclipself_hip.so"
+
+EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32 = range(6)
+DX_BF16, DX_F32_ASSIGN, DX_F32_ACCUM = range(3)
+
+_vp, _i, _l, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol declared in include/clipself_hip.h
+SIGNATURES = {
+    "cs_last_error": (ctypes.c_char_p, []),
+    "cs_gemm_nt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cs_layernorm_fwd": (_i, [_vp, _i, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _vp]),
+    "cs_layernorm_bwd_workspace": (_sz, [_i, _i]),
+    "cs_layernorm_bwd": (_i, [_vp, _l, _vp, _i, _l, _vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "cs_l2norm_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    "cs_l2norm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "cs_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "cs_attn_bwd_workspace": (_sz, [_i, _i, _i]),
+    "cs_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "cs_swiglu_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
+    "cs_swiglu_bwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _vp]),
+    "cs_cast_f32_bf16": (_i, [_vp, _vp, _l, _vp]),
+    "cs_transpose_bf16": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
+    "cs_colsum_bf16": (_i, [_vp, _l, _vp, _i, _i, _vp]),
+    "cs_im2row": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "cs_cls_row": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "cs_roialign_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cs_roialign_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cs_cosine_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "cs_cosine_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
+    "cs_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp]),
+}
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def build_library(force: bool = False) -> Path:
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        for o in _CSRC.glob("_obj_*.o"):
+            o.unlink()
+    subprocess.run(["bash", str(_CSRC / "build.sh")], check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: build it with clipself_amd/csrc/build.sh (or __graft_entry__.build()). "
+                "There is no CPU fallback for the CLIPSelf hot path.")
+        lib = ctypes.CDLL(str(_LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dt(t) -> int:
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+class HipOps:
+    """Tensor-level face of the C ABI.  Tensors are 2-D (rows, cols) views whose last stride is 1; row strides
+    become the `ld*` arguments.  Outputs are written in place into caller-allocated tensors."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipOps needs a ROCm device (torch.cuda.is_available() is False); no CPU fallback exists")
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def _ok(self, rc, who):
+        if rc != 0:
+            raise RuntimeError(f"{who} failed ({rc}): {self.lib.cs_last_error().decode()}")
+
+    @staticmethod
+    def _chk(*ts):
+        for t in ts:
+            if t is not None and not t.is_cuda:
+                raise RuntimeError("HipOps received a non-GPU tensor; the hot path has no CPU fallback")
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device="cuda")
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device="cuda")
+
+    # -- ops -------------------------------------------------------------------------------------
+    def gemm_nt(self, A, B, C, bias=None, extra=None, epi=EPI_BF16, splits=1, group=0, flags=0):
+        self._chk(A, B, C, bias, extra)
+        M, K = A.shape
+        N = B.shape[0]
+        assert B.shape[1] == K and A.stride(1) == 1 and B.stride(1) == 1 and C.stride(-1) == 1
+        if extra is not None and epi in (EPI_RESID_F32, EPI_PATCH_F32):
+            assert extra.stride(0) == C.stride(0), "extra must share C's row stride"
+        self._ok(self.lib.cs_gemm_nt(_p(A), _p(B), _p(C), _p(bias), _p(extra), M, N, K, A.stride(0), B.stride(0),
+                                     C.stride(0), epi, splits, group, flags, self._stream()), "cs_gemm_nt")
+
+    def layernorm_fwd(self, x, gamma, beta, y, mean=None, rstd=None, eps=1e-6):
+        self._chk(x, gamma, beta, y, mean, rstd)
+        M, C = x.shape
+        self._ok(self.lib.cs_layernorm_fwd(_p(x), _dt(x), x.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0),
+                                           _p(mean), _p(rstd), M, C, eps, self._stream()), "cs_layernorm_fwd")
+
+    def layernorm_bwd_workspace(self, M, C) -> int:
+        return int(self.lib.cs_layernorm_bwd_workspace(M, C))
+
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dx_mode, dgamma=None, dbeta=None, accumulate=False, workspace=None):
+        self._chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace)
+        M, C = x.shape
+        self._ok(self.lib.cs_layernorm_bwd(_p(dy), dy.stride(0), _p(x), _dt(x), x.stride(0), _p(gamma), _p(mean), _p(rstd),
+                                           _p(dx), dx_mode, dx.stride(0), _p(dgamma), _p(dbeta), int(accumulate),
+                                           _p(workspace), M, C, self._stream()), "cs_layernorm_bwd")
+
+    def l2norm_fwd(self, x, y, inv_norm, eps=1e-12):
+        self._chk(x, y, inv_norm)
+        M, C = x.shape
+        assert x.is_contiguous() and y.is_contiguous()
+        self._ok(self.lib.cs_l2norm_fwd(_p(x), _p(y), _p(inv_norm), M, C, eps, self._stream()), "cs_l2norm_fwd")
+
+    def l2norm_bwd(self, dy, y, inv_norm, dx):
+        self._chk(dy, y, inv_norm, dx)
+        M, C = y.shape
+        assert dy.is_contiguous() and y.is_contiguous() and dx.is_contiguous()
+        self._ok(self.lib.cs_l2norm_bwd(_p(dy), _p(y), _p(inv_norm), _p(dx), M, C, self._stream()), "cs_l2norm_bwd")
+
+    def attn_fwd(self, qkv, cos, sin, out, lse, B, Ntok, H, scale):
+        self._chk(qkv, cos, sin, out, lse)
+        self._ok(self.lib.cs_attn_fwd(_p(qkv), _p(cos), _p(sin), _p(out), _p(lse), B, Ntok, H, qkv.stride(0), out.stride(0),
+                                      scale, self._stream()), "cs_attn_fwd")
+
+    def attn_bwd_workspace(self, B, Ntok, H) -> int:
+        return int(self.lib.cs_attn_bwd_workspace(B, Ntok, H))
+
+    def attn_bwd(self, qkv, o, dout, lse, cos, sin, dqkv, workspace, B, Ntok, H, scale):
+        self._chk(qkv, o, dout, lse, cos, sin, dqkv, workspace)
+        assert o.stride(0) == dout.stride(0) and qkv.stride(0) == dqkv.stride(0)
+        self._ok(self.lib.cs_attn_bwd(_p(qkv), _p(o), _p(dout), _p(lse), _p(cos), _p(sin), _p(dqkv), _p(workspace), B, Ntok, H,
+                                      qkv.stride(0), o.stride(0), scale, self._stream()), "cs_attn_bwd")
+
+    def swiglu_fwd(self, x12, h):
+        self._chk(x12, h)
+        M, Hd = h.shape
+        self._ok(self.lib.cs_swiglu_fwd(_p(x12), x12.stride(0), _p(h), h.stride(0), M, Hd, self._stream()), "cs_swiglu_fwd")
+
+    def swiglu_bwd(self, dh, x12, dx12):
+        self._chk(dh, x12, dx12)
+        M, Hd = dh.shape
+        self._ok(self.lib.cs_swiglu_bwd(_p(dh), dh.stride(0), _p(x12), x12.stride(0), _p(dx12), dx12.stride(0), M, Hd,
+                                        self._stream()), "cs_swiglu_bwd")
+
+    def cast_f32_bf16(self, x, y):
+        self._chk(x, y)
+        assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+        self._ok(self.lib.cs_cast_f32_bf16(_p(x), _p(y), x.numel(), self._stream()), "cs_cast_f32_bf16")
+
+    def transpose_bf16(self, inp, out):
+        """out[c, r] = inp[r, c]; out is [Cc, ld_out >= R] and columns R.. are zero-filled."""
+        self._chk(inp, out)
+        R, Cc = inp.shape
+        assert out.shape[0] == Cc and out.is_contiguous()
+        self._ok(self.lib.cs_transpose_bf16(_p(inp), inp.stride(0), _p(out), out.shape[1], R, Cc, self._stream()), "cs_transpose_bf16")
+
+    def colsum_bf16(self, x, out):
+        self._chk(x, out)
+        M, N = x.shape
+        self._ok(self.lib.cs_colsum_bf16(_p(x), x.stride(0), _p(out), M, N, self._stream()), "cs_colsum_bf16")
+
+    def im2row(self, img, out, p):
+        self._chk(img, out)
+        B, _, S, _ = img.shape
+        assert img.is_contiguous()
+        self._ok(self.lib.cs_im2row(_p(img), _dt(img), _p(out), B, S, p, out.stride(0), self._stream()), "cs_im2row")
+
+    def cls_row(self, x, cls, pos):
+        self._chk(x, cls, pos)
+        B, Ntok, C = x.shape
+        self._ok(self.lib.cs_cls_row(_p(x), _p(cls), _p(pos), B, Ntok, C, self._stream()), "cs_cls_row")
+
+    def roialign_fwd(self, feat, rois, pooled, grid_h, grid_w, tok_off):
+        self._chk(feat, rois, pooled)
+        B, Ntok, E = feat.shape
+        self._ok(self.lib.cs_roialign_fwd(_p(feat), _p(rois), _p(pooled), rois.shape[0], Ntok, grid_h, grid_w, E, tok_off,
+                                          self._stream()), "cs_roialign_fwd")
+
+    def roialign_bwd(self, dpooled, rois, dfeat, grid_h, grid_w, tok_off):
+        self._chk(dpooled, rois, dfeat)
+        B, Ntok, E = dfeat.shape
+        self._ok(self.lib.cs_roialign_bwd(_p(dpooled), _p(rois), _p(dfeat), rois.shape[0], Ntok, grid_h, grid_w, E, tok_off,
+                                          self._stream()), "cs_roialign_bwd")
+
+    def cosine_loss_fwd(self, student, teacher, stats, loss, weight):
+        self._chk(student, teacher, stats, loss)
+        K, E = student.shape
+        self._ok(self.lib.cs_cosine_loss_fwd(_p(student), _p(teacher), _p(stats), _p(loss), K, E, weight, self._stream()),
+                 "cs_cosine_loss_fwd")
+
+    def cosine_loss_bwd(self, student, teacher, stats, dstudent, weight, grad_scale=1.0):
+        self._chk(student, teacher, stats, dstudent)
+        K, E = student.shape
+        self._ok(self.lib.cs_cosine_loss_bwd(_p(student), _p(teacher), _p(stats), _p(dstudent), K, E, weight, grad_scale,
+                                             self._stream()), "cs_cosine_loss_bwd")
+
+    def adamw_step(self, p, g, m, v, shadow, flags, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+        self._chk(p, g, m, v, shadow, flags)
+        self._ok(self.lib.cs_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), _p(flags), p.numel(), lr, beta1, beta2, eps, wd,
+                                        step, grad_scale, self._stream()), "cs_adamw_step")

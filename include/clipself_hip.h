@@ -1,0 +1,94 @@
+/* C ABI of libclipself_hip.so -- the drop-in seam under the CLIPSelf hot path.
+ *
+ * The reference (wusize/CLIPSelf) is pure Python and has no FFI of its own; the native code it reaches lives in
+ * third-party wheels (cuBLAS/cuDNN via torch, torchvision roi_align, xformers attention, apex LayerNorm).  Each
+ * entry point below names the reference call site(s) (file:line under /root/reference) whose kernel it replaces.
+ *
+ * Conventions: plain pointers + sizes, no torch types; every buffer (incl. workspaces) is caller-allocated device
+ * memory; launches are asynchronous on `stream`; return 0 on success, negative on error (message via
+ * cs_last_error(), thread-local); no global mutable state; re-entrant from any thread that owns the stream.
+ * bf16 tensors are passed as `void*` / `const void*`.  Row-major everywhere; `ld*` are row strides in elements.
+ */
+#ifndef CLIPSELF_HIP_H
+#define CLIPSELF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* cs_stream_t; /* == hipStream_t */
+
+const char* cs_last_error(void);
+
+/* --- matmuls: F.linear at src/open_clip/eva_clip/eva_vit_model.py:99-103 (SwiGLU w1,w2,w3), :177-179 (q/k/v proj),
+ *     :219/:253 (attn proj), :250 (v-only proj of the last dense block), :585/:617 (head), nn.Conv2d patch embed :348,355
+ *     (as im2row GEMM), and their autograd backward (dgrad / wgrad).
+ * C[M,N] (+epilogue) = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulation.  K % 64 == 0, lda/ldb % 8 == 0.
+ * epi: 0 bf16 = acc+bias | 1 f32 = acc+bias | 2 f32 = extra(residual)+acc+bias (in-place allowed) |
+ *      3 fused SwiGLU: B=[W1;W2] [2*group,K], bias [2*group], out bf16 [M,group] = silu(x1)*x2 |
+ *      4 f32 atomic accumulate (split-K allowed, `splits` >= 1) |
+ *      5 patch embed: out row = row + row/group + 1, value += extra[(row%group+1)*ldc + col]   (cls/pos layout :540-543)
+ * flags bit0: use register staging instead of the global_load_lds DMA path. */
+int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
+               int lda, int ldb, int ldc, int epi, int splits, int group, int flags, cs_stream_t stream);
+
+/* --- LayerNorm(eps, biased var): src/open_clip/eva_clip/transformer.py:52-58 used at eva_vit_model.py:306-307 (norm1/2),
+ *     :218 (inner_attn_ln), :102 (ffn_ln), :565/:616 (final norm); replaces apex FusedLayerNorm / F.layer_norm.
+ * x_dtype 0=f32 1=bf16; y bf16; mean/rstd [M] f32 (nullable when no backward is needed). */
+int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                     float* mean, float* rstd, int M, int C, float eps, cs_stream_t stream);
+size_t cs_layernorm_bwd_workspace(int M, int C);
+/* dx_mode 0: bf16 write, 1: f32 write, 2: f32 accumulate (residual gradient stream).  dgamma/dbeta nullable (frozen). */
+int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
+                     const float* rstd, void* dx, int dx_mode, long lddx, float* dgamma, float* dbeta, int accumulate_params,
+                     void* workspace, int M, int C, cs_stream_t stream);
+
+/* --- F.normalize(x, dim=-1) of the dense token map: eva_vit_model.py:620 (eps 1e-12) and its backward. */
+int cs_l2norm_fwd(const float* x, float* y, float* inv_norm, int M, int C, float eps, cs_stream_t stream);
+int cs_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, void* dx_bf16, int M, int C, cs_stream_t stream);
+
+/* --- attention core: xops.memory_efficient_attention / softmax math branch at eva_vit_model.py:198-243 together with
+ *     VisionRotaryEmbeddingFast.forward (src/open_clip/eva_clip/rope.py:148-164) on q,k tokens 1.. ; head dim 64.
+ * qkv [B*Ntok, ldqkv] bf16 = q|k|v (bias added, not rotated); cos/sin [(Ntok-1),64] f32; out [B*Ntok, ldo] bf16;
+ * lse [B*H, Ntok] f32 (nullable in inference). */
+int cs_attn_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* out, float* lse, int B, int Ntok, int H,
+                int ldqkv, int ldo, float scale, cs_stream_t stream);
+size_t cs_attn_bwd_workspace(int B, int Ntok, int H);
+int cs_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* cos_t, const float* sin_t,
+                void* dqkv, void* workspace, int B, int Ntok, int H, int ldqkv, int ldo, float scale, cs_stream_t stream);
+
+/* --- SwiGLU elementwise: eva_vit_model.py:101  hidden = silu(x1) * x2   (x12 = [x1 | x2], each Hd wide) */
+int cs_swiglu_fwd(const void* x12, long ldx, void* h, long ldh, int M, int Hd, cs_stream_t stream);
+int cs_swiglu_bwd(const void* dh, long lddh, const void* x12, long ldx, void* dx12, long lddx, int M, int Hd, cs_stream_t stream);
+
+/* --- data movement helpers of the step */
+int cs_cast_f32_bf16(const float* x, void* y, long n, cs_stream_t stream);
+int cs_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int Cc, cs_stream_t stream); /* out[c,r]; zero pad r in [R, ld_out) */
+int cs_colsum_bf16(const void* x, long ldx, float* out, int M, int N, cs_stream_t stream);                    /* out[n] += sum_m x[m,n] (bias grads) */
+int cs_im2row(const void* img, int img_dtype, void* out, int B, int S, int p, int ldo, cs_stream_t stream);    /* PatchEmbed unfold, eva_vit_model.py:355 */
+int cs_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok, int C, cs_stream_t stream);      /* x[b,0,:] = cls + pos[0], :540-543 */
+
+/* --- RoIAlign 1x1 / aligned / adaptive sampling on the token-major map: torchvision.ops.roi_align called at
+ *     eva_vit_model.py:628-629 with boxes from _denormalize_boxes :655-664 (boxes given normalised to [0,1]). */
+int cs_roialign_fwd(const float* feat, const float* rois, float* pooled, int K, int Ntok, int grid_h, int grid_w, int E,
+                    int tok_off, cs_stream_t stream);
+int cs_roialign_bwd(const float* dpooled, const float* rois, float* dfeat, int K, int Ntok, int grid_h, int grid_w, int E,
+                    int tok_off, cs_stream_t stream);
+
+/* --- cosine distillation loss: src/training/clipself.py:42-47.  stats [K,3] f32 workspace kept for the backward. */
+int cs_cosine_loss_fwd(const float* student, const float* teacher, float* stats, float* loss, int K, int E, float weight,
+                       cs_stream_t stream);
+int cs_cosine_loss_bwd(const float* student, const float* teacher, const float* stats, float* dstudent, int K, int E,
+                       float weight, float grad_scale, cs_stream_t stream);
+
+/* --- optimizer: torch.optim.AdamW built at src/training/main.py:198-213, stepped at src/training/train.py:115.
+ * Flat fp32 master/grad/moment buffers; flags[n/256]: bit0 = tensor has a gradient this step, bit1 = weight decay applies. */
+int cs_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, const uint8_t* flags, long n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, cs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

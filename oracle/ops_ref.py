@@ -1,0 +1,248 @@
+"""TEST INFRASTRUCTURE -- CPU oracle, never imported by the product path.
+
+Per-kernel references: one plain-torch (fp32 math) restatement for every entry point of the C ABI
+(include/clipself_hip.h), with the *same tensor-level signature* as clipself_amd.hip.HipOps, writing into the
+caller's output tensors.  Used (a) by the `-m gpu` tests to check each HIP kernel in isolation on identical inputs
+and (b) by the CPU tests to run the step engine's op decomposition (clipself_amd/engine.py) against the monolithic
+oracle (oracle/eva_ref.py) -- i.e. to prove on CPU that the hand-written backward chain is the true gradient.
+
+Reference file:line for each op is the same as listed in include/clipself_hip.h.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .roi_align_ref import roi_align_1x1
+
+EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32 = range(6)
+DX_BF16, DX_F32_ASSIGN, DX_F32_ACCUM = range(3)
+
+
+def _rope_rows(t, cos, sin, inverse=False):
+    """t [..., N, d]; rows 1.. rotated by tables [(N-1), d] (rope.py:25-29,163-164); inverse = transpose rotation."""
+    body = t[..., 1:, :]
+    pairs = body.reshape(*body.shape[:-1], -1, 2)
+    c = cos.reshape(cos.shape[0], -1, 2)
+    s = sin.reshape(sin.shape[0], -1, 2)
+    x0, x1 = pairs[..., 0], pairs[..., 1]
+    if not inverse:
+        y0 = x0 * c[..., 0] - x1 * s[..., 0]
+        y1 = x1 * c[..., 1] + x0 * s[..., 1]
+    else:
+        y0 = x0 * c[..., 0] + x1 * s[..., 1]
+        y1 = x1 * c[..., 1] - x0 * s[..., 0]
+    out = torch.stack((y0, y1), dim=-1).flatten(-2)
+    return torch.cat((t[..., :1, :], out), dim=-2)
+
+
+class RefOps:
+    name = "ref"
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype)
+
+    # ------------------------------------------------------------------------------------------
+    def gemm_nt(self, A, B, C, bias=None, extra=None, epi=EPI_BF16, splits=1, group=0, flags=0):
+        acc = A.float() @ B.float().T
+        if epi == EPI_SWIGLU_BF16:
+            if bias is not None:
+                acc = acc + bias
+            x1, x2 = acc[:, :group], acc[:, group:]
+            C.copy_((F.silu(x1) * x2).to(torch.bfloat16))
+            return
+        if bias is not None:
+            acc = acc + bias
+        if epi == EPI_BF16:
+            C.copy_(acc.to(torch.bfloat16))
+        elif epi == EPI_F32:
+            C.copy_(acc)
+        elif epi == EPI_RESID_F32:
+            C.copy_(extra + acc)
+        elif epi == EPI_ATOMIC_F32:
+            C.add_(acc)
+        elif epi == EPI_PATCH_F32:
+            M, N = acc.shape
+            nimg = M // group
+            out = C.reshape(nimg, group + 1, -1)
+            out[:, 1:, :N] = acc.reshape(nimg, group, N) + extra[1:group + 1, :N]
+        else:
+            raise ValueError(epi)
+
+    def layernorm_fwd(self, x, gamma, beta, y, mean=None, rstd=None, eps=1e-6):
+        xf = x.float()
+        mu = xf.mean(-1, keepdim=True)
+        var = ((xf - mu) ** 2).mean(-1, keepdim=True)
+        r = torch.rsqrt(var + eps)
+        y.copy_(((xf - mu) * r * gamma + beta).to(torch.bfloat16))
+        if mean is not None:
+            mean.copy_(mu[:, 0])
+            rstd.copy_(r[:, 0])
+
+    def layernorm_bwd_workspace(self, M, C):
+        return 4
+
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dx_mode, dgamma=None, dbeta=None, accumulate=False, workspace=None):
+        xh = (x.float() - mean[:, None]) * rstd[:, None]
+        g = dy.float()
+        gy = g * gamma
+        m1 = gy.mean(-1, keepdim=True)
+        m2 = (gy * xh).mean(-1, keepdim=True)
+        d = rstd[:, None] * (gy - m1 - xh * m2)
+        if dx_mode == DX_BF16:
+            dx.copy_(d.to(torch.bfloat16))
+        elif dx_mode == DX_F32_ASSIGN:
+            dx.copy_(d)
+        else:
+            dx.add_(d)
+        if dgamma is not None:
+            if accumulate:
+                dgamma.add_((g * xh).sum(0))
+                dbeta.add_(g.sum(0))
+            else:
+                dgamma.copy_((g * xh).sum(0))
+                dbeta.copy_(g.sum(0))
+
+    def l2norm_fwd(self, x, y, inv_norm, eps=1e-12):
+        inv = 1.0 / x.norm(dim=-1).clamp_min(eps)
+        y.copy_(x * inv[:, None])
+        if inv_norm is not None:
+            inv_norm.copy_(inv)
+
+    def l2norm_bwd(self, dy, y, inv_norm, dx):
+        dot = (dy * y).sum(-1, keepdim=True)
+        dx.copy_(((dy - y * dot) * inv_norm[:, None]).to(torch.bfloat16))
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _split_heads(qkv, B, Ntok, H):
+        C = H * 64
+        t = qkv[:, :3 * C].float().reshape(B, Ntok, 3, H, 64).permute(2, 0, 3, 1, 4)
+        return t[0], t[1], t[2]
+
+    @staticmethod
+    def _r(t):
+        return t.to(torch.bfloat16).float()
+
+    def _attn_core(self, qkv, cos, sin, B, Ntok, H, scale):
+        q, k, v = self._split_heads(qkv, B, Ntok, H)
+        q = self._r(_rope_rows(q, cos, sin))
+        k = self._r(_rope_rows(k, cos, sin))
+        s = (q @ k.transpose(-1, -2)) * scale
+        lse = torch.logsumexp(s, dim=-1)
+        p = torch.exp(s - lse[..., None])
+        return q, k, v, p, lse
+
+    def attn_fwd(self, qkv, cos, sin, out, lse, B, Ntok, H, scale):
+        q, k, v, p, l = self._attn_core(qkv, cos, sin, B, Ntok, H, scale)
+        # the kernel feeds un-normalised bf16 probabilities exp(s - max) to the PV MFMA and divides by the fp32 row sum
+        s = (q @ k.transpose(-1, -2)) * scale
+        mx = s.max(-1, keepdim=True).values
+        e = torch.exp(s - mx)
+        o = (self._r(e) @ v) / e.sum(-1, keepdim=True)
+        out.copy_(o.permute(0, 2, 1, 3).reshape(B * Ntok, H * 64).to(torch.bfloat16))
+        if lse is not None:
+            lse.copy_(l.reshape(B * H, Ntok))
+
+    def attn_bwd_workspace(self, B, Ntok, H):
+        return 4
+
+    def attn_bwd(self, qkv, o, dout, lse, cos, sin, dqkv, workspace, B, Ntok, H, scale):
+        q, k, v, p, _ = self._attn_core(qkv, cos, sin, B, Ntok, H, scale)
+        do = dout.float().reshape(B, Ntok, H, 64).permute(0, 2, 1, 3)
+        of = o.float().reshape(B, Ntok, H, 64).permute(0, 2, 1, 3)
+        dsum = (do * of).sum(-1, keepdim=True)
+        dv = self._r(p).transpose(-1, -2) @ do
+        dp = do @ v.transpose(-1, -2)
+        ds = self._r(p * (dp - dsum) * scale)
+        dq = _rope_rows(ds @ k, cos, sin, inverse=True)
+        dk = _rope_rows(ds.transpose(-1, -2) @ q, cos, sin, inverse=True)
+        full = torch.stack((dq, dk, dv), dim=0).permute(1, 3, 0, 2, 4).reshape(B * Ntok, 3 * H * 64)
+        dqkv[:, :3 * H * 64] = full.to(torch.bfloat16)
+
+    # ------------------------------------------------------------------------------------------
+    def swiglu_fwd(self, x12, h):
+        Hd = h.shape[1]
+        x1, x2 = x12[:, :Hd].float(), x12[:, Hd:2 * Hd].float()
+        h.copy_((F.silu(x1) * x2).to(torch.bfloat16))
+
+    def swiglu_bwd(self, dh, x12, dx12):
+        Hd = dh.shape[1]
+        x1, x2, d = x12[:, :Hd].float(), x12[:, Hd:2 * Hd].float(), dh.float()
+        sig = torch.sigmoid(x1)
+        dx12[:, :Hd] = (d * x2 * (sig + x1 * sig * (1 - sig))).to(torch.bfloat16)
+        dx12[:, Hd:2 * Hd] = (d * x1 * sig).to(torch.bfloat16)
+
+    def cast_f32_bf16(self, x, y):
+        y.copy_(x.to(torch.bfloat16))
+
+    def transpose_bf16(self, inp, out):
+        R = inp.shape[0]
+        out.zero_()
+        out[:, :R] = inp.T
+
+    def colsum_bf16(self, x, out):
+        out.add_(x.float().sum(0))
+
+    def im2row(self, img, out, p):
+        B, _, S, _ = img.shape
+        g = S // p
+        patches = img.float().reshape(B, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B * g * g, 3 * p * p)
+        out[:, :3 * p * p] = patches.to(torch.bfloat16)
+
+    def cls_row(self, x, cls, pos):
+        x[:, 0, :] = cls + pos[0]
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _rois_pixels(rois, grid_h, grid_w):
+        r = rois.detach().float().clone()
+        r[:, [1, 3]] *= grid_w
+        r[:, [2, 4]] *= grid_h
+        return r
+
+    def roialign_fwd(self, feat, rois, pooled, grid_h, grid_w, tok_off):
+        B, Ntok, E = feat.shape
+        fmap = feat[:, tok_off:tok_off + grid_h * grid_w].reshape(B, grid_h, grid_w, E)
+        pooled.copy_(roi_align_1x1(fmap, self._rois_pixels(rois, grid_h, grid_w)))
+
+    def roialign_bwd(self, dpooled, rois, dfeat, grid_h, grid_w, tok_off):
+        B, Ntok, E = dfeat.shape
+        probe = torch.zeros(B, grid_h, grid_w, E, requires_grad=True)
+        out = roi_align_1x1(probe, self._rois_pixels(rois, grid_h, grid_w))
+        (g,) = torch.autograd.grad(out, probe, dpooled)
+        dfeat[:, tok_off:tok_off + grid_h * grid_w] += g.reshape(B, grid_h * grid_w, E)
+
+    def cosine_loss_fwd(self, student, teacher, stats, loss, weight):
+        ns, nt = student.norm(dim=-1).clamp_min(1e-12), teacher.norm(dim=-1).clamp_min(1e-12)
+        cos = (student * teacher).sum(-1) / (ns * nt)
+        stats[:, 0] = cos
+        stats[:, 1] = 1.0 / ns
+        stats[:, 2] = 1.0 / nt
+        loss[0] = weight * (1.0 - cos.mean())
+
+    def cosine_loss_bwd(self, student, teacher, stats, dstudent, weight, grad_scale=1.0):
+        K = student.shape[0]
+        cos, i_s, i_t = stats[:, 0:1], stats[:, 1:2], stats[:, 2:3]
+        dstudent.copy_((-weight * grad_scale / K) * (teacher * i_t - cos * student * i_s) * i_s)
+
+    def adamw_step(self, p, g, m, v, shadow, flags, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+        act = (flags & 1).bool().repeat_interleave(256)
+        dec = (flags & 2).bool().repeat_interleave(256)
+        gg = g * grad_scale
+        bc1 = 1.0 - beta1 ** step
+        bc2s = math.sqrt(1.0 - beta2 ** step)
+        pn = torch.where(dec, p * (1.0 - lr * wd), p)
+        mn = beta1 * m + (1 - beta1) * gg
+        vn = beta2 * v + (1 - beta2) * gg * gg
+        pn = pn - (lr / bc1) * (mn / (vn.sqrt() / bc2s + eps))
+        p.copy_(torch.where(act, pn, p))
+        m.copy_(torch.where(act, mn, m))
+        v.copy_(torch.where(act, vn, v))
+        if shadow is not None:
+            shadow.copy_(torch.where(act, p.to(torch.bfloat16), shadow))
