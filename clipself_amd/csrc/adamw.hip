@@ -3,9 +3,9 @@
 // (no-decay group = ndim<2 / "ln" / "bias" / "logit_scale"; decay group wd=args.wd), stepped at train.py:115;
 // parameters whose grad is None are skipped entirely (no decay either) -- SURVEY.md D7.
 //
-// MI355X layout: all trainable parameters live in ONE fp32 master buffer (every tensor starts on a 256-element
-// boundary) with same-layout fp32 grad / exp_avg / exp_avg_sq buffers and a same-layout bf16 "shadow" that the
-// MFMA GEMMs read.  A per-256-element chunk flag byte carries (bit0) "has a gradient this step" and (bit1)
+// MI355X layout: all trainable parameters live in ONE fp32 master buffer (every tensor starts on a 64-element
+// boundary, total padded to 256) with same-layout fp32 grad / exp_avg / exp_avg_sq buffers and a same-layout bf16 "shadow" that the
+// MFMA GEMMs read.  A flag byte per 64 elements carries (bit0) "has a gradient this step" and (bit1)
 // "weight decay applies".  The kernel is a pure HBM stream: 4 fp32 reads + 3 fp32 writes + 1 bf16 write per element.
 #include "cs_common.h"
 
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     // one wave per 256-element chunk, 4 elements per lane
     const long chunk = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (chunk >= a.nchunks) return;
-    const uint8_t f = a.flags[chunk];
+    const uint8_t f = a.flags[chunk * 4 + ((threadIdx.x & 63) >> 4)];   // one flag byte per 64 elements (= 16 lanes)
     if (!(f & 1)) return;
     const long i = chunk * 256 + (threadIdx.x & 63) * 4;
     float4 p = *(const float4*)(a.p + i);
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 
 }  // namespace
 
-// n must be a multiple of 256; flags has n/256 bytes (bit0 = active, bit1 = decay).  `step` is the 1-based AdamW
+// n must be a multiple of 256; flags has n/64 bytes (bit0 = active, bit1 = decay).  `step` is the 1-based AdamW
 // step count (bias corrections computed here in double like torch's scalar path).
 extern "C" int cs_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, const uint8_t* flags, long n,
                              float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,

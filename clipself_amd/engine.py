@@ -1,0 +1,464 @@
+"""Step engine of the EVA02 vision tower on the CLIPSelf hot path: an explicit forward / hand-written backward
+schedule over the C-ABI kernels (clipself_amd/hip.py), with all parameters in flat buffers.
+
+No tracing compiler and no autograd graph inside the tower: the schedule below *is* the program.  What each stage
+computes, and where the reference does it (paths under /root/reference/src/open_clip/eva_clip/):
+
+  stem            eva_vit_model.py:537-544   patch-embed conv (im2row + GEMM) + cls_token + pos_embed
+  block           eva_vit_model.py:300-307   x += attn(norm1(x)); x += mlp(norm2(x))
+  attention       eva_vit_model.py:174-247   q/k/v proj (+q_bias, none, +v_bias) -> RoPE(q,k) -> softmax(qk^T/8)v
+                                              -> inner_attn_ln -> proj                 (rope.py:148-164)
+  last dense blk  eva_vit_model.py:249-256,317-324   proj(inner_attn_ln(v_proj(norm1 x)+v_bias)), no attention
+  SwiGLU          eva_vit_model.py:98-105    w3(ffn_ln(silu(w1 x) * (w2 x)))
+  teacher head    eva_vit_model.py:565-569,585   head(norm(x)[:,0])
+  dense head      eva_vit_model.py:615-623   normalize(head(norm(x[:,1:])))
+  RoI pooling     eva_vit_model.py:625-629,655-664
+
+Memory layout (MI355X: 288 GB HBM3E -- nothing is recomputed, nothing is re-laid-out):
+  * one fp32 master buffer for every parameter of the tower, tensors back-to-back on 64-element boundaries, in
+    layer order; [Wq;Wk;Wv], [q_bias;0;v_bias], [W1;W2], [b1;b2] are *adjacent* so the fused QKV / SwiGLU GEMMs read
+    them as single matrices without any packing step;
+  * a same-layout bf16 shadow (MFMA operand), and for the student same-layout fp32 grad / exp_avg / exp_avg_sq (one
+    flat AdamW launch, one contiguous all-reduce bucket per block) plus transposed bf16 shadows for the dgrad GEMMs;
+  * residual stream fp32 [B*N, C]; every GEMM operand bf16; LayerNorm / softmax statistics fp32.
+
+The engine is backend-agnostic on purpose: `ops` is clipself_amd.hip.HipOps in the product; the CPU test-suite
+injects the per-kernel references (oracle/ops_ref.py) to verify this schedule -- in particular the hand-written
+backward -- against the monolithic autograd oracle without a GPU.  The product never constructs anything but HipOps.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+from .config import TowerCfg
+
+BF16, F32 = torch.bfloat16, torch.float32
+EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32 = range(6)
+DX_BF16, DX_F32_ASSIGN, DX_F32_ACCUM = range(3)
+ALIGN = 64
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def param_groups_layout(cfg: TowerCfg, prefix: str = "visual."):
+    """Allocation groups (tensors of a group are contiguous, group starts are 64-aligned), in layer order.
+    Names are the reference state-dict keys; names starting with '_' inside a block are private padding."""
+    C, Hd, E, p = cfg.width, cfg.hidden, cfg.embed_dim, cfg.patch_size
+    groups = [[(prefix + "cls_token", (1, 1, C))], [(prefix + "pos_embed", (1, cfg.tokens, C))],
+              [(prefix + "patch_embed.proj.weight", (C, 3, p, p))], [(prefix + "patch_embed.proj.bias", (C,))]]
+    for i in range(cfg.layers):
+        b = f"{prefix}blocks.{i}."
+        groups += [
+            [(b + "norm1.weight", (C,))], [(b + "norm1.bias", (C,))],
+            [(b + "attn.q_proj.weight", (C, C)), (b + "attn.k_proj.weight", (C, C)), (b + "attn.v_proj.weight", (C, C))],
+            [(b + "attn.q_bias", (C,)), (b + "attn._k_bias_zero", (C,)), (b + "attn.v_bias", (C,))],
+            [(b + "attn.inner_attn_ln.weight", (C,))], [(b + "attn.inner_attn_ln.bias", (C,))],
+            [(b + "attn.proj.weight", (C, C))], [(b + "attn.proj.bias", (C,))],
+            [(b + "norm2.weight", (C,))], [(b + "norm2.bias", (C,))],
+            [(b + "mlp.w1.weight", (Hd, C)), (b + "mlp.w2.weight", (Hd, C))],
+            [(b + "mlp.w1.bias", (Hd,)), (b + "mlp.w2.bias", (Hd,))],
+            [(b + "mlp.ffn_ln.weight", (Hd,))], [(b + "mlp.ffn_ln.bias", (Hd,))],
+            [(b + "mlp.w3.weight", (C, Hd))], [(b + "mlp.w3.bias", (C,))],
+        ]
+    groups += [[(prefix + "norm.weight", (C,))], [(prefix + "norm.bias", (C,))],
+               [(prefix + "head.weight", (E, C))], [(prefix + "head.bias", (E,))]]
+    return groups
+
+
+def is_no_decay(name: str, ndim: int) -> bool:
+    """AdamW grouping rule of the reference (src/training/main.py:199)."""
+    return ndim < 2 or "bn" in name or "ln" in name or "bias" in name or "logit_scale" in name
+
+
+class EvaEngine:
+    def __init__(self, cfg: TowerCfg, ops, trainable: bool = False, prefix: str = "visual."):
+        self.cfg, self.ops, self.prefix, self.trainable = cfg, ops, prefix, trainable
+        self.offsets = OrderedDict()          # name -> (offset, shape)
+        off = 0
+        self.block_ranges = []                # flat [begin, end) of each block (contiguous all-reduce buckets)
+        cur_block, blk_begin = None, 0
+        for grp in param_groups_layout(cfg, prefix):
+            off = _round_up(off, ALIGN)
+            name0 = grp[0][0]
+            blk = int(name0[len(prefix) + 7:].split(".")[0]) if name0.startswith(prefix + "blocks.") else None
+            if blk != cur_block:
+                if cur_block is not None:
+                    self.block_ranges.append((blk_begin, off))
+                cur_block, blk_begin = blk, off
+            for name, shape in grp:
+                self.offsets[name] = (off, shape)
+                off += math.prod(shape)
+        self.numel = _round_up(off, 256)
+        self.master = ops.zeros((self.numel,), F32)
+        self.shadow = ops.zeros((self.numel,), BF16)
+        self.device = self.master.device
+        self.p = {n: self.master[o:o + math.prod(s)].view(s) for n, (o, s) in self.offsets.items()}
+        self.w = {n: self.shadow[o:o + math.prod(s)].view(s) for n, (o, s) in self.offsets.items()}
+        self._tables = {}
+        self._pos_cache = {}
+        self.grad = self.exp_avg = self.exp_avg_sq = self.flags = None
+        self.g = {}
+        self.wt = {}
+        self.first_trainable = cfg.layers      # no block trainable until lock()/unlock is applied
+        self.grad_ready_hook = None            # callable(block_index) fired when a block's grads are complete
+        self._ctx = None
+        if trainable:
+            self.grad = ops.zeros((self.numel,), F32)
+            self.exp_avg = ops.zeros((self.numel,), F32)
+            self.exp_avg_sq = ops.zeros((self.numel,), F32)
+            self.g = {n: self.grad[o:o + math.prod(s)].view(s) for n, (o, s) in self.offsets.items()}
+            self.flags = torch.zeros(self.numel // 64, dtype=torch.uint8, device=self.device)
+
+    # ------------------------------------------------------------------------------------------ parameters
+    def public_names(self):
+        return [n for n in self.offsets if "._" not in n]
+
+    def load_state(self, sd: dict, strict: bool = True):
+        missing = []
+        with torch.no_grad():
+            for n in self.public_names():
+                if n in sd:
+                    self.p[n].copy_(sd[n].to(self.device, F32).reshape(self.p[n].shape))
+                else:
+                    missing.append(n)
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:5]}... ({len(missing)})")
+        self.sync_shadow()
+        return missing
+
+    def sync_shadow(self):
+        """bf16 MFMA operands from the fp32 masters (after a load; AdamW refreshes them itself each step)."""
+        self.ops.cast_f32_bf16(self.master, self.shadow)
+        self._pos_cache.clear()
+        if self.trainable:
+            self.sync_transposed()
+
+    def _wt_alloc(self, key, rows, cols):
+        t = self.wt.get(key)
+        if t is None:
+            t = self.ops.zeros((cols, _round_up(rows, 64)), BF16)
+            self.wt[key] = t
+        return t
+
+    def sync_transposed(self, blocks=None):
+        """W^T shadows for the dgrad GEMMs (dx = dy . W needs W with the contraction dimension contiguous)."""
+        cfg, C, Hd = self.cfg, self.cfg.width, self.cfg.hidden
+        for i in (range(self.first_trainable, cfg.layers) if blocks is None else blocks):
+            b = f"{self.prefix}blocks.{i}."
+            o = self.offsets[b + "attn.q_proj.weight"][0]
+            self.ops.transpose_bf16(self.shadow[o:o + 3 * C * C].view(3 * C, C), self._wt_alloc((i, "qkv"), 3 * C, C))
+            self.ops.transpose_bf16(self.w[b + "attn.proj.weight"], self._wt_alloc((i, "proj"), C, C))
+            o = self.offsets[b + "mlp.w1.weight"][0]
+            self.ops.transpose_bf16(self.shadow[o:o + 2 * Hd * C].view(2 * Hd, C), self._wt_alloc((i, "w12"), 2 * Hd, C))
+            self.ops.transpose_bf16(self.w[b + "mlp.w3.weight"], self._wt_alloc((i, "w3"), C, Hd))
+        self.ops.transpose_bf16(self.w[self.prefix + "head.weight"], self._wt_alloc("head", self.cfg.embed_dim, C))
+
+    def set_trainable_blocks(self, unlocked_groups: int):
+        """visual.lock(unlocked_groups) (eva_vit_model.py:500-516): only the last n blocks train
+        (blocks[-0:] is the whole list, as in the reference)."""
+        L = self.cfg.layers
+        self.first_trainable = L - unlocked_groups if 0 < unlocked_groups <= L else 0
+        if not self.trainable:
+            return
+        self.flags.zero_()
+        for name, (o, s) in self.offsets.items():
+            if not name.startswith(self.prefix + "blocks.") or "._" in name:
+                continue
+            i = int(name[len(self.prefix) + 7:].split(".")[0])
+            if i < self.first_trainable:
+                continue
+            # the dense path runs the last block without attention: its q/k projections and q_bias never get a
+            # gradient, so torch's AdamW skips them (no decay either) -- SURVEY.md D7.
+            if i == L - 1 and name.rsplit(".", 2)[-2:] in (["q_proj", "weight"], ["k_proj", "weight"]) or \
+                    (i == L - 1 and name.endswith("attn.q_bias")):
+                continue
+            n = math.prod(s)
+            assert o % 64 == 0 and n % 64 == 0, f"{name}: flag granularity"
+            self.flags[o // 64:(o + n) // 64] = 1 | (0 if is_no_decay(name, len(s)) else 2)
+        self.sync_transposed()
+
+    def trainable_names(self):
+        return [n for n in self.public_names()
+                if n.startswith(self.prefix + "blocks.") and int(n[len(self.prefix) + 7:].split(".")[0]) >= self.first_trainable]
+
+    # ------------------------------------------------------------------------------------------ tables
+    def rope_tables(self, grid: int):
+        """cos/sin [grid*grid, 64] (rope.py:118-142,179-214): 16 frequencies theta^(-2i/32), positions
+        arange(grid)/grid*pt_seq_len, each repeated twice, row block then column block."""
+        key = ("rope", grid)
+        if key not in self._tables:
+            half = self.cfg.head_width // 2
+            freqs = 1.0 / (10000.0 ** (torch.arange(0, half, 2)[: half // 2].float() / half))
+            t = torch.arange(grid).float() / grid * self.cfg.pt_hw_seq_len
+            ang = (t[:, None] * freqs[None, :]).repeat_interleave(2, dim=-1)
+            full = torch.cat([ang[:, None, :].expand(grid, grid, half), ang[None, :, :].expand(grid, grid, half)], dim=-1)
+            full = full.reshape(grid * grid, self.cfg.head_width)
+            self._tables[key] = (full.cos().contiguous().to(self.device), full.sin().contiguous().to(self.device))
+        return self._tables[key]
+
+    def pos_for(self, grid: int):
+        """pos_embed [N, C] fp32, bicubic-rescaled for a non-native grid (eva_vit_model.py:631-643).  One-time
+        host-side table preparation per grid size, cached."""
+        if grid not in self._pos_cache:
+            pe = self.p[self.prefix + "pos_embed"][0]
+            if grid != self.cfg.grid:
+                C = pe.shape[1]
+                pe2 = pe[1:].T.contiguous().view(1, C, self.cfg.grid, self.cfg.grid)
+                pe2 = F.interpolate(pe2, (grid, grid), mode="bicubic", align_corners=False).view(C, grid * grid)
+                pe = torch.cat([pe[:1], pe2.T], dim=0)
+            self._pos_cache[grid] = pe.contiguous()
+        return self._pos_cache[grid]
+
+    # ------------------------------------------------------------------------------------------ forward pieces
+    def _stem(self, images):
+        ops, cfg, P = self.ops, self.cfg, self.prefix
+        B, _, S, _ = images.shape
+        p, C = cfg.patch_size, cfg.width
+        g = S // p
+        N, Kpe = g * g + 1, 3 * p * p
+        A = ops.empty((B * g * g, Kpe), BF16)
+        ops.im2row(images.contiguous(), A, p)
+        x = ops.empty((B, N, C), F32)
+        pos = self.pos_for(g)
+        ops.gemm_nt(A, self.w[P + "patch_embed.proj.weight"].view(C, Kpe), x.view(B * N, C),
+                    bias=self.p[P + "patch_embed.proj.bias"], extra=pos, epi=EPI_PATCH_F32, group=g * g)
+        ops.cls_row(x, self.p[P + "cls_token"].view(C), pos)
+        return x, g
+
+    def _qkv_w(self, b):
+        C = self.cfg.width
+        o = self.offsets[b + "attn.q_proj.weight"][0]
+        ob = self.offsets[b + "attn.q_bias"][0]
+        return self.shadow[o:o + 3 * C * C].view(3 * C, C), self.master[ob:ob + 3 * C]
+
+    def _w12(self, b):
+        C, Hd = self.cfg.width, self.cfg.hidden
+        o = self.offsets[b + "mlp.w1.weight"][0]
+        ob = self.offsets[b + "mlp.w1.bias"][0]
+        return self.shadow[o:o + 2 * Hd * C].view(2 * Hd, C), self.master[ob:ob + 2 * Hd]
+
+    def _block_fwd(self, i, x, B, N, cos, sin, with_attn=True, save=None, inplace=True):
+        """x: fp32 [B*N, C].  Returns the block output (x itself when inplace)."""
+        ops, cfg = self.ops, self.cfg
+        C, Hd, H, eps = cfg.width, cfg.hidden, cfg.heads, cfg.ln_eps
+        b = f"{self.prefix}blocks.{i}."
+        M = B * N
+        keep = save is not None
+        st = (lambda: (ops.empty((M,), F32), ops.empty((M,), F32))) if keep else (lambda: (None, None))
+
+        ln1 = ops.empty((M, C), BF16)
+        m1, r1 = st()
+        ops.layernorm_fwd(x, self.p[b + "norm1.weight"], self.p[b + "norm1.bias"], ln1, m1, r1, eps)
+        wqkv, bqkv = self._qkv_w(b)
+        qkv = lse = None
+        if with_attn:
+            qkv = ops.empty((M, 3 * C), BF16)
+            ops.gemm_nt(ln1, wqkv, qkv, bias=bqkv, epi=EPI_BF16)
+            att = ops.empty((M, C), BF16)
+            lse = ops.empty((B * H, N), F32) if keep else None
+            ops.attn_fwd(qkv, cos, sin, att, lse, B, N, H, cfg.head_width ** -0.5)
+        else:
+            att = ops.empty((M, C), BF16)      # v only: every token "attends" to itself (proj_without_attn)
+            ops.gemm_nt(ln1, wqkv[2 * C:], att, bias=bqkv[2 * C:], epi=EPI_BF16)
+        iln = ops.empty((M, C), BF16)
+        m2, r2 = st()
+        ops.layernorm_fwd(att, self.p[b + "attn.inner_attn_ln.weight"], self.p[b + "attn.inner_attn_ln.bias"], iln, m2, r2, eps)
+        x1 = x if inplace else ops.empty((M, C), F32)
+        ops.gemm_nt(iln, self.w[b + "attn.proj.weight"], x1, bias=self.p[b + "attn.proj.bias"], extra=x, epi=EPI_RESID_F32)
+
+        ln2 = ops.empty((M, C), BF16)
+        m3, r3 = st()
+        ops.layernorm_fwd(x1, self.p[b + "norm2.weight"], self.p[b + "norm2.bias"], ln2, m3, r3, eps)
+        w12, b12 = self._w12(b)
+        hid = ops.empty((M, Hd), BF16)
+        x12 = None
+        if keep:
+            x12 = ops.empty((M, 2 * Hd), BF16)
+            ops.gemm_nt(ln2, w12, x12, bias=b12, epi=EPI_BF16)
+            ops.swiglu_fwd(x12, hid)
+        else:
+            ops.gemm_nt(ln2, w12, hid, bias=b12, epi=EPI_SWIGLU_BF16, group=Hd)
+        fln = ops.empty((M, Hd), BF16)
+        m4, r4 = st()
+        ops.layernorm_fwd(hid, self.p[b + "mlp.ffn_ln.weight"], self.p[b + "mlp.ffn_ln.bias"], fln, m4, r4, eps)
+        x2 = x1 if inplace else ops.empty((M, C), F32)
+        ops.gemm_nt(fln, self.w[b + "mlp.w3.weight"], x2, bias=self.p[b + "mlp.w3.bias"], extra=x1, epi=EPI_RESID_F32)
+        if keep:
+            save.update(x0=x, ln1=ln1, st1=(m1, r1), qkv=qkv, lse=lse, att=att, iln=iln, st2=(m2, r2), x1=x1, ln2=ln2,
+                        st3=(m3, r3), x12=x12, hid=hid, fln=fln, st4=(m4, r4), with_attn=with_attn)
+        return x2
+
+    # ------------------------------------------------------------------------------------------ teacher
+    def encode_image(self, images, chunk: int = 256):
+        """Frozen-teacher path: full ViT, final LN on the CLS row, head.  [K,3,S,S] -> fp32 [K,E].
+        Activation-free: crops are streamed in chunks, blocks update the residual stream in place."""
+        ops, cfg, P = self.ops, self.cfg, self.prefix
+        K = images.shape[0]
+        out = ops.empty((K, cfg.embed_dim), F32)
+        for k0 in range(0, K, chunk):
+            img = images[k0:k0 + chunk]
+            B = img.shape[0]
+            x, g = self._stem(img)
+            N = g * g + 1
+            cos, sin = self.rope_tables(g)
+            xf = x.view(B * N, cfg.width)
+            for i in range(cfg.layers):
+                self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
+            cls = ops.empty((B, cfg.width), BF16)
+            ops.layernorm_fwd(x[:, 0, :], self.p[P + "norm.weight"], self.p[P + "norm.bias"], cls, None, None, cfg.ln_eps)
+            ops.gemm_nt(cls, self.w[P + "head.weight"], out[k0:k0 + B], bias=self.p[P + "head.bias"], epi=EPI_F32)
+        return out
+
+    # ------------------------------------------------------------------------------------------ student
+    def encode_dense(self, images, need_grad: bool = False):
+        """Dense path -> L2-normalised token map fp32 [B, N, E] (row 0 of each image is the unused CLS slot).
+        With need_grad the activations of the trainable blocks are kept for backward_dense()."""
+        ops, cfg, P = self.ops, self.cfg, self.prefix
+        B = images.shape[0]
+        x, g = self._stem(images)
+        N, C, E = g * g + 1, cfg.width, cfg.embed_dim
+        cos, sin = self.rope_tables(g)
+        xf = x.view(B * N, C)
+        saves = {}
+        for i in range(cfg.layers):
+            keep = need_grad and i >= self.first_trainable
+            save = {} if keep else None
+            xf = self._block_fwd(i, xf, B, N, cos, sin, with_attn=(i < cfg.layers - 1), save=save, inplace=not keep)
+            if keep:
+                saves[i] = save
+        M = B * N
+        lnf = ops.empty((M, C), BF16)
+        mean = ops.empty((M,), F32) if need_grad else None
+        rstd = ops.empty((M,), F32) if need_grad else None
+        ops.layernorm_fwd(xf, self.p[P + "norm.weight"], self.p[P + "norm.bias"], lnf, mean, rstd, cfg.ln_eps)
+        feats = ops.empty((M, E), F32)
+        ops.gemm_nt(lnf, self.w[P + "head.weight"], feats, bias=self.p[P + "head.bias"], epi=EPI_F32)
+        dense = ops.empty((M, E), F32)
+        inv = ops.empty((M,), F32)
+        ops.l2norm_fwd(feats, dense, inv)
+        if need_grad:
+            self._ctx = dict(B=B, N=N, g=g, saves=saves, xL=xf, stf=(mean, rstd), dense=dense, inv=inv, cos=cos, sin=sin)
+        return dense.view(B, N, E), g
+
+    def roi_pool(self, dense, rois, g):
+        """rois [K,5] = (image index, x0,y0,x1,y1 normalised to [0,1]) -> fp32 [K,E]."""
+        pooled = self.ops.empty((rois.shape[0], dense.shape[2]), F32)
+        if rois.shape[0]:
+            self.ops.roialign_fwd(dense, rois, pooled, g, g, 1)
+        return pooled
+
+    # ------------------------------------------------------------------------------------------ backward
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def _wgrad(self, dY, Xt, dW):
+        """dW[N,K] += dY^T X with X^T [K, Mp] already materialised (contraction dim contiguous, zero padded)."""
+        ops = self.ops
+        M, N = dY.shape
+        Mp = Xt.shape[1]
+        dYt = ops.empty((N, Mp), BF16)
+        ops.transpose_bf16(dY, dYt)
+        tiles = ((N + 127) // 128) * ((Xt.shape[0] + 127) // 128)
+        splits = max(1, min(Mp // 64, round(768 / tiles)))
+        ops.gemm_nt(dYt, Xt, dW, epi=EPI_ATOMIC_F32, splits=splits)
+
+    def _transposed(self, X):
+        M, K = X.shape
+        Xt = self.ops.empty((K, _round_up(M, 64)), BF16)
+        self.ops.transpose_bf16(X, Xt)
+        return Xt
+
+    def _block_bwd(self, i, s, g, B, N, cos, sin, ws):
+        """g: fp32 [M,C] gradient w.r.t. the block output; updated in place to the gradient w.r.t. its input."""
+        ops, cfg = self.ops, self.cfg
+        C, Hd, H = cfg.width, cfg.hidden, cfg.heads
+        b = f"{self.prefix}blocks.{i}."
+        M = B * N
+        G = self.g
+        # ---- MLP: x2 = x1 + w3(ffn_ln(silu(x1')*x2')) ------------------------------------------
+        gb = ops.empty((M, C), BF16)
+        ops.cast_f32_bf16(g, gb)
+        ops.colsum_bf16(gb, G[b + "mlp.w3.bias"])
+        self._wgrad(gb, self._transposed(s["fln"]), G[b + "mlp.w3.weight"])
+        d_fln = ops.empty((M, Hd), BF16)
+        ops.gemm_nt(gb, self.wt[(i, "w3")][:, :C], d_fln, epi=EPI_BF16)                     # [M,C] . W3[C,Hd]
+        d_hid = ops.empty((M, Hd), BF16)
+        ops.layernorm_bwd(d_fln, s["hid"], self.p[b + "mlp.ffn_ln.weight"], *s["st4"], d_hid, DX_BF16,
+                          G[b + "mlp.ffn_ln.weight"], G[b + "mlp.ffn_ln.bias"], True, ws)
+        d_x12 = ops.empty((M, 2 * Hd), BF16)
+        ops.swiglu_bwd(d_hid, s["x12"], d_x12)
+        ob = self.offsets[b + "mlp.w1.bias"][0]
+        ops.colsum_bf16(d_x12, self.grad[ob:ob + 2 * Hd])
+        ow = self.offsets[b + "mlp.w1.weight"][0]
+        self._wgrad(d_x12, self._transposed(s["ln2"]), self.grad[ow:ow + 2 * Hd * C].view(2 * Hd, C))
+        d_ln2 = ops.empty((M, C), BF16)
+        ops.gemm_nt(d_x12, self.wt[(i, "w12")][:, :2 * Hd], d_ln2, epi=EPI_BF16)            # [M,2Hd] . W12[2Hd,C]
+        ops.layernorm_bwd(d_ln2, s["x1"], self.p[b + "norm2.weight"], *s["st3"], g, DX_F32_ACCUM,
+                          G[b + "norm2.weight"], G[b + "norm2.bias"], True, ws)
+        # ---- attention branch: x1 = x0 + proj(inner_ln(att)) -------------------------------------
+        ops.cast_f32_bf16(g, gb)
+        ops.colsum_bf16(gb, G[b + "attn.proj.bias"])
+        self._wgrad(gb, self._transposed(s["iln"]), G[b + "attn.proj.weight"])
+        d_iln = ops.empty((M, C), BF16)
+        ops.gemm_nt(gb, self.wt[(i, "proj")][:, :C], d_iln, epi=EPI_BF16)
+        d_att = ops.empty((M, C), BF16)
+        ops.layernorm_bwd(d_iln, s["att"], self.p[b + "attn.inner_attn_ln.weight"], *s["st2"], d_att, DX_BF16,
+                          G[b + "attn.inner_attn_ln.weight"], G[b + "attn.inner_attn_ln.bias"], True, ws)
+        ln1_t = self._transposed(s["ln1"])
+        oq = self.offsets[b + "attn.q_proj.weight"][0]
+        d_ln1 = ops.empty((M, C), BF16)
+        if s["with_attn"]:
+            d_qkv = ops.empty((M, 3 * C), BF16)
+            ops.attn_bwd(s["qkv"], s["att"], d_att, s["lse"], cos, sin, d_qkv, ws, B, N, H, cfg.head_width ** -0.5)
+            ops.colsum_bf16(d_qkv[:, :C], G[b + "attn.q_bias"])        # K has no bias (eva_vit_model.py:178)
+            ops.colsum_bf16(d_qkv[:, 2 * C:], G[b + "attn.v_bias"])
+            self._wgrad(d_qkv, ln1_t, self.grad[oq:oq + 3 * C * C].view(3 * C, C))
+            ops.gemm_nt(d_qkv, self.wt[(i, "qkv")][:, :3 * C], d_ln1, epi=EPI_BF16)
+        else:
+            ops.colsum_bf16(d_att, G[b + "attn.v_bias"])
+            self._wgrad(d_att, ln1_t, G[b + "attn.v_proj.weight"])
+            ops.gemm_nt(d_att, self.wt[(i, "qkv")][:, 2 * C:3 * C], d_ln1, epi=EPI_BF16)
+        ops.layernorm_bwd(d_ln1, s["x0"], self.p[b + "norm1.weight"], *s["st1"], g, DX_F32_ACCUM,
+                          G[b + "norm1.weight"], G[b + "norm1.bias"], True, ws)
+
+    def backward_dense(self, d_dense):
+        """d_dense: fp32 [B, N, E] gradient w.r.t. the normalised token map (CLS rows zero).  Accumulates every
+        trainable-block gradient into the flat grad buffer; fires grad_ready_hook(block) as blocks complete."""
+        ops, cfg, P = self.ops, self.cfg, self.prefix
+        c = self._ctx
+        if c is None:
+            raise RuntimeError("backward_dense() without a preceding encode_dense(need_grad=True)")
+        self._ctx = None
+        B, N, C, E = c["B"], c["N"], cfg.width, cfg.embed_dim
+        M = B * N
+        d_feats = ops.empty((M, E), BF16)
+        ops.l2norm_bwd(d_dense.reshape(M, E), c["dense"], c["inv"], d_feats)
+        d_lnf = ops.empty((M, C), BF16)
+        ops.gemm_nt(d_feats, self.wt["head"][:, :E], d_lnf, epi=EPI_BF16)                  # head frozen: dgrad only
+        g = ops.empty((M, C), F32)
+        ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "norm.weight"], *c["stf"], g, DX_F32_ASSIGN)   # final norm frozen
+        ws_bytes = max(ops.layernorm_bwd_workspace(M, max(C, cfg.hidden)), ops.attn_bwd_workspace(B, N, cfg.heads))
+        ws = ops.empty((ws_bytes,), torch.uint8)
+        for i in range(cfg.layers - 1, self.first_trainable - 1, -1):
+            self._block_bwd(i, c["saves"].pop(i), g, B, N, c["cos"], c["sin"], ws)
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(i)
+
+    def roi_pool_backward(self, d_pooled, rois, B, N, g):
+        d_dense = self.ops.zeros((B, N, self.cfg.embed_dim), F32)
+        if rois.shape[0]:
+            self.ops.roialign_bwd(d_pooled.contiguous(), rois, d_dense, g, g, 1)
+        return d_dense
+
+    # ------------------------------------------------------------------------------------------ optimizer
+    def adamw_step(self, step: int, lr: float, wd: float, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale: float = 1.0):
+        """One flat AdamW launch over every trainable tensor (fp32 master + bf16 shadow refresh), then the W^T shadows."""
+        self.ops.adamw_step(self.master, self.grad, self.exp_avg, self.exp_avg_sq, self.shadow, self.flags,
+                            lr, beta1, beta2, eps, wd, step, grad_scale)
+        self.sync_transposed()

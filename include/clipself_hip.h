@@ -84,7 +84,7 @@ int cs_cosine_loss_bwd(const float* student, const float* teacher, const float* 
                        float weight, float grad_scale, cs_stream_t stream);
 
 /* --- optimizer: torch.optim.AdamW built at src/training/main.py:198-213, stepped at src/training/train.py:115.
- * Flat fp32 master/grad/moment buffers; flags[n/256]: bit0 = tensor has a gradient this step, bit1 = weight decay applies. */
+ * Flat fp32 master/grad/moment buffers; flags[n/64]: bit0 = tensor has a gradient this step, bit1 = weight decay applies. */
 int cs_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, const uint8_t* flags, long n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, cs_stream_t stream);
 

@@ -232,8 +232,8 @@ class RefOps:
         dstudent.copy_((-weight * grad_scale / K) * (teacher * i_t - cos * student * i_s) * i_s)
 
     def adamw_step(self, p, g, m, v, shadow, flags, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
-        act = (flags & 1).bool().repeat_interleave(256)
-        dec = (flags & 2).bool().repeat_interleave(256)
+        act = (flags & 1).bool().repeat_interleave(64)
+        dec = (flags & 2).bool().repeat_interleave(64)
         gg = g * grad_scale
         bc1 = 1.0 - beta1 ** step
         bc2s = math.sqrt(1.0 - beta2 ** step)

@@ -329,10 +329,11 @@ def test_cosine_loss(hip, ref):
 def test_adamw_matches_torch(hip, ref):
     n = 256 * 40
     p0, g = rnd((n,), F32, 0.02, seed=70), rnd((n,), F32, 1e-3, seed=71)
-    flags = torch.tensor([3, 1, 0, 2] * 10, dtype=torch.uint8)      # decay+active, active, inactive, decay but inactive
+    flags = torch.tensor([3, 1, 0, 2] * 10, dtype=torch.uint8).repeat_interleave(4)   # one byte per 64 elements
+    flags[4:8] = torch.tensor([1, 0, 1, 0], dtype=torch.uint8)     # mixed flags inside one 256-element wave chunk
     pd, md, vd = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     sh = torch.zeros(n, dtype=BF, device="cuda")
-    tp = [p0[i * 256:(i + 1) * 256].clone().requires_grad_(True) for i in range(40)]
+    tp = [p0[i * 64:(i + 1) * 64].clone().requires_grad_(True) for i in range(160)]
     dec = [t for i, t in enumerate(tp) if flags[i] == 3]
     nod = [t for i, t in enumerate(tp) if flags[i] == 1]
     opt = torch.optim.AdamW([{"params": nod, "weight_decay": 0.0}, {"params": dec, "weight_decay": 0.1}], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
@@ -340,9 +341,9 @@ def test_adamw_matches_torch(hip, ref):
         gs = g * step
         hip.adamw_step(pd, gs.cuda(), md, vd, sh, flags.cuda(), 1e-3, 0.9, 0.999, 1e-8, 0.1, step)
         for i, t in enumerate(tp):
-            t.grad = gs[i * 256:(i + 1) * 256].clone() if flags[i] & 1 else None
+            t.grad = gs[i * 64:(i + 1) * 64].clone() if flags[i] & 1 else None
         opt.step()
     want = torch.cat([t.detach() for t in tp])
     check("adamw.p", pd, want, 1e-6)
-    act = (flags & 1).bool().repeat_interleave(256)
+    act = (flags & 1).bool().repeat_interleave(64)
     assert torch.equal(sh.cpu()[act], pd.cpu().to(BF)[act]) and float(sh.cpu()[~act].abs().max()) == 0.0
