@@ -135,9 +135,11 @@ __global__ __launch_bounds__(256) void cosine_reduce_kernel(const float* __restr
 
 // d loss / d s_k = -(weight*gscale/K) * (t_hat - cos_k * s_hat) / |s|
 __global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict__ s, const float* __restrict__ t, const float* __restrict__ stats,
-                                                         float* __restrict__ ds, int K, int E, float coef) {
+                                                         float* __restrict__ ds, int K, int E, float coef,
+                                                         const float* __restrict__ upstream) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)K * E) return;
+    if (upstream) coef *= upstream[0];        // d(total)/d(loss) left on the device: no host sync in backward
     const int k = (int)(i / E);
     const float cosv = stats[k * 3], is = stats[k * 3 + 1], it = stats[k * 3 + 2];
     ds[i] = coef * (t[i] * it - cosv * s[i] * is) * is;
@@ -177,10 +179,10 @@ extern "C" int cs_cosine_loss_fwd(const float* student, const float* teacher, fl
     return 0;
 }
 extern "C" int cs_cosine_loss_bwd(const float* student, const float* teacher, const float* stats, float* dstudent, int K, int E,
-                                  float weight, float grad_scale, hipStream_t stream) {
+                                  float weight, float grad_scale, const float* upstream, hipStream_t stream) {
     CS_CHECK_ARG(K > 0, "cs_cosine_loss_bwd: K must be positive");
     const float coef = -weight * grad_scale / (float)K;
-    hipLaunchKernelGGL(cosine_bwd_kernel, dim3((int)(((long)K * E + 255) / 256)), dim3(256), 0, stream, student, teacher, stats, dstudent, K, E, coef);
+    hipLaunchKernelGGL(cosine_bwd_kernel, dim3((int)(((long)K * E + 255) / 256)), dim3(256), 0, stream, student, teacher, stats, dstudent, K, E, coef, upstream);
     CS_LAUNCH_CHECK();
     return 0;
 }

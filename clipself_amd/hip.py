@@ -44,7 +44,7 @@ SIGNATURES = {
     "cs_roialign_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_roialign_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_cosine_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
-    "cs_cosine_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
+    "cs_cosine_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     "cs_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp]),
 }
 
@@ -233,11 +233,11 @@ class HipOps:
         self._ok(self.lib.cs_cosine_loss_fwd(_p(student), _p(teacher), _p(stats), _p(loss), K, E, weight, self._stream()),
                  "cs_cosine_loss_fwd")
 
-    def cosine_loss_bwd(self, student, teacher, stats, dstudent, weight, grad_scale=1.0):
-        self._chk(student, teacher, stats, dstudent)
+    def cosine_loss_bwd(self, student, teacher, stats, dstudent, weight, grad_scale=1.0, upstream=None):
+        self._chk(student, teacher, stats, dstudent, upstream)
         K, E = student.shape
         self._ok(self.lib.cs_cosine_loss_bwd(_p(student), _p(teacher), _p(stats), _p(dstudent), K, E, weight, grad_scale,
-                                             self._stream()), "cs_cosine_loss_bwd")
+                                             _p(upstream), self._stream()), "cs_cosine_loss_bwd")
 
     def adamw_step(self, p, g, m, v, shadow, flags, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
         self._chk(p, g, m, v, shadow, flags)

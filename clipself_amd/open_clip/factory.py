@@ -1,0 +1,131 @@
+"""`open_clip` factory surface for the CLIPSelf hot path.
+
+Mirrors the call signatures of the reference (src/open_clip/factory.py:111-149 `create_model`, :267-350
+`create_model_and_transforms`; src/open_clip/eva_clip/factory.py:211-355) for the EVA towers
+(`pretrained='eva'`, checkpoint path passed as `cache_dir`).  Anything else the reference's zoo can build
+(ResNets, timm, CoCa, OpenAI ViT) is outside the hot path and raises.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Optional
+
+import torch
+
+from ..config import get_tower_cfg, list_models as _list_models
+from .model import CustomCLIP
+
+
+def list_models():
+    return _list_models()
+
+
+def get_cast_dtype(precision: str):
+    # eva_clip/model.py:83-89
+    if precision == "bf16":
+        return torch.bfloat16
+    if precision == "fp16":
+        return torch.float16
+    return None
+
+
+def load_state_dict(checkpoint_path: str, map_location="cpu", model_key="model|module|state_dict"):
+    """eva_clip/factory.py:80-106: pick the state dict out of a checkpoint, strip 'module.', drop RoPE tables."""
+    checkpoint = torch.load(checkpoint_path, map_location=map_location, weights_only=False)
+    state_dict = checkpoint
+    for mk in model_key.split("|"):
+        if isinstance(checkpoint, dict) and mk in checkpoint:
+            state_dict = checkpoint[mk]
+            break
+    if next(iter(state_dict.items()))[0].startswith("module"):
+        state_dict = {k[7:]: v for k, v in state_dict.items()}
+    return {k: v for k, v in state_dict.items() if "freqs_cos" not in k and "freqs_sin" not in k}
+
+
+def _resize_pos_embed(state_dict, model):
+    """eva_clip/utils.py:78-106 (resize_evaclip_pos_embed): bicubic resize of a checkpoint's grid to the model's."""
+    key = "visual.pos_embed"
+    if key not in state_dict:
+        return
+    pe = state_dict[key].float()
+    cfg = model.visual.cfg
+    new_n = cfg.grid * cfg.grid
+    old_n = pe.shape[1] - 1
+    if old_n == new_n:
+        return
+    old_g = int(old_n ** 0.5)
+    body = pe[:, 1:].reshape(1, old_g, old_g, -1).permute(0, 3, 1, 2)
+    body = torch.nn.functional.interpolate(body, size=(cfg.grid, cfg.grid), mode="bicubic", align_corners=False)
+    state_dict[key] = torch.cat([pe[:, :1], body.permute(0, 2, 3, 1).flatten(1, 2)], dim=1)
+
+
+def load_checkpoint(model, checkpoint_path, strict=False):
+    sd = load_state_dict(checkpoint_path)
+    if "text.logit_scale" in sd:
+        sd["logit_scale"] = sd.pop("text.logit_scale")
+    _resize_pos_embed(sd, model)
+    return model.load_state_dict(sd, strict=strict)
+
+
+def create_model(model_name: str, pretrained: Optional[str] = None, precision: str = "fp32", device="cpu", jit: bool = False,
+                 force_quick_gelu: bool = False, force_custom_text: bool = False, force_patch_dropout=None,
+                 force_image_size=None, pretrained_image: bool = False, pretrained_hf: bool = True,
+                 cache_dir: Optional[str] = None, output_dict: Optional[bool] = None, require_pretrained: bool = False,
+                 ops=None, trainable: bool = True):
+    """Returns a CustomCLIP whose vision tower runs on the HIP engine.
+
+    `precision` is accepted for CLI compatibility; the hot path always computes with bf16 MFMA operands,
+    fp32 accumulation/statistics and fp32 master weights.  `device` must be a ROCm device.
+    """
+    model_name = model_name.replace("/", "-")
+    if pretrained not in ("eva", None, ""):
+        raise NotImplementedError(f"pretrained={pretrained!r}: only the EVA towers (pretrained='eva') are on the CLIPSelf hot path")
+    if jit:
+        raise NotImplementedError("torchscript is not supported by the HIP engine")
+    cfg = get_tower_cfg(model_name)
+    os.environ["RoPE"] = "1"                      # side effect of the reference factory (eva_clip/factory.py:249-253)
+    model = CustomCLIP(cfg, ops=ops, trainable=trainable)
+    if cache_dir and os.path.exists(cache_dir) and os.path.isfile(cache_dir):
+        logging.info(f"Loading pretrained {model_name} weights ({cache_dir}).")
+        load_checkpoint(model, cache_dir, strict=False)
+    elif cache_dir and require_pretrained:
+        raise RuntimeError(f"Pretrained weights ({cache_dir}) not found for model {model_name}.")
+    else:
+        from ..init import seeded_visual_state
+        logging.info(f"No checkpoint at {cache_dir!r}: {model_name} starts from the seeded random initialisation")
+        model.visual.engine.load_state(seeded_visual_state(cfg, seed=0))
+    return model
+
+
+class _HostTransformOutOfScope:
+    """The PIL/torchvision preprocessing pipeline (reference: src/open_clip/transform.py) is outside the hot path
+    (SURVEY.md §8 row N3); the training entrypoint here feeds tensors that already follow the batch contract."""
+
+    def __init__(self, name, size):
+        self.name, self.size = name, size
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError(f"{self.name}: host-side image preprocessing is out of scope of the MI355X hot path")
+
+
+def create_model_and_transforms(model_name: str, pretrained: Optional[str] = None, precision: str = "fp32", device="cpu",
+                                jit: bool = False, force_quick_gelu: bool = False, force_custom_text: bool = False,
+                                force_patch_dropout=None, force_image_size=None, pretrained_image: bool = False,
+                                pretrained_hf: bool = True, image_mean=None, image_std=None, aug_cfg=None,
+                                cache_dir: Optional[str] = None, output_dict: Optional[bool] = None,
+                                det_image_size=1024, dataset_type=None, ops=None):
+    model = create_model(model_name, pretrained, precision=precision, device=device, jit=jit,
+                         force_quick_gelu=force_quick_gelu, force_custom_text=force_custom_text,
+                         force_patch_dropout=force_patch_dropout, force_image_size=force_image_size,
+                         pretrained_image=pretrained_image, pretrained_hf=pretrained_hf, cache_dir=cache_dir,
+                         output_dict=output_dict, ops=ops)
+    det = _HostTransformOutOfScope("det_image_transform", det_image_size)
+    crop = _HostTransformOutOfScope("image_transform", model.visual.image_size)
+    return model, [det, crop], [det, crop]
+
+
+def get_tokenizer(model_name):
+    def _no_text(*a, **k):
+        raise NotImplementedError("tokenisation / the text tower are outside the CLIPSelf hot path")
+    return _no_text

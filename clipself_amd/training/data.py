@@ -1,0 +1,58 @@
+"""Batch contract of the distillation datasets + a synthetic, device-resident producer.
+
+The reference's COCO/LVIS pipeline (src/training/data.py: GridDistillDataset :135-281, ProposalDistillDataset
+:30-132; PIL + pycocotools in DataLoader workers) is outside the MI355X hot path; what the step
+consumes is its *output contract* (data.py:247-281):
+    images [B,3,S,S], normed_boxes [B,max_boxes,5] = (x0,y0,x1,y1 in [0,1], valid in {0,1}), image_crops [B,max_boxes,3,Sc,Sc]
+`SyntheticDistillData` emits exactly that (SURVEY.md §8 M2 recipe) straight into HBM, shaped like the reference's
+DataInfo/DataLoader pair (`.dataloader.num_batches`, `.num_samples`, `.set_epoch`)."""
+from dataclasses import dataclass
+
+import torch
+
+from ..init import synthetic_batch
+
+
+class _SyntheticLoader:
+    def __init__(self, steps, batch_size, boxes, image_size, crop_size, device, rank, world, seed=1234, valid_prob=1.0, resident=True):
+        self.num_batches, self.num_samples = steps, steps * batch_size * world
+        self.args = (batch_size, boxes, image_size, crop_size)
+        self.device, self.rank, self.seed, self.valid_prob, self.resident = device, rank, seed, valid_prob, resident
+        self.epoch = 0
+        self._cache = None
+
+    def _make(self, i):
+        b = synthetic_batch(*self.args, seed=self.seed + 1000 * self.epoch + i, rank=self.rank * 7919, valid_prob=self.valid_prob)
+        return tuple(t.to(self.device) for t in b)
+
+    def __len__(self):
+        return self.num_batches
+
+    def __iter__(self):
+        for i in range(self.num_batches):
+            if self.resident:                      # throughput mode: one batch generated once, re-used (already in HBM)
+                if self._cache is None:
+                    self._cache = self._make(0)
+                yield self._cache
+            else:
+                yield self._make(i)
+
+
+@dataclass
+class DataInfo:
+    dataloader: _SyntheticLoader
+
+    def set_epoch(self, epoch):
+        self.dataloader.epoch = epoch
+
+
+def get_data(args, preprocess_fns=None, epoch=0, tokenizer=None):
+    if args.train_data != "synthetic":
+        raise NotImplementedError(
+            "only --train-data synthetic is wired in this build: the COCO/LVIS PIL pipeline is host-side and out of "
+            "scope of the MI355X hot path (SURVEY.md §8 N3); any iterable yielding the batch contract can be plugged in")
+    size = args.synthetic_image_size or args.det_image_size
+    loader = _SyntheticLoader(args.synthetic_steps, args.batch_size, args.max_boxes, size, args.input_size,
+                              args.device, args.rank, args.world_size, seed=1234 + args.seed,
+                              valid_prob=0.7 if args.dataset_type == "proposals_distill" else 1.0, resident=False)
+    return {"train": DataInfo(loader)}

@@ -1,0 +1,119 @@
+"""One process per GPU; `torch.distributed` (backend 'nccl' == RCCL over xGMI on ROCm; 'gloo' on CPU tests).
+
+Environment handling follows the reference (src/training/distributed.py:36-114): torchrun-style env://
+rendezvous from RANK / LOCAL_RANK / WORLD_SIZE (SLURM variables accepted), `--dist-backend`, `--dist-url`.
+
+Gradient exchange is what the reference *intends* but never executes (its CLIPSelf method unwraps `.module`, so
+DistributedDataParallel's reducer never fires -- SURVEY.md D3): the mean over ranks of every student gradient.
+Here each transformer block's gradients are one contiguous slice of the flat fp32 grad buffer, so the exchange is
+one asynchronous all-reduce per block, issued the moment the block's backward finishes (reverse layer order) and
+overlapped with the remaining backward; xGMI is point-to-point, so ~28 MB (B/16) buckets keep every ring step
+bandwidth- rather than latency-bound.  SUM on the wire, 1/world folded into the AdamW kernel.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_global_master(args):
+    return args.rank == 0
+
+
+def is_local_master(args):
+    return args.local_rank == 0
+
+
+def is_master(args, local=False):
+    return is_local_master(args) if local else is_global_master(args)
+
+
+def world_info_from_env():
+    def first(names, default):
+        for v in names:
+            if v in os.environ:
+                return int(os.environ[v])
+        return default
+    return (first(("LOCAL_RANK", "SLURM_LOCALID"), 0), first(("RANK", "SLURM_PROCID"), 0),
+            first(("WORLD_SIZE", "SLURM_NTASKS"), 1))
+
+
+def is_using_distributed():
+    return world_info_from_env()[2] > 1
+
+
+def init_distributed_device(args):
+    args.distributed, args.world_size, args.rank, args.local_rank = False, 1, 0, 0
+    if getattr(args, "horovod", False):
+        raise NotImplementedError("horovod is not part of the MI355X build; use torchrun (RCCL)")
+    if is_using_distributed():
+        args.local_rank, args.rank, args.world_size = world_info_from_env()
+        if not dist.is_initialized():
+            dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url,
+                                    world_size=args.world_size, rank=args.rank)
+        args.distributed = True
+    if torch.cuda.is_available():
+        device = f"cuda:{args.local_rank}" if args.distributed and not getattr(args, "no_set_device_rank", False) else "cuda:0"
+        torch.cuda.set_device(device)
+    else:
+        device = "cpu"
+    args.device = device
+    return torch.device(device)
+
+
+def broadcast_object(args, obj, src=0):
+    objects = [obj] if args.rank == src else [None]
+    dist.broadcast_object_list(objects, src=src)
+    return objects[0]
+
+
+def all_gather_object(args, obj, dst=0):
+    objects = [None for _ in range(args.world_size)]
+    dist.all_gather_object(objects, obj)
+    return objects
+
+
+class StudentDataParallel(torch.nn.Module):
+    """`.module`-carrying wrapper (the reference's methods unwrap it: clipself.py:8-10) that (1) broadcasts rank 0's
+    parameters once and (2) arms the engine's per-block grad-ready hook with asynchronous bucket all-reduces."""
+
+    def __init__(self, module, process_group=None):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        eng = module.visual.engine
+        dist.broadcast(eng.master, src=0, group=process_group)
+        with torch.no_grad():
+            dist.broadcast(module.logit_scale.data, src=0, group=process_group)
+        eng.sync_shadow()
+        self._pending = []
+        if eng.trainable:
+            eng.grad_ready_hook = self._on_block_ready
+
+    def _on_block_ready(self, block: int):
+        eng = self.module.visual.engine
+        lo, hi = eng.block_ranges[block]
+        self._pending.append(dist.all_reduce(eng.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish_grad_sync(self):
+        """Make the current stream wait for every outstanding bucket (call before the optimizer step)."""
+        for h in self._pending:
+            h.wait()
+        self._pending.clear()
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+class FrozenDataParallel(torch.nn.Module):
+    """Teacher wrapper: parameters broadcast once, no gradient traffic (main.py:191-192)."""
+
+    def __init__(self, module, process_group=None):
+        super().__init__()
+        self.module = module
+        dist.broadcast(module.visual.engine.master, src=0, group=process_group)
+        module.visual.engine.sync_shadow()
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)

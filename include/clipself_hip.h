@@ -80,8 +80,9 @@ int cs_roialign_bwd(const float* dpooled, const float* rois, float* dfeat, int K
 /* --- cosine distillation loss: src/training/clipself.py:42-47.  stats [K,3] f32 workspace kept for the backward. */
 int cs_cosine_loss_fwd(const float* student, const float* teacher, float* stats, float* loss, int K, int E, float weight,
                        cs_stream_t stream);
+/* upstream: optional device scalar d(total)/d(loss) multiplied in on the device (nullable = 1). */
 int cs_cosine_loss_bwd(const float* student, const float* teacher, const float* stats, float* dstudent, int K, int E,
-                       float weight, float grad_scale, cs_stream_t stream);
+                       float weight, float grad_scale, const float* upstream, cs_stream_t stream);
 
 /* --- optimizer: torch.optim.AdamW built at src/training/main.py:198-213, stepped at src/training/train.py:115.
  * Flat fp32 master/grad/moment buffers; flags[n/64]: bit0 = tensor has a gradient this step, bit1 = weight decay applies. */

@@ -213,9 +213,10 @@ class RefOps:
 
     def roialign_bwd(self, dpooled, rois, dfeat, grid_h, grid_w, tok_off):
         B, Ntok, E = dfeat.shape
-        probe = torch.zeros(B, grid_h, grid_w, E, requires_grad=True)
-        out = roi_align_1x1(probe, self._rois_pixels(rois, grid_h, grid_w))
-        (g,) = torch.autograd.grad(out, probe, dpooled)
+        with torch.enable_grad():          # may be called from inside an autograd backward (grad mode off)
+            probe = torch.zeros(B, grid_h, grid_w, E, requires_grad=True)
+            out = roi_align_1x1(probe, self._rois_pixels(rois, grid_h, grid_w))
+            (g,) = torch.autograd.grad(out, probe, dpooled.detach())
         dfeat[:, tok_off:tok_off + grid_h * grid_w] += g.reshape(B, grid_h * grid_w, E)
 
     def cosine_loss_fwd(self, student, teacher, stats, loss, weight):
@@ -226,8 +227,10 @@ class RefOps:
         stats[:, 2] = 1.0 / nt
         loss[0] = weight * (1.0 - cos.mean())
 
-    def cosine_loss_bwd(self, student, teacher, stats, dstudent, weight, grad_scale=1.0):
+    def cosine_loss_bwd(self, student, teacher, stats, dstudent, weight, grad_scale=1.0, upstream=None):
         K = student.shape[0]
+        if upstream is not None:
+            grad_scale = grad_scale * float(upstream.reshape(-1)[0])
         cos, i_s, i_t = stats[:, 0:1], stats[:, 1:2], stats[:, 2:3]
         dstudent.copy_((-weight * grad_scale / K) * (teacher * i_t - cos * student * i_s) * i_s)
 

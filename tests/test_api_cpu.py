@@ -1,0 +1,137 @@
+"""CPU: the drop-in API layer (clipself_amd.open_clip / clipself_amd.training) driven end-to-end with the per-kernel
+references injected as `ops` (test infrastructure): method call contract, autograd bridge, parameter/grad views,
+optimizer grouping, LR schedule, state-dict keys, checkpoint round trip -- against the reference-derived goldens."""
+import json
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from clipself_amd.config import tiny_cfg
+from clipself_amd.init import seeded_visual_state, synthetic_batch
+from clipself_amd.open_clip import create_model
+from clipself_amd.open_clip.model import CustomCLIP
+from clipself_amd.training.clipself import CLIPSelf
+from clipself_amd.training.optim import FlatAdamW
+from clipself_amd.training.scheduler import cosine_lr
+from clipself_amd.training.train import student_teacher_ensemble, train_step
+from oracle.ops_ref import RefOps
+
+
+def _pair(cfg, seed):
+    student = CustomCLIP(cfg, ops=RefOps(), trainable=True)
+    teacher = CustomCLIP(cfg, ops=RefOps(), trainable=False)
+    for m in (student, teacher):
+        m.visual.engine.load_state(seeded_visual_state(cfg, seed))
+    student.lock_image_tower(unlocked_groups=cfg.layers)
+    student.train()
+    teacher.eval()
+    return student, teacher
+
+
+def _args(**kw):
+    base = dict(device="cpu", precision="amp", distributed=False, skip_scheduler=False, grad_clip_norm=None,
+                multiscale=False, extract_type="v2", cosine_weight=1.0)
+    base.update(kw)
+    return SimpleNamespace(**base)
+
+
+def test_three_training_steps_through_the_reference_call_contract(golden_dir):
+    g = np.load(golden_dir / "tiny_step.npz")
+    rec = json.loads(str(g["recipe"]))
+    cfg = tiny_cfg()
+    student, teacher = _pair(cfg, rec["seed_w"])
+    opt = FlatAdamW(student, lr=rec["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=rec["wd"])
+    sched = cosine_lr(opt, rec["lr"], rec["warmup"], rec["total"])
+    method, args = CLIPSelf(), _args()
+    losses = []
+    for step in range(rec["steps"]):
+        batch = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"] + step)
+        out, bs, logit_scale = train_step(student, method, batch, opt, sched, step, teacher, args)
+        assert bs == rec["batch"] and set(out) == {"loss_cosine", "loss"}
+        assert float(logit_scale) == pytest.approx(1 / 0.07, rel=1e-5)
+        assert opt.param_groups[0]["lr"] == pytest.approx(g["lrs"][step])
+        losses.append(float(out["loss"]))
+        if step == 0:
+            none = {str(n) for n in g["grad_none"]}
+            for n, p in student.named_parameters():
+                if not p.requires_grad:
+                    continue
+                if n in none:
+                    assert p.grad is None, n
+                else:
+                    assert p.grad is not None and p.grad.data_ptr() == student.visual.engine.g[n].data_ptr(), n
+    assert np.allclose(losses, g["losses"], atol=1e-2)
+    w = dict(student.named_parameters())["visual.blocks.0.mlp.w1.weight"]
+    ref = torch.from_numpy(g["final/visual.blocks.0.mlp.w1.weight"])
+    assert float((w.detach() - ref).norm() / ref.norm()) < 2e-2
+
+
+def test_list_of_boxes_and_no_grad_paths_agree():
+    cfg = tiny_cfg()
+    student, teacher = _pair(cfg, 3)
+    images, boxes, crops = synthetic_batch(2, 4, cfg.image_size, cfg.image_size, seed=9, valid_prob=0.6)
+    rois_list = [b[b[:, -1] > 0.5, :4] for b in boxes]
+    with torch.no_grad():
+        a = student.encode_pseudo_boxes(images, rois_list, normalize=False, extract_type="v2")
+        d = student.encode_dense(images, normalize=False, keep_shape=True)
+    b = student.encode_pseudo_boxes(images, rois_list)
+    # inference path = fused SwiGLU epilogue (fp32 x1,x2); training path stores x1|x2 as bf16 for the backward
+    assert b.requires_grad and float((a - b.detach()).norm() / a.norm()) < 1e-2
+    assert d.shape == (2, cfg.embed_dim, cfg.grid, cfg.grid)
+    assert torch.allclose(d.norm(dim=1), torch.ones(2, cfg.grid, cfg.grid), atol=1e-5)
+    # ragged batch through the method (invalid rows dropped like clipself.py:29-36)
+    out, bs, _ = CLIPSelf()((images, boxes, crops), student, teacher, None, "cpu", None, False, _args())
+    assert bs == 2 and torch.isfinite(out["loss_cosine"])
+    out["loss_cosine"].backward()
+    assert student.visual.engine.g["visual.blocks.0.norm1.weight"].abs().sum() > 0
+
+
+def test_state_dict_keys_and_param_groups_match_the_reference(golden_dir):
+    blob = json.loads((golden_dir / "param_groups.json").read_text())
+    model = create_model("EVA02-CLIP-B-16", "eva", cache_dir=None, ops=RefOps())
+    model.lock_image_tower(unlocked_groups=12)
+    names = dict(model.named_parameters())
+    for n, grp in blob["groups"].items():
+        assert n in names, n
+        assert names[n].requires_grad == (grp != "frozen"), n
+    assert {n for n in names if not n.startswith("text.")} == set(blob["groups"])
+    opt = FlatAdamW(model, lr=1e-5, weight_decay=0.1)
+    ids = {id(p): n for n, p in names.items()}
+    assert {ids[id(p)] for p in opt.param_groups[0]["params"]} == {n for n, g in blob["groups"].items() if g == "no_decay"}
+    assert {ids[id(p)] for p in opt.param_groups[1]["params"]} == {n for n, g in blob["groups"].items() if g == "decay"}
+    sd = model.state_dict()
+    for k in ("visual.rope.freqs_cos", "visual.blocks.3.attn.rope.freqs_sin", "logit_scale", "text.token_embedding.weight",
+              "text.transformer.resblocks.11.mlp.c_proj.bias", "visual.patch_embed.proj.weight"):
+        assert k in sd, k
+    eng = model.visual.engine
+    act = int((eng.flags & 1).sum()) * 64
+    # 84 934 656 decay + 190 465 no-decay elements train; minus the 4 tensors the dense path never reaches
+    assert act == 84934656 + 190464 - 2 * 768 * 768 - 768
+    assert float(model.logit_scale) == pytest.approx(math.log(1 / 0.07))
+
+
+def test_checkpoint_roundtrip_and_ensemble(tmp_path):
+    cfg = tiny_cfg()
+    student, teacher = _pair(cfg, 1)
+    with torch.no_grad():
+        student.visual.engine.master.mul_(1.5)
+    student.visual.engine.sync_shadow()
+    ens = student_teacher_ensemble(student.state_dict(), teacher.state_dict(), alpha=0.7)
+    k = "visual.blocks.1.mlp.w3.weight"
+    assert torch.allclose(ens[k], student.state_dict()[k] * 0.7 + teacher.state_dict()[k] * 0.3)
+    opt = FlatAdamW(student, lr=1e-3, weight_decay=0.1)
+    path = tmp_path / "epoch_1.pt"
+    torch.save({"epoch": 1, "name": "t", "state_dict": ens, "optimizer": opt.state_dict()}, path)
+    fresh = create_model_from_ckpt(cfg, path)
+    assert torch.allclose(fresh.state_dict()[k], ens[k])
+    assert torch.equal(fresh.visual.engine.w[k], ens[k].to(torch.bfloat16))      # bf16 shadow refreshed on load
+
+
+def create_model_from_ckpt(cfg, path):
+    from clipself_amd.open_clip.factory import load_checkpoint
+    m = CustomCLIP(cfg, ops=RefOps(), trainable=False)
+    load_checkpoint(m, str(path), strict=False)
+    return m
