@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the CLIPSelf distillation step (student + teacher), BASELINE.json metric.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one full training iteration of the hot path on one synthetic batch already resident in HBM:
+teacher EVA02-CLIP-B-16 forward over 64x32 region crops (224^2) -> student dense forward over 64 images (224^2) ->
+RoIAlign -> cosine loss -> student backward (12 blocks) -> [bucketed RCCL all-reduce] -> AdamW, through the same
+`train_step` the training entrypoint uses.  Workload = BASELINE.json configs[1].
+
+The JSON line also carries
+  roofline      MFMA roofline of the dominant kernel (the fused W1|W2 SwiGLU GEMM of the teacher, one shape per
+                launch): algorithmic FLOPs per launch / mean launch duration, measured with HIP events recorded on
+                the launch stream inside the timed region; peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).
+  cpu_baseline  the fp32 CPU oracle (oracle/eva_ref.py, validated against the reference) timed on the host cores on a
+                bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+from types import SimpleNamespace
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+MODEL = "EVA02-CLIP-B-16"
+BATCH, CROPS, SIZE = 64, 32, 224
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def flops_per_image(cfg, k):
+    """2*MACs of the matmuls only."""
+    N, C, Hd, E, L, p = cfg.tokens, cfg.width, cfg.hidden, cfg.embed_dim, cfg.layers, cfg.patch_size
+    pe = 2 * (N - 1) * (3 * p * p) * C
+    blk = 2 * N * C * C * 4 + 4 * N * N * C + 6 * N * C * Hd
+    blk_na = 4 * N * C * C + 6 * N * C * Hd
+    T = pe + L * blk + 2 * C * E
+    Sf = pe + (L - 1) * blk + blk_na + 2 * (N - 1) * C * E
+    Sb = 2 * ((L - 1) * blk + blk_na) + 2 * (N - 1) * C * E
+    return k * T + Sf + Sb
+
+
+class KernelTimer:
+    """HIP-event timing of one kernel class on its launch stream (our launches go to torch's current stream)."""
+
+    def __init__(self, ops, epi, max_events=4096):
+        self.ops, self.epi, self.on, self.pairs, self.flops = ops, epi, False, [], 0.0
+        self._inner = ops.gemm_nt
+        self._pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max_events)]
+        ops.gemm_nt = self._wrapped
+
+    def _wrapped(self, A, B, C, bias=None, extra=None, epi=0, splits=1, group=0, flags=0):
+        if self.on and epi == self.epi and len(self.pairs) < len(self._pool):
+            e0, e1 = self._pool[len(self.pairs)]
+            e0.record()
+            self._inner(A, B, C, bias, extra, epi, splits, group, flags)
+            e1.record()
+            self.pairs.append((e0, e1))
+            self.flops += 2.0 * A.shape[0] * B.shape[0] * A.shape[1]
+        else:
+            self._inner(A, B, C, bias, extra, epi, splits, group, flags)
+
+    def result(self):
+        if not self.pairs:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
+        return dict(launches=len(self.pairs), mean_us=1e3 * ms / len(self.pairs), tflops=self.flops / (ms * 1e-3) / 1e12,
+                    flops_per_launch=self.flops / len(self.pairs))
+
+
+def cpu_baseline():
+    """fp32 CPU oracle on the host cores: 1 image x 32 crops (the per-image work of the GPU workload), 1 warm-up + 2 timed steps."""
+    from clipself_amd.config import get_tower_cfg
+    from clipself_amd.init import seeded_visual_state, synthetic_batch
+    from oracle import eva_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = get_tower_cfg(MODEL)
+    student, teacher = seeded_visual_state(cfg, 0), seeded_visual_state(cfg, 0)
+    batches = [synthetic_batch(1, CROPS, SIZE, SIZE, seed=1234 + i) for i in range(3)]
+    eva_ref.train_steps(student, teacher, cfg, batches[:1])
+    t0 = time.time()
+    eva_ref.train_steps(student, teacher, cfg, batches[1:])
+    dt = (time.time() - t0) / 2
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{MODEL} fp32 oracle/eva_ref.py, 1 image x {CROPS} crops {SIZE}^2 per step, 2 timed steps after 1 warm-up "
+                      f"({dt:.2f} s/step, torch {torch.get_num_threads()} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--teacher-chunk", type=int, default=256)
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    from clipself_amd.init import synthetic_batch
+    from clipself_amd.open_clip import create_model
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.distributed import FrozenDataParallel, StudentDataParallel
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.scheduler import cosine_lr
+    from clipself_amd.training.train import train_step
+
+    rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    distributed = world > 1
+    torch.cuda.set_device(local)
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+    device = f"cuda:{local}"
+
+    student = create_model(MODEL, "eva", precision="amp_bf16", device=device, cache_dir=None)
+    teacher = create_model(MODEL, "eva", precision="amp_bf16", device=device, cache_dir=None, trainable=False)
+    teacher.visual.teacher_chunk = a.teacher_chunk
+    cfg = student.visual.cfg
+    student.lock_image_tower(unlocked_groups=cfg.layers)
+    student.train()
+    teacher.eval()
+    model, dist_model = student, teacher
+    if distributed:
+        model, dist_model = StudentDataParallel(student), FrozenDataParallel(teacher)
+    opt = FlatAdamW(student, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, grad_divisor=float(world))
+    sched = cosine_lr(opt, 1e-5, 1000, 100000)
+    args = SimpleNamespace(device=device, precision="amp_bf16", distributed=distributed, skip_scheduler=False, grad_clip_norm=None,
+                           multiscale=False, extract_type="v2", cosine_weight=1.0)
+    batch = tuple(t.to(device) for t in synthetic_batch(BATCH, CROPS, SIZE, SIZE, seed=1234, rank=rank))
+    method = CLIPSelf()
+    timer = KernelTimer(teacher.visual.engine.ops, epi=3)     # the fused SwiGLU GEMM is launched by the teacher's engine
+
+    def sync():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(a.warmup):
+        train_step(model, method, batch, opt, sched, step, dist_model, args)
+        step += 1
+    sync()
+    timer.on = True
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(a.steps):
+        last, _, _ = train_step(model, method, batch, opt, sched, step, dist_model, args)
+        step += 1
+    sync()
+    elapsed = time.perf_counter() - t0
+    timer.on = False
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(last["loss"]) if last is not None else float("nan")
+
+    if rank == 0:
+        ips = world * BATCH * a.steps / elapsed
+        F = flops_per_image(cfg, CROPS)
+        kt = timer.result()
+        out = {
+            "metric": "images/sec (student+teacher distill step), ViT-B/16 32 crops/img",
+            "value": ips, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / max(a.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{MODEL} CLIPSelf image-patches step, {BATCH} images x {CROPS} crops per GPU, {SIZE}^2 (BASELINE configs[1])",
+                       "global_batch": BATCH * world, "crops_per_image": CROPS, "image_size": SIZE,
+                       "parallelism": f"dp{world}", "teacher_chunk": a.teacher_chunk, "loss_last_step": loss},
+            "step_tflops": F * ips / 1e12, "step_mfma_frac": F * ips / 1e12 / (PEAK_BF16_TFLOPS * world),
+        }
+        if kt:
+            out["roofline"] = {"bound": "mfma", "achieved": kt["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": kt["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                               "kernel": "gemm_nt_kernel<EPI_SWIGLU_BF16> (teacher W1|W2 GEMM + SiLU*mul, M=chunk*197,N=4096,K=768)",
+                               "launches": kt["launches"], "mean_us": kt["mean_us"], "flops_per_launch": kt["flops_per_launch"]}
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:          # the oracle lives in tests' territory; never let it break the GPU number
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

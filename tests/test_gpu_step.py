@@ -1,0 +1,176 @@
+"""`-m gpu`: the whole CLIPSelf step on the MI355X through the drop-in API (HIP kernels only), against golden
+vectors captured from the real reference (tests/golden, made by oracle/gen_golden.py) and, at full BASELINE size,
+against size-independent properties."""
+import json
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from clipself_amd.config import get_tower_cfg, tiny_cfg          # noqa: E402
+from clipself_amd.init import seeded_visual_state, synthetic_batch  # noqa: E402
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def one_minus_cos(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((1 - torch.nn.functional.cosine_similarity(a, b, dim=-1)).max())
+
+
+def _args(**kw):
+    base = dict(device="cuda", precision="amp", distributed=False, skip_scheduler=False, grad_clip_norm=None,
+                multiscale=False, extract_type="v2", cosine_weight=1.0)
+    base.update(kw)
+    return SimpleNamespace(**base)
+
+
+def _pair(cfg, seed):
+    from clipself_amd.open_clip.model import CustomCLIP
+    student, teacher = CustomCLIP(cfg, trainable=True), CustomCLIP(cfg, trainable=False)
+    for m in (student, teacher):
+        m.visual.engine.load_state(seeded_visual_state(cfg, seed))
+    student.lock_image_tower(unlocked_groups=cfg.layers)
+    student.train()
+    teacher.eval()
+    return student, teacher
+
+
+def _log(msg):
+    from pathlib import Path
+    p = Path(__file__).resolve().parent.parent / "gpurun_out"
+    p.mkdir(exist_ok=True)
+    with open(p / "step_metrics.txt", "a") as f:
+        f.write(msg + "\n")
+
+
+def test_tiny_step_matches_reference_goldens(golden_dir):
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.scheduler import cosine_lr
+    from clipself_amd.training.train import train_step
+    g = np.load(golden_dir / "tiny_step.npz")
+    rec = json.loads(str(g["recipe"]))
+    cfg = tiny_cfg()
+    student, teacher = _pair(cfg, rec["seed_w"])
+    assert type(student.visual.engine.ops).__name__ == "HipOps"
+    images, boxes, crops = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"])
+    with torch.no_grad():
+        t = teacher.encode_image(crops.flatten(0, 1).cuda())
+        s = student.encode_pseudo_boxes(images.cuda(), [b[:, :4].cuda() for b in boxes])
+        d = student.encode_dense(images.cuda(), keep_shape=False)
+        im64, bx64, _ = synthetic_batch(2, 3, 64, cfg.image_size, seed=77)
+        r64 = student.encode_pseudo_boxes(im64.cuda(), [b[:, :4].cuda() for b in bx64])
+    _log(f"tiny teacher rel={rel(t, g['teacher']):.3e} 1-cos={one_minus_cos(t, g['teacher']):.2e}; roi rel={rel(s, g['student_roi']):.3e} "
+         f"1-cos={one_minus_cos(s, g['student_roi']):.2e}; dense rel={rel(d, g['dense']):.3e}; roi64 rel={rel(r64, g['roi64']):.3e}")
+    assert rel(t, g["teacher"]) < 2e-2 and one_minus_cos(t, g["teacher"]) < 1e-3
+    assert rel(s, g["student_roi"]) < 2e-2 and one_minus_cos(s, g["student_roi"]) < 1e-3
+    assert rel(d, g["dense"]) < 2e-2
+    assert rel(r64, g["roi64"]) < 2e-2                      # rescaled pos-embed + regenerated RoPE tables (8x8 grid)
+    opt = FlatAdamW(student, lr=rec["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=rec["wd"])
+    sched = cosine_lr(opt, rec["lr"], rec["warmup"], rec["total"])
+    losses = []
+    for step in range(rec["steps"]):
+        batch = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"] + step)
+        out, bs, _ = train_step(student, CLIPSelf(), batch, opt, sched, step, teacher, _args())
+        losses.append(float(out["loss"]))
+        if step == 0:
+            none = {str(n) for n in g["grad_none"]}
+            worst = 0.0
+            for n, p in student.named_parameters():
+                if not p.requires_grad:
+                    continue
+                if n in none:
+                    assert p.grad is None, n
+                    continue
+                r = rel(p.grad, g["grad/" + n])
+                worst = max(worst, r)
+                assert r < 6e-2, f"{n}: {r:.3e}"
+            _log(f"tiny worst grad rel={worst:.3e}")
+    _log(f"tiny losses {losses} vs {g['losses'].tolist()}")
+    assert np.allclose(losses, g["losses"], atol=1e-2)
+    w = dict(student.named_parameters())["visual.blocks.0.mlp.w1.weight"]
+    assert rel(w, g["final/visual.blocks.0.mlp.w1.weight"]) < 2e-2
+
+
+def test_b16_cfg1_matches_reference_goldens(golden_dir):
+    """BASELINE configs[0]: EVA02-CLIP-B-16, 2 images x 8 boxes, 224^2: loss, feature directions, every gradient norm,
+    the grad-None set and the 4-step loss trajectory of the real reference."""
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.scheduler import cosine_lr
+    from clipself_amd.training.train import train_step
+    g = np.load(golden_dir / "b16_cfg1.npz")
+    rec = json.loads(str(g["recipe"]))
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    student, teacher = _pair(cfg, rec["seed_w"])
+    opt = FlatAdamW(student, lr=rec["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=rec["wd"])
+    sched = cosine_lr(opt, rec["lr"], rec["warmup"], rec["total"])
+    losses = []
+    for step in range(rec["steps"]):
+        batch = synthetic_batch(rec["batch"], rec["boxes"], 224, 224, seed=rec["seed_b"] + step)
+        if step == 0:
+            with torch.no_grad():
+                t = teacher.encode_image(batch[2].flatten(0, 1).cuda())
+                s = student.encode_pseudo_boxes(batch[0].cuda(), [b[:, :4].cuda() for b in batch[1]])
+            cos = torch.nn.functional.cosine_similarity(t, s, dim=-1).cpu()
+            _log(f"b16 teacher_slice rel={rel(t[:4, :16], g['teacher_slice']):.3e} roi_slice rel={rel(s[:4, :16], g['student_roi_slice']):.3e} "
+                 f"rownorm rel t={rel(t.norm(dim=-1), g['teacher_rownorm']):.3e} s={rel(s.norm(dim=-1), g['student_rownorm']):.3e} "
+                 f"cos maxabs={float((cos - torch.from_numpy(g['cos'])).abs().max()):.3e}")
+            assert rel(t[:4, :16], g["teacher_slice"]) < 3e-2 and rel(s[:4, :16], g["student_roi_slice"]) < 3e-2
+            assert rel(t.norm(dim=-1), g["teacher_rownorm"]) < 1e-2 and rel(s.norm(dim=-1), g["student_rownorm"]) < 1e-2
+            assert float((cos - torch.from_numpy(g["cos"])).abs().max()) < 5e-3
+        out, bs, _ = train_step(student, CLIPSelf(), batch, opt, sched, step, teacher, _args())
+        losses.append(float(out["loss"]))
+        if step == 0:
+            none = {str(n) for n in g["grad_none"]}
+            norms = dict(zip((str(x) for x in g["grad_names"]), g["grad_norms"]))
+            worst = ("", 0.0)
+            for n, p in student.named_parameters():
+                if not p.requires_grad:
+                    continue
+                if n in none:
+                    assert p.grad is None, n
+                    continue
+                r = abs(float(p.grad.double().norm()) - norms[n]) / norms[n]
+                if r > worst[1]:
+                    worst = (n, r)
+                assert r < 5e-2, f"{n}: grad-norm rel {r:.3e}"
+            for n in ("visual.blocks.11.mlp.w3.bias", "visual.blocks.0.norm1.weight", "visual.blocks.5.attn.q_bias", "visual.blocks.11.attn.v_bias"):
+                r = rel(dict(student.named_parameters())[n].grad, g["grad/" + n])
+                _log(f"b16 grad {n} rel={r:.3e}")
+                assert r < 6e-2, n
+            _log(f"b16 worst grad-norm rel {worst}")
+    _log(f"b16 losses {losses} vs {g['losses'].tolist()}")
+    assert abs(losses[0] - g["losses"][0]) / g["losses"][0] < 1e-3          # north-star tolerance on the loss
+    assert np.allclose(losses, g["losses"], rtol=2e-3)
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] shapes (64 images x 32 crops): properties that need no oracle run --
+    dense map rows are unit vectors; a box covering exactly one token cell returns that token (norm 1);
+    permuting images permutes outputs; teacher chunking does not change results."""
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    student, teacher = _pair(cfg, 0)
+    images, boxes, crops = synthetic_batch(64, 32, 224, 224, seed=3)
+    images, crops = images.cuda(), crops.flatten(0, 1).cuda()
+    with torch.no_grad():
+        d = student.encode_dense(images, keep_shape=False)
+        assert torch.allclose(d.norm(dim=-1), torch.ones_like(d[..., 0]), atol=1e-4)
+        cell = torch.tensor([[3 / 14, 5 / 14, 4 / 14, 6 / 14]], device="cuda")       # x in [3,4), y in [5,6) -> token (5,3)
+        one = student.encode_pseudo_boxes(images[:1], [cell])
+        assert rel(one[0], d[0, 5 * 14 + 3]) < 1e-5
+        perm = torch.randperm(64, device="cuda")
+        d2 = student.encode_dense(images[perm], keep_shape=False)
+        assert torch.equal(d2, d[perm])
+        t_a = teacher.encode_image(crops[:300])
+        teacher.visual.teacher_chunk = 77
+        t_b = teacher.encode_image(crops[:300])
+        assert torch.equal(t_a, t_b)
+        assert torch.isfinite(t_a).all()
