@@ -163,7 +163,7 @@ def test_full_size_properties():
     with torch.no_grad():
         d = student.encode_dense(images, keep_shape=False)
         assert torch.allclose(d.norm(dim=-1), torch.ones_like(d[..., 0]), atol=1e-4)
-        cell = torch.tensor([[3 / 14, 5 / 14, 4 / 14, 6 / 14]], device="cuda")       # x in [3,4), y in [5,6) -> token (5,3)
+        cell = torch.tensor([[3.1 / 14, 5.1 / 14, 3.9 / 14, 5.9 / 14]], device="cuda")   # one sample at the centre of token (5,3)
         one = student.encode_pseudo_boxes(images[:1], [cell])
         assert rel(one[0], d[0, 5 * 14 + 3]) < 1e-5
         perm = torch.randperm(64, device="cuda")
