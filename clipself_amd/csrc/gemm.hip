@@ -9,20 +9,27 @@
 //   dgrad    dx = dy W          A = dy [M,N'],    B = W^T [K',N'] (bf16 shadow kept transposed)
 //   wgrad    dW = dy^T x        A = dy^T [N',Mp], B = x^T [K',Mp] (explicit transposes, split-K)
 //
-// Tiling: 128x128x64 per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA 32x32x16
-// tiles, 64 fp32 accumulators/lane).  Operands are staged global -> LDS with the direct
-// `global_load_lds` 16-byte DMA (lane-linear LDS image; the XOR bank swizzle is applied to the
-// per-lane *source* chunk and again on the ds_read_b128 side), double buffered, one barrier per
-// K tile.  Workgroup ids are remapped so that each XCD (private L2) owns a contiguous range of
-// M panels and walks the N tiles of a panel back to back (A panel re-use stays in that L2).
+// Structure (MI355X: 256 CUs x 4 SIMDs, 64-lane waves, 160 KiB LDS/CU, 8 XCDs with private L2):
+//   * workgroup tile BM x BN x 64, three shapes: 256x256 (8 waves, 128x64 per wave, 1 WG/CU), 256x128 (8 waves,
+//     64x64 per wave) and 128x128 (4 waves); MFMA 32x32x16 bf16, fp32 accumulators in registers.
+//     The large tiles exist to cut LDS traffic per MFMA (operand re-use across the wave tile and across waves):
+//     at 128x128 the LDS-DMA fill + fragment reads cost about as many LDS cycles as the MFMAs themselves.
+//   * operands go global -> LDS with the 16-byte `global_load_lds` DMA (no VGPR round trip), double buffered,
+//     one barrier per K tile.  The LDS image is lane-linear by construction of that instruction, so the bank
+//     swizzle is applied to the per-lane SOURCE address: two 128-byte tile rows share one 256-byte LDS row whose
+//     sixteen 16-byte slots are XOR-permuted by (lds_row & 15) -> every ds_read_b128 lane group hits 16 distinct
+//     slots (conflict free).
+//   * epilogue through LDS: each wave parks a 32 x TN fp32 slab of its accumulators in a private LDS region and
+//     reads it back row-wise, so global stores/loads (bias, residual, pos-embed) are 16-byte per lane and cover
+//     whole 256-byte row segments instead of 2-byte scattered stores.
+//   * workgroup ids are remapped so that each XCD owns a contiguous range of M panels and walks the N tiles of a
+//     panel back to back (the A panel is fetched from HBM once per XCD L2).
 #include "cs_common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per operand tile
-
+constexpr int BK = 64;
 enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID_F32 = 2, EPI_SWIGLU_BF16 = 3, EPI_ATOMIC_F32 = 4, EPI_PATCH_F32 = 5 };
 
 struct GemmArgs {
@@ -38,16 +45,26 @@ struct GemmArgs {
     int group;            // EPI_PATCH: tokens-1 per image ; EPI_SWIGLU: hidden width Hd
 };
 
-__device__ __forceinline__ void stage_tile(const __bf16* __restrict__ src, int ld, int k0, char* lds_tile,
-                                           int wave, int lane, const int (&grow)[4], bool use_glds) {
-    // tile = 128 rows x 8 chunks(16 B).  Wave w, step i covers rows (w*4+i)*8 .. +8; lane -> (row&7 = lane>>3, slot = lane&7)
-    // and fetches source chunk slot ^ (row&7) so that LDS holds chunk c of row r at slot c ^ (r&7).
-    const int chunk = (lane & 7) ^ (lane >> 3);
+// LDS byte offset of (tile row r, 16-byte chunk c) inside an operand tile of 128-byte rows
+__device__ __forceinline__ int lds_off(int r, int c) { return ((r >> 1) << 8) + (((((r & 1) << 3) | c) ^ ((r >> 1) & 15)) << 4); }
+
+// One wave instruction fills 1 KiB = 8 tile rows (row group rg).  Lane l lands at rg*1024 + l*16, i.e. LDS row
+// rg*4 + (l>>4), slot l&15, and must therefore fetch the chunk that lds_off() maps to that slot.
+__device__ __forceinline__ void lane_source(int rg, int lane, int& tile_row, int& chunk) {
+    const int lrow = rg * 4 + (lane >> 4);
+    const int c16 = (lane & 15) ^ (lrow & 15);
+    tile_row = lrow * 2 + (c16 >> 3);
+    chunk = c16 & 7;
+}
+
+template <int NINSTR, bool GLDS>
+__device__ __forceinline__ void stage_tile(const __bf16* __restrict__ src, int ld, int k0, char* lds_tile, int rg0, int lane,
+                                           const int (&grow)[NINSTR], const int (&gchunk)[NINSTR]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const __bf16* g = src + (size_t)grow[i] * ld + k0 + chunk * 8;
-        char* dst = lds_tile + (wave * 4 + i) * 1024;     // wave-uniform
-        if (use_glds) {
+    for (int i = 0; i < NINSTR; ++i) {
+        const __bf16* g = src + (size_t)grow[i] * ld + k0 + gchunk[i] * 8;
+        char* dst = lds_tile + (rg0 + i) * 1024;          // wave-uniform
+        if (GLDS) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         } else {
@@ -56,15 +73,23 @@ __device__ __forceinline__ void stage_tile(const __bf16* __restrict__ src, int l
     }
 }
 
-template <int EPI, bool GLDS>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+constexpr int EP_LD = 68;                       // fp32 row stride of the epilogue slab (64 + 4 pad)
+constexpr int EP_BYTES = 32 * EP_LD * 4;        // 32 rows per wave slab
+
+template <int EPI, int BM, int BN, int WM, int WN, bool GLDS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;           // wave tile
+    constexpr int FM = TM / 32, FN = TN / 32;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+    static_assert(TN == 64, "epilogue assumes 64-column wave tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // buffer b: A tile at smem + b*2*TILE_BYTES, B tile right after it
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave - wm * WN;
     const int hf = lane >> 5, l31 = lane & 31;
 
     // ---- XCD-aware bijective remap of the 1-D workgroup id (block b runs on XCD b % 8)
@@ -73,18 +98,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int tn = swz % p.tiles_n, tm = swz / p.tiles_n;
     const int m0 = tm * BM;
-    const int n0 = tn * BN;          // for EPI_SWIGLU: tile-local packing, see below
+    const int n0 = tn * BN;
 
-    // ---- source rows for the 4 staging steps of this wave
-    int arow[4], brow[4];
+    // ---- per-lane source rows/chunks of this wave's staging instructions
+    int arow[A_INSTR], achk[A_INSTR], brow[B_INSTR], bchk[B_INSTR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int tr = (wave * 4 + i) * 8 + (lane >> 3);       // tile-local row
+    for (int i = 0; i < A_INSTR; ++i) {
+        int tr;
+        lane_source(wave * A_INSTR + i, lane, tr, achk[i]);
         arow[i] = min(m0 + tr, p.M - 1);
+    }
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        int tr;
+        lane_source(wave * B_INSTR + i, lane, tr, bchk[i]);
         if (EPI == EPI_SWIGLU_BF16) {
-            // tile rows [wn'*64 + jj*32 + t] <- weight row jj*Hd + (tn*64 + wn'*32 + t): x1 and x2 of the
-            // same hidden unit land in the same lane/register of accumulator tiles j=0 / j=1.
-            const int hidx = tn * 64 + (tr >> 6) * 32 + (tr & 31);
+            // tile rows [w*64 + jj*32 + t] <- weight row jj*Hd + (tn*(BN/2) + w*32 + t): x1 and x2 of one hidden unit land in
+            // the same lane/register of accumulator column-tiles j=0 / j=1 of wave column w.
+            const int hidx = tn * (BN / 2) + (tr >> 6) * 32 + (tr & 31);
             brow[i] = ((tr >> 5) & 1) * p.group + min(hidx, p.group - 1);
         } else {
             brow[i] = min(n0 + tr, p.N - 1);
@@ -94,108 +125,167 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     const int kt_begin = blockIdx.y * p.ktiles_per_split;
     const int kt_end = min(kt_begin + p.ktiles_per_split, p.K / BK);
 
-    f32x16 acc[2][2];
+    f32x16 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (kt_begin < kt_end) {
-        stage_tile(p.A, p.lda, kt_begin * BK, smem, wave, lane, arow, GLDS);
-        stage_tile(p.B, p.ldb, kt_begin * BK, smem + TILE_BYTES, wave, lane, brow, GLDS);
+        stage_tile<A_INSTR, GLDS>(p.A, p.lda, kt_begin * BK, smem, wave * A_INSTR, lane, arow, achk);
+        stage_tile<B_INSTR, GLDS>(p.B, p.ldb, kt_begin * BK, smem + A_BYTES, wave * B_INSTR, lane, brow, bchk);
     }
+    // fragment addressing: row = base + l31 with base a multiple of 32 -> (row>>1)&15 == l31>>1, row&1 == l31&1
+    const int a_base = ((wm * TM + l31) >> 1) << 8;
+    const int b_base = ((wn * TN + l31) >> 1) << 8;
+    const int par8 = (l31 & 1) << 3, sw = l31 >> 1;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
         __syncthreads();            // tile kt landed (the barrier drains the LDS-DMA queue); buffer cur^1 is free
         if (kt + 1 < kt_end) {
-            stage_tile(p.A, p.lda, (kt + 1) * BK, smem + (cur ^ 1) * 2 * TILE_BYTES, wave, lane, arow, GLDS);
-            stage_tile(p.B, p.ldb, (kt + 1) * BK, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, wave, lane, brow, GLDS);
+            char* nxt = smem + (cur ^ 1) * STAGE;
+            stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 1) * BK, nxt, wave * A_INSTR, lane, arow, achk);
+            stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 1) * BK, nxt + A_BYTES, wave * B_INSTR, lane, brow, bchk);
         }
-        const char* la = smem + cur * 2 * TILE_BYTES + (wm * 64 + l31) * 128;
-        const char* lb = smem + cur * 2 * TILE_BYTES + TILE_BYTES + (wn * 64 + l31) * 128;
-        const int sw = lane & 7;    // (row & 7): the 32/64-row offsets are multiples of 8
+        const char* la = smem + cur * STAGE + a_base;
+        const char* lb = smem + cur * STAGE + A_BYTES + b_base;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int off = (((ks * 2 + hf) ^ sw) << 4);
-            bf16x8 a0 = *(const bf16x8*)(la + off);
-            bf16x8 a1 = *(const bf16x8*)(la + 32 * 128 + off);
-            bf16x8 b0 = *(const bf16x8*)(lb + off);
-            bf16x8 b1 = *(const bf16x8*)(lb + 32 * 128 + off);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            const int off = ((par8 | (ks * 2 + hf)) ^ sw) << 4;
+            bf16x8 a[FM], b[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(la + i * (16 * 256) + off);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(lb + j * (16 * 256) + off);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
 
-    // ---- epilogue: lane owns column (l31) of each 32x32 tile; register e <-> row mfma32_row(e, lane)
-    if (EPI == EPI_SWIGLU_BF16) {
-        const int hcol = tn * 64 + wn * 32 + l31;
-        if (hcol < p.group) {
-            const float b1 = p.bias ? p.bias[hcol] : 0.f;
-            const float b2 = p.bias ? p.bias[p.group + hcol] : 0.f;
-            __bf16* out = (__bf16*)p.C;
+    // ---- epilogue through a wave-private LDS slab [32][EP_LD] fp32 -------------------------------------------
+    __syncthreads();                                    // every wave is done reading the operand buffers
+    float* slab = (float*)(smem + wave * EP_BYTES);
+    const int rrow = lane >> 4, rcol = (lane & 15) * 4;  // read-out: 16 lanes per row, 4 consecutive columns per lane
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FM; ++i) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = m0 + wm * 64 + i * 32 + mfma32_row(e, lane);
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slab[mfma32_row(e, lane) * EP_LD + j * 32 + l31] = acc[i][j][e];
+        __syncthreads();
+        const int row_base = m0 + wm * TM + i * 32;
+        if (EPI == EPI_SWIGLU_BF16) {
+            // slab columns [0,32) = x1, [32,64) = x2 of hidden units hcol0 .. hcol0+31; 8 lanes per row, 4 hidden units per lane
+            const int hr = lane >> 3, hc = (lane & 7) * 4;
+            const int hcol = tn * (BN / 2) + wn * 32 + hc;
+            if (hcol < p.group) {
+                float b1[4] = {0, 0, 0, 0}, b2[4] = {0, 0, 0, 0};
+                if (p.bias) {
+                    const float4 t1 = *(const float4*)(p.bias + hcol), t2 = *(const float4*)(p.bias + p.group + hcol);
+                    b1[0] = t1.x; b1[1] = t1.y; b1[2] = t1.z; b1[3] = t1.w; b2[0] = t2.x; b2[1] = t2.y; b2[2] = t2.z; b2[3] = t2.w;
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rl = hr + it * 8, row = row_base + rl;
                     if (row < p.M) {
-                        const float x1 = acc[i][0][e] + b1, x2 = acc[i][1][e] + b2;
-                        out[(size_t)row * p.ldc + hcol] = f2bf(x1 / (1.f + __expf(-x1)) * x2);
+                        const float4 x1 = *(const float4*)(slab + rl * EP_LD + hc), x2 = *(const float4*)(slab + rl * EP_LD + 32 + hc);
+                        const float u[4] = {x1.x + b1[0], x1.y + b1[1], x1.z + b1[2], x1.w + b1[3]};
+                        const float v[4] = {x2.x + b2[0], x2.y + b2[1], x2.z + b2[2], x2.w + b2[3]};
+                        U64 o;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o.e[t] = f2bf(u[t] / (1.f + __expf(-u[t])) * v[t]);
+                        *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + hcol) = o.u;
                     }
                 }
-        }
-        return;
-    }
+            }
+        } else {
+            const int col = n0 + wn * TN + rcol;
+            if (col < p.N) {
+                float bv[4] = {0, 0, 0, 0};
+                if (p.bias) { const float4 t = *(const float4*)(p.bias + col); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+                for (int it = 0; it < 8; ++it) {
+                    const int rl = rrow + it * 4, row = row_base + rl;
+                    if (row >= p.M) continue;
+                    const float4 s = *(const float4*)(slab + rl * EP_LD + rcol);
+                    float v[4] = {s.x + bv[0], s.y + bv[1], s.z + bv[2], s.w + bv[3]};
+                    if (EPI == EPI_BF16) {
+                        U64 o;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+                        for (int t = 0; t < 4; ++t) o.e[t] = f2bf(v[t]);
+                        *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + col) = o.u;
+                    } else if (EPI == EPI_F32) {
+                        *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else if (EPI == EPI_RESID_F32) {
+                        const size_t o = (size_t)row * p.ldc + col;
+                        const float4 x = *(const float4*)(p.extra + o);
+                        *(float4*)((float*)p.C + o) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
+                    } else if (EPI == EPI_ATOMIC_F32) {
+                        float* d = (float*)p.C + (size_t)row * p.ldc + col;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 64 + i * 32 + mfma32_row(e, lane);
-                if (row >= p.M) continue;
-                const float v = acc[i][j][e] + bv;
-                if (EPI == EPI_BF16) {
-                    ((__bf16*)p.C)[(size_t)row * p.ldc + col] = f2bf(v);
-                } else if (EPI == EPI_F32) {
-                    ((float*)p.C)[(size_t)row * p.ldc + col] = v;
-                } else if (EPI == EPI_RESID_F32) {
-                    const size_t o = (size_t)row * p.ldc + col;
-                    ((float*)p.C)[o] = p.extra[o] + v;
-                } else if (EPI == EPI_ATOMIC_F32) {
-                    unsafeAtomicAdd(((float*)p.C) + (size_t)row * p.ldc + col, v);
-                } else if (EPI == EPI_PATCH_F32) {
-                    const int img = row / p.group, t = row - img * p.group;
-                    ((float*)p.C)[(size_t)(row + img + 1) * p.ldc + col] = v + p.extra[(size_t)(t + 1) * p.ldc + col];
+                        for (int t = 0; t < 4; ++t) unsafeAtomicAdd(d + t, v[t]);
+                    } else if (EPI == EPI_PATCH_F32) {
+                        const int img = row / p.group, t = row - img * p.group;
+                        const float4 x = *(const float4*)(p.extra + (size_t)(t + 1) * p.ldc + col);
+                        *(float4*)((float*)p.C + (size_t)(row + img + 1) * p.ldc + col) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
+                    }
                 }
             }
+        }
+        if (i + 1 < FM) __syncthreads();                // slab is rewritten by the next 32-row block
     }
 }
 
-template <int EPI>
-int launch(const GemmArgs& a, int splits, int use_glds, hipStream_t stream) {
-    dim3 grid(a.tiles_m * a.tiles_n, splits), block(256);
-    const size_t lds = 4 * TILE_BYTES;
+template <int EPI, int BM, int BN, int WM, int WN>
+int launch_cfg(GemmArgs a, int splits, int use_glds, hipStream_t stream) {
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + BN / 2 - 1) / (BN / 2) : (a.N + BN - 1) / BN;
+    constexpr int NW = WM * WN;
+    constexpr size_t stage = (size_t)(BM + BN) * BK * 2 * 2;
+    constexpr size_t lds = stage > (size_t)NW * EP_BYTES ? stage : (size_t)NW * EP_BYTES;
+    dim3 grid(a.tiles_m * a.tiles_n, splits), block(NW * 64);
     if (use_glds) {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, true>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, true>,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, true>), grid, block, lds, stream, a);
     } else {
-        static bool once = (hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, false>,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, false>), grid, block, lds, stream, a);
     }
     CS_LAUNCH_CHECK();
     return 0;
+}
+
+// tile-shape choice: prefer the big tiles (less LDS traffic per MFMA) unless the grid would leave CUs idle
+inline double wave_eff(long tiles, int per_cu) {
+    const long slots = 256L * per_cu;
+    const long rounds = (tiles + slots - 1) / slots;
+    return (double)tiles / (double)(rounds * slots);
+}
+
+template <int EPI>
+int launch(const GemmArgs& a, int splits, int use_glds, int force_cfg, hipStream_t stream) {
+    const long ncols = (EPI == EPI_SWIGLU_BF16) ? 2L * a.group : a.N;
+    auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((ncols + bn - 1) / bn) * splits; };
+    int cfg = force_cfg;
+    if (cfg == 0) {
+        const double s_big = (a.M >= 256 && ncols >= 256) ? 1.00 * wave_eff(tiles(256, 256), 1) : 0.0;
+        const double s_mid = (a.M >= 256 && ncols >= 128) ? 0.85 * wave_eff(tiles(256, 128), 1) : 0.0;
+        const double s_small = 0.62 * wave_eff(tiles(128, 128), 2);
+        cfg = (s_big >= s_mid && s_big >= s_small) ? 3 : (s_mid >= s_small ? 2 : 1);
+    }
+    switch (cfg) {
+        case 3: return launch_cfg<EPI, 256, 256, 2, 4>(a, splits, use_glds, stream);
+        case 2: return launch_cfg<EPI, 256, 128, 4, 2>(a, splits, use_glds, stream);
+        default: return launch_cfg<EPI, 128, 128, 2, 2>(a, splits, use_glds, stream);
+    }
 }
 
 }  // namespace
@@ -206,36 +296,35 @@ int launch(const GemmArgs& a, int splits, int use_glds, hipStream_t stream) {
 //      4 f32 atomic accumulate (split-K, C pre-zeroed or accumulating) |
 //      5 patch-embed: out row = row + row/group + 1, += extra[(row%group+1)*ldc + col]
 // flags bit0: 0 = global_load_lds staging, 1 = register staging (debug/fallback A-B switch)
-extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra,
-                          int M, int N, int K, int lda, int ldb, int ldc, int epi, int splits, int group,
-                          int flags, hipStream_t stream) {
+//       bits 4-5: force tile shape (1 = 128x128, 2 = 256x128, 3 = 256x256; 0 = heuristic)
+extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
+                          int lda, int ldb, int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
     CS_CHECK_ARG(M > 0 && N > 0 && K > 0, "cs_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
     CS_CHECK_ARG(K % BK == 0, "cs_gemm_nt: K=%d must be a multiple of %d", K, BK);
     CS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0, "cs_gemm_nt: lda/ldb must be multiples of 8 (16-byte rows)");
     CS_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "cs_gemm_nt: operands must be 16-byte aligned");
     CS_CHECK_ARG(splits >= 1 && (splits == 1 || epi == EPI_ATOMIC_F32), "cs_gemm_nt: split-K needs the atomic epilogue");
+    CS_CHECK_ARG((epi == EPI_SWIGLU_BF16 ? group : N) % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16) == 0,
+                 "cs_gemm_nt: N, ldc must be multiples of 4 and C 16-byte aligned (vector epilogue)");
+    CS_CHECK_ARG(bias == nullptr || ((uintptr_t)bias % 16) == 0, "cs_gemm_nt: bias must be 16-byte aligned");
     GemmArgs a;
     a.A = (const __bf16*)A; a.B = (const __bf16*)B; a.C = C; a.bias = bias; a.extra = extra;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.group = group;
-    a.tiles_m = (M + BM - 1) / BM;
-    if (epi == EPI_SWIGLU_BF16) {
-        CS_CHECK_ARG(group > 0 && N == 2 * group, "cs_gemm_nt: swiglu epilogue needs N == 2*group");
-        a.tiles_n = (group + 63) / 64;
-    } else {
-        a.tiles_n = (N + BN - 1) / BN;
-    }
-    if (epi == EPI_PATCH_F32 || epi == EPI_RESID_F32) CS_CHECK_ARG(extra != nullptr, "cs_gemm_nt: epilogue %d needs extra", epi);
+    a.tiles_m = a.tiles_n = 0;
+    if (epi == EPI_SWIGLU_BF16) CS_CHECK_ARG(group > 0 && N == 2 * group, "cs_gemm_nt: swiglu epilogue needs N == 2*group");
+    if (epi == EPI_PATCH_F32 || epi == EPI_RESID_F32) CS_CHECK_ARG(extra != nullptr && ((uintptr_t)extra % 16) == 0, "cs_gemm_nt: epilogue %d needs 16-byte aligned extra", epi);
     if (epi == EPI_PATCH_F32) CS_CHECK_ARG(group > 0, "cs_gemm_nt: patch epilogue needs group");
     const int ktiles = K / BK;
     a.ktiles_per_split = (ktiles + splits - 1) / splits;
     const int glds = (flags & 1) ? 0 : 1;
+    const int force = (flags >> 4) & 3;
     switch (epi) {
-        case EPI_BF16: return launch<EPI_BF16>(a, splits, glds, stream);
-        case EPI_F32: return launch<EPI_F32>(a, splits, glds, stream);
-        case EPI_RESID_F32: return launch<EPI_RESID_F32>(a, splits, glds, stream);
-        case EPI_SWIGLU_BF16: return launch<EPI_SWIGLU_BF16>(a, splits, glds, stream);
-        case EPI_ATOMIC_F32: return launch<EPI_ATOMIC_F32>(a, splits, glds, stream);
-        case EPI_PATCH_F32: return launch<EPI_PATCH_F32>(a, splits, glds, stream);
+        case EPI_BF16: return launch<EPI_BF16>(a, splits, glds, force, stream);
+        case EPI_F32: return launch<EPI_F32>(a, splits, glds, force, stream);
+        case EPI_RESID_F32: return launch<EPI_RESID_F32>(a, splits, glds, force, stream);
+        case EPI_SWIGLU_BF16: return launch<EPI_SWIGLU_BF16>(a, splits, glds, force, stream);
+        case EPI_ATOMIC_F32: return launch<EPI_ATOMIC_F32>(a, splits, glds, force, stream);
+        case EPI_PATCH_F32: return launch<EPI_PATCH_F32>(a, splits, glds, force, stream);
     }
     cs_set_error("cs_gemm_nt: unknown epilogue %d", epi);
     return -1;

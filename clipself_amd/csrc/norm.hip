@@ -184,14 +184,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
 }
 
 // part [nparts][2][C] -> dgamma[C] (+=), dbeta[C] (+=)
-__global__ void ln_param_reduce_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * C) return;
+// 64 columns per workgroup, the 4 waves split the partial rows 4 ways, LDS combine in fixed order (deterministic)
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * 2 * C + c];
-    float* dst = c < C ? dgamma + c : dbeta + (c - C);
-    *dst = accumulate ? *dst + s : s;
+    if (c < 2 * C)
+        for (int p = w; p < nparts; p += 4) s += part[(size_t)p * 2 * C + c];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < 2 * C) {
+        s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float* dst = c < C ? dgamma + c : dbeta + (c - C);
+        *dst = accumulate ? *dst + s : s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -253,7 +261,7 @@ extern "C" int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const floa
 // dx_mode: 0 = write bf16, 1 = write f32, 2 = accumulate into f32 (residual-gradient stream).
 // dgamma/dbeta may be null (frozen LN); otherwise `workspace` must hold cs_layernorm_bwd_workspace(M,C) bytes.
 extern "C" size_t cs_layernorm_bwd_workspace(int M, int C) {
-    const int nwg = min(1024, (M + 3) / 4);
+    const int nwg = min(512, (M + 3) / 4);
     return (size_t)nwg * 2 * C * sizeof(float);
 }
 extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
@@ -264,7 +272,7 @@ extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_
     CS_CHECK_ARG(dx_mode >= 0 && dx_mode <= 2, "cs_layernorm_bwd: bad dx_mode");
     CS_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "cs_layernorm_bwd: dgamma/dbeta must both be given or both null");
     CS_CHECK_ARG(dgamma == nullptr || workspace != nullptr, "cs_layernorm_bwd: workspace required for dgamma/dbeta");
-    const int nwg = min(1024, (M + 3) / 4);
+    const int nwg = min(512, (M + 3) / 4);
     float* part = dgamma ? (float*)workspace : nullptr;
     const size_t lds = (size_t)3 * 2 * C * sizeof(float);
     dim3 grid(nwg), block(256);
@@ -284,7 +292,7 @@ extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_
 #undef LNB3
     CS_LAUNCH_CHECK();
     if (dgamma) {
-        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, part, nwg, C, dgamma, dbeta, accumulate_params);
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, stream, part, nwg, C, dgamma, dbeta, accumulate_params);
         CS_LAUNCH_CHECK();
     }
     return 0;

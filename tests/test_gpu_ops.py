@@ -52,7 +52,7 @@ def both(cpu_tensors):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x31])      # heuristic, register staging, forced 128x128 / 256x128 / 256x256
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (3152, 768, 768), (300, 192, 64), (128, 64, 256), (1000, 2304, 768)])
 def test_gemm_bf16_bias(hip, ref, M, N, K, flags):
     A, B, bias = rnd((M, K), BF, seed=1), rnd((N, K), BF, 0.05, seed=2), rnd((N,), F32, seed=3)
@@ -64,7 +64,7 @@ def test_gemm_bf16_bias(hip, ref, M, N, K, flags):
     check(f"gemm_bf16[{M},{N},{K}] flags={flags}", Cd, Cr, TOL_BF)
 
 
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30])
 def test_gemm_f32_resid_strided(hip, ref, flags):
     M, N, K = 788, 768, 2048
     Abig = rnd((M, K + 64), BF, seed=4)
@@ -83,15 +83,16 @@ def test_gemm_f32_resid_strided(hip, ref, flags):
     check(f"gemm_f32_nobias flags={flags}", Cd2, Cr2, TOL_F32)
 
 
+@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30])
 @pytest.mark.parametrize("Hd,M", [(2048, 394), (256, 34), (96, 130)])
-def test_gemm_swiglu(hip, ref, Hd, M):
+def test_gemm_swiglu(hip, ref, Hd, M, flags):
     K = 128
     A, W, bias = rnd((M, K), BF, seed=8), rnd((2 * Hd, K), BF, 0.1, seed=9), rnd((2 * Hd,), F32, 0.5, seed=10)
     Cr = torch.empty(M, Hd, dtype=BF)
     ref.gemm_nt(A, W, Cr, bias, epi=3, group=Hd)
     Cd = torch.full((M, Hd), float("nan"), dtype=BF, device="cuda")
-    hip.gemm_nt(A.cuda(), W.cuda(), Cd, bias.cuda(), epi=3, group=Hd)
-    check(f"gemm_swiglu[{M},{Hd}]", Cd, Cr, TOL_BF)
+    hip.gemm_nt(A.cuda(), W.cuda(), Cd, bias.cuda(), epi=3, group=Hd, flags=flags)
+    check(f"gemm_swiglu[{M},{Hd}] flags={flags}", Cd, Cr, TOL_BF)
 
 
 def test_gemm_splitk_atomic_wgrad_shape(hip, ref):
@@ -101,9 +102,10 @@ def test_gemm_splitk_atomic_wgrad_shape(hip, ref):
     base = rnd((N, Kd), F32, seed=13)
     Cr = base.clone()
     ref.gemm_nt(A, B, Cr, epi=4)
-    Cd = base.cuda()
-    hip.gemm_nt(A.cuda(), B.cuda(), Cd, epi=4, splits=7)
-    check("gemm_splitk_atomic", Cd, Cr, TOL_F32)
+    for flags in (0, 0x10, 0x20, 0x30):
+        Cd = base.cuda()
+        hip.gemm_nt(A.cuda(), B.cuda(), Cd, epi=4, splits=7, flags=flags)
+        check(f"gemm_splitk_atomic flags={flags}", Cd, Cr, TOL_F32)
 
 
 def test_gemm_patch_epilogue(hip, ref):
@@ -112,9 +114,10 @@ def test_gemm_patch_epilogue(hip, ref):
     pos = rnd((G + 1, N), F32, seed=17)
     Cr = torch.zeros(nimg * (G + 1), N)
     ref.gemm_nt(A, W, Cr, bias, pos, epi=5, group=G)
-    Cd = torch.zeros(nimg * (G + 1), N, device="cuda")
-    hip.gemm_nt(A.cuda(), W.cuda(), Cd, bias.cuda(), pos.cuda(), epi=5, group=G)
-    check("gemm_patch", Cd, Cr, TOL_F32)
+    for flags in (0x10, 0x20, 0x30, 0):
+        Cd = torch.zeros(nimg * (G + 1), N, device="cuda")
+        hip.gemm_nt(A.cuda(), W.cuda(), Cd, bias.cuda(), pos.cuda(), epi=5, group=G, flags=flags)
+        check(f"gemm_patch flags={flags}", Cd, Cr, TOL_F32)
     cls = rnd((N,), F32, seed=18)
     xr, xd = Cr.reshape(nimg, G + 1, N), Cd.reshape(nimg, G + 1, N)
     ref.cls_row(xr, cls, pos)
