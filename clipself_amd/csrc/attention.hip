@@ -100,9 +100,73 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int ks, in
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// LDS images of the forward kernel:
+//   K  : [keys][64] bf16, two 128-byte key rows per 256-byte LDS row, sixteen 16-byte slots XOR-permuted by
+//        (lds_row & 15)  -> conflict-free ds_write_b128 (staging) and ds_read_b128 (MFMA A fragments)
+//   V^T: [64 d][VT_LD keys] bf16 built by an in-register 8x8 transpose (8 keys x 8 dims per thread, eight
+//        ds_write_b128); key blocks of 8 are XOR-permuted by (d>>3)&7 so the 8 writers of one key block hit 8 slots.
+constexpr int VT_LD = 264;            // 33 blocks of 8 keys: odd block stride -> ds_read_b128 rows spread over all slots
+
+__device__ __forceinline__ int k_off(int r, int c) { return ((r >> 1) << 8) + (((((r & 1) << 3) | c) ^ ((r >> 1) & 15)) << 4); }
+
+template <int CHK>
+__device__ __forceinline__ void stage_k(const __bf16* __restrict__ src, size_t rowbase, int ld, int coloff, int tok0, int Ntok,
+                                        const float* cos_t, const float* sin_t, char* tile, int tid) {
+    for (int idx = tid; idx < CHK * 8; idx += 512) {
+        const int r = idx >> 3, c = idx & 7, tok = tok0 + r;
+        U128 v;
+        if (tok < Ntok) {
+            v.u = *(const uint4*)(src + (rowbase + tok) * ld + coloff + c * 8);
+            if (tok > 0) rope8(v, cos_t + (size_t)(tok - 1) * HD + c * 8, sin_t + (size_t)(tok - 1) * HD + c * 8);
+        } else {
+            v.u = make_uint4(0, 0, 0, 0);
+        }
+        *(uint4*)(tile + k_off(r, c)) = v.u;
+    }
+}
+
+template <int CHK>
+__device__ __forceinline__ void stage_vt(const __bf16* __restrict__ src, size_t rowbase, int ld, int coloff, int tok0, int Ntok,
+                                         __bf16* vt, int tid) {
+    for (int idx = tid; idx < CHK; idx += 512) {             // CHK/8 key blocks x 8 dim chunks
+        const int kb = idx >> 3, c = idx & 7;
+        U128 in[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tok = tok0 + kb * 8 + i;
+            if (tok < Ntok) in[i].u = *(const uint4*)(src + (rowbase + tok) * ld + coloff + c * 8);
+            else in[i].u = make_uint4(0, 0, 0, 0);
+        }
+        const int pos = (kb ^ c) * 8;                        // (d>>3)&7 == c for d = c*8 + j
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            U128 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.e[i] = in[i].e[j];
+            *(uint4*)(vt + (c * 8 + j) * VT_LD + pos) = o.u;
+        }
+    }
+}
+
+// P^T accumulator registers [8*c2, 8*c2+8) of both wave halves -> B fragment in the conventional slot order
+// (half h supplies keys 8h..8h+7 of the 16-key step): pack to bf16 pairs, then exchange half 0's keys 8-11 with
+// half 1's keys 4-7 (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second).
+__device__ __forceinline__ bf16x8 pack8_swapped(const f32x16& a, int c2) {
+    union { bf16x2 h; unsigned u; } x0, x1, y0, y1;
+    x0.h[0] = f2bf(a[c2 * 8 + 0]); x0.h[1] = f2bf(a[c2 * 8 + 1]);
+    x1.h[0] = f2bf(a[c2 * 8 + 2]); x1.h[1] = f2bf(a[c2 * 8 + 3]);
+    y0.h[0] = f2bf(a[c2 * 8 + 4]); y0.h[1] = f2bf(a[c2 * 8 + 5]);
+    y1.h[0] = f2bf(a[c2 * 8 + 6]); y1.h[1] = f2bf(a[c2 * 8 + 7]);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(x0.u, y0.u, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(x1.u, y1.u, false, false);
+    union { unsigned u[4]; bf16x8 v; } out;
+    out.u[0] = r0[0]; out.u[1] = r1[0]; out.u[2] = r0[1]; out.u[3] = r1[1];
+    return out.v;
+}
+
 template <int CH>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
-    constexpr int CHK = CH * 32, VLD = CHK + 4;
+    constexpr int CHK = CH * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kl = smem;
     __bf16* Vt = (__bf16*)(smem + CHK * 128);
@@ -128,11 +192,13 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
 
     float m = -INFINITY, l = 0.f;
     f32x16 o[2] = {zero16(), zero16()};
+    // fragment addressing (row = t*32 + l31): LDS row (row>>1), slot ((row&1)*8 | chunk) ^ ((row>>1)&15)
+    const int k_base = (l31 >> 1) << 8, par8 = (l31 & 1) << 3, sw = l31 >> 1;
 
     for (int key0 = 0; key0 < p.Ntok; key0 += CHK) {
         __syncthreads();
-        stage_rows<CHK, true, false>(p.qkv, rowbase, p.ldqkv, C + h * HD, key0, p.Ntok, p.cos_t, p.sin_t, Kl, nullptr, 0, tid);
-        stage_rows<CHK, false, true>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0, p.Ntok, nullptr, nullptr, nullptr, Vt, VLD, tid);
+        stage_k<CHK>(p.qkv, rowbase, p.ldqkv, C + h * HD, key0, p.Ntok, p.cos_t, p.sin_t, Kl, tid);
+        stage_vt<CHK>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0, p.Ntok, Vt, tid);
         __syncthreads();
         if (!wave_active) continue;
 
@@ -141,8 +207,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
         for (int t = 0; t < CH; ++t) {
             s[t] = zero16();
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(Kl, t * 32 + l31, ks, hf), qf[ks], s[t], 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kfrag = *(const bf16x8*)(Kl + t * (16 * 256) + k_base + (((par8 | (ks * 2 + hf)) ^ sw) << 4));
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], s[t], 0, 0, 0);
+            }
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -156,29 +224,35 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx);
         const float alpha = exp2f((m - m_new) * sl2);
+        const float msc = m_new * sl2;
         float rs = 0.f;
 #pragma unroll
         for (int t = 0; t < CH; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float pv = exp2f((s[t][e] - m_new) * sl2);
+                const float pv = exp2f(s[t][e] * sl2 - msc);
                 s[t][e] = pv;
                 rs += pv;
             }
         rs += __shfl_xor(rs, 32, 64);
         l = l * alpha + rs;
         m = m_new;
+        if (key0 > 0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+            for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+        }
 #pragma unroll
         for (int t = 0; t < CH; ++t)
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
-                const bf16x8 pb = pack8(s[t], c2);
-                const int base = t * 32 + c2 * 16;
+                const bf16x8 pb = pack8_swapped(s[t], c2);
+                const int kb = t * 4 + c2 * 2 + hf;              // key block (8 keys) this half supplies
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_t_frag(Vt, VLD, dt * 32 + l31, base, hf), pb, o[dt], 0, 0, 0);
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int d = dt * 32 + l31;
+                    const bf16x8 vfrag = *(const bf16x8*)(Vt + d * VT_LD + ((kb ^ ((d >> 3) & 7)) << 3));
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pb, o[dt], 0, 0, 0);
+                }
             }
     }
 
@@ -419,7 +493,7 @@ extern "C" int cs_attn_fwd(const void* qkv, const float* cos_t, const float* sin
     a.Ntok = Ntok; a.H = H; a.ldqkv = ldqkv; a.ldo = ldo; a.scale = scale;
     dim3 grid((Ntok + 255) / 256, B * H), block(512);
     constexpr int CH = 7;
-    const size_t lds = (size_t)CH * 32 * 128 + (size_t)HD * (CH * 32 + 4) * 2;
+    const size_t lds = (size_t)CH * 32 * 128 + (size_t)HD * VT_LD * 2;
     static bool once = (set_lds(attn_fwd_kernel<CH>, lds), true);
     (void)once;
     hipLaunchKernelGGL((attn_fwd_kernel<CH>), grid, block, lds, stream, a);

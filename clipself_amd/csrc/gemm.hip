@@ -271,20 +271,32 @@ inline double wave_eff(long tiles, int per_cu) {
 }
 
 template <int EPI>
-int launch(const GemmArgs& a, int splits, int use_glds, int force_cfg, hipStream_t stream) {
+int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stream) {
     const long ncols = (EPI == EPI_SWIGLU_BF16) ? 2L * a.group : a.N;
-    auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((ncols + bn - 1) / bn) * splits; };
+    const int ktiles = a.K / BK;
+    auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((ncols + bn - 1) / bn); };
+    // split-K (atomic epilogue only): splits <= 0 asks for ~2 full rounds of workgroups with >= 4 K tiles per slice
+    auto auto_splits = [&](long t, int per_cu) {
+        if (splits > 0) return splits;
+        long s = (2L * 256 * per_cu + t - 1) / t;
+        s = s < 1 ? 1 : s;
+        if (s > ktiles / 4) s = ktiles / 4 > 0 ? ktiles / 4 : 1;
+        return (int)s;
+    };
+    const int sp[4] = {0, auto_splits(tiles(128, 128), 2), auto_splits(tiles(256, 128), 1), auto_splits(tiles(256, 256), 1)};
     int cfg = force_cfg;
     if (cfg == 0) {
-        const double s_big = (a.M >= 256 && ncols >= 256) ? 1.00 * wave_eff(tiles(256, 256), 1) : 0.0;
-        const double s_mid = (a.M >= 256 && ncols >= 128) ? 0.85 * wave_eff(tiles(256, 128), 1) : 0.0;
-        const double s_small = 0.62 * wave_eff(tiles(128, 128), 2);
+        const double s_big = (a.M >= 256 && ncols >= 256) ? 1.00 * wave_eff(tiles(256, 256) * sp[3], 1) : 0.0;
+        const double s_mid = (a.M >= 256 && ncols >= 128) ? 0.85 * wave_eff(tiles(256, 128) * sp[2], 1) : 0.0;
+        const double s_small = 0.62 * wave_eff(tiles(128, 128) * sp[1], 2);
         cfg = (s_big >= s_mid && s_big >= s_small) ? 3 : (s_mid >= s_small ? 2 : 1);
     }
+    const int ns = sp[cfg];
+    a.ktiles_per_split = (ktiles + ns - 1) / ns;
     switch (cfg) {
-        case 3: return launch_cfg<EPI, 256, 256, 2, 4>(a, splits, use_glds, stream);
-        case 2: return launch_cfg<EPI, 256, 128, 4, 2>(a, splits, use_glds, stream);
-        default: return launch_cfg<EPI, 128, 128, 2, 2>(a, splits, use_glds, stream);
+        case 3: return launch_cfg<EPI, 256, 256, 2, 4>(a, ns, use_glds, stream);
+        case 2: return launch_cfg<EPI, 256, 128, 4, 2>(a, ns, use_glds, stream);
+        default: return launch_cfg<EPI, 128, 128, 2, 2>(a, ns, use_glds, stream);
     }
 }
 
@@ -303,7 +315,7 @@ extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bi
     CS_CHECK_ARG(K % BK == 0, "cs_gemm_nt: K=%d must be a multiple of %d", K, BK);
     CS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0, "cs_gemm_nt: lda/ldb must be multiples of 8 (16-byte rows)");
     CS_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "cs_gemm_nt: operands must be 16-byte aligned");
-    CS_CHECK_ARG(splits >= 1 && (splits == 1 || epi == EPI_ATOMIC_F32), "cs_gemm_nt: split-K needs the atomic epilogue");
+    CS_CHECK_ARG(splits == 1 || epi == EPI_ATOMIC_F32, "cs_gemm_nt: split-K (splits != 1; <= 0 = automatic) needs the atomic epilogue");
     CS_CHECK_ARG((epi == EPI_SWIGLU_BF16 ? group : N) % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C % 16) == 0,
                  "cs_gemm_nt: N, ldc must be multiples of 4 and C 16-byte aligned (vector epilogue)");
     CS_CHECK_ARG(bias == nullptr || ((uintptr_t)bias % 16) == 0, "cs_gemm_nt: bias must be 16-byte aligned");
@@ -314,8 +326,7 @@ extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bi
     if (epi == EPI_SWIGLU_BF16) CS_CHECK_ARG(group > 0 && N == 2 * group, "cs_gemm_nt: swiglu epilogue needs N == 2*group");
     if (epi == EPI_PATCH_F32 || epi == EPI_RESID_F32) CS_CHECK_ARG(extra != nullptr && ((uintptr_t)extra % 16) == 0, "cs_gemm_nt: epilogue %d needs 16-byte aligned extra", epi);
     if (epi == EPI_PATCH_F32) CS_CHECK_ARG(group > 0, "cs_gemm_nt: patch epilogue needs group");
-    const int ktiles = K / BK;
-    a.ktiles_per_split = (ktiles + splits - 1) / splits;
+    a.ktiles_per_split = K / BK;
     const int glds = (flags & 1) ? 0 : 1;
     const int force = (flags >> 4) & 3;
     switch (epi) {

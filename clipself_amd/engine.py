@@ -364,9 +364,7 @@ class EvaEngine:
         Mp = Xt.shape[1]
         dYt = ops.empty((N, Mp), BF16)
         ops.transpose_bf16(dY, dYt)
-        tiles = ((N + 127) // 128) * ((Xt.shape[0] + 127) // 128)
-        splits = max(1, min(Mp // 64, round(768 / tiles)))
-        ops.gemm_nt(dYt, Xt, dW, epi=EPI_ATOMIC_F32, splits=splits)
+        ops.gemm_nt(dYt, Xt, dW, epi=EPI_ATOMIC_F32, splits=0)          # 0 = library picks the split-K factor
 
     def _transposed(self, X):
         M, K = X.shape

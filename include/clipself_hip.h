@@ -28,7 +28,7 @@ const char* cs_last_error(void);
  * C[M,N] (+epilogue) = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulation.  K % 64 == 0, lda/ldb % 8 == 0.
  * epi: 0 bf16 = acc+bias | 1 f32 = acc+bias | 2 f32 = extra(residual)+acc+bias (in-place allowed) |
  *      3 fused SwiGLU: B=[W1;W2] [2*group,K], bias [2*group], out bf16 [M,group] = silu(x1)*x2 |
- *      4 f32 atomic accumulate (split-K allowed, `splits` >= 1) |
+ *      4 f32 atomic accumulate (split-K allowed: `splits` >= 1, or <= 0 = chosen by the library) |
  *      5 patch embed: out row = row + row/group + 1, value += extra[(row%group+1)*ldc + col]   (cls/pos layout :540-543)
  * flags bit0: use register staging instead of the global_load_lds DMA path. */
 int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
