@@ -109,26 +109,31 @@ constexpr int VT_LD = 264;            // 33 blocks of 8 keys: odd block stride -
 
 __device__ __forceinline__ int k_off(int r, int c) { return ((r >> 1) << 8) + (((((r & 1) << 3) | c) ^ ((r >> 1) & 15)) << 4); }
 
-template <int CHK>
+template <int CHK, int NT>
 __device__ __forceinline__ void stage_k(const __bf16* __restrict__ src, size_t rowbase, int ld, int coloff, int tok0, int Ntok,
                                         const float* cos_t, const float* sin_t, char* tile, int tid) {
-    for (int idx = tid; idx < CHK * 8; idx += 512) {
-        const int r = idx >> 3, c = idx & 7, tok = tok0 + r;
-        U128 v;
-        if (tok < Ntok) {
-            v.u = *(const uint4*)(src + (rowbase + tok) * ld + coloff + c * 8);
-            if (tok > 0) rope8(v, cos_t + (size_t)(tok - 1) * HD + c * 8, sin_t + (size_t)(tok - 1) * HD + c * 8);
-        } else {
-            v.u = make_uint4(0, 0, 0, 0);
+    constexpr int ITEMS = (CHK * 8 + NT - 1) / NT;
+    U128 v[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {                      // all loads in flight before the first use
+        const int idx = tid + it * NT, tok = tok0 + (idx >> 3);
+        if (idx < CHK * 8 && tok < Ntok) v[it].u = *(const uint4*)(src + (rowbase + tok) * ld + coloff + (idx & 7) * 8);
+        else v[it].u = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int idx = tid + it * NT, r = idx >> 3, c = idx & 7, tok = tok0 + r;
+        if (idx < CHK * 8) {
+            if (tok > 0 && tok < Ntok) rope8(v[it], cos_t + (size_t)(tok - 1) * HD + c * 8, sin_t + (size_t)(tok - 1) * HD + c * 8);
+            *(uint4*)(tile + k_off(r, c)) = v[it].u;
         }
-        *(uint4*)(tile + k_off(r, c)) = v.u;
     }
 }
 
-template <int CHK>
+template <int CHK, int NT>
 __device__ __forceinline__ void stage_vt(const __bf16* __restrict__ src, size_t rowbase, int ld, int coloff, int tok0, int Ntok,
                                          __bf16* vt, int tid) {
-    for (int idx = tid; idx < CHK; idx += 512) {             // CHK/8 key blocks x 8 dim chunks
+    for (int idx = tid; idx < CHK; idx += NT) {              // CHK/8 key blocks x 8 dim chunks
         const int kb = idx >> 3, c = idx & 7;
         U128 in[8];
 #pragma unroll
@@ -164,23 +169,7 @@ __device__ __forceinline__ bf16x8 pack8_swapped(const f32x16& a, int c2) {
     return out.v;
 }
 
-template <int CH>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
-    constexpr int CHK = CH * 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Kl = smem;
-    __bf16* Vt = (__bf16*)(smem + CHK * 128);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-    const int C = p.H * HD;
-    const size_t rowbase = (size_t)b * p.Ntok;
-    const int q = blockIdx.x * 256 + wave * 32 + l31;
-    const int qc = min(q, p.Ntok - 1);
-    const bool wave_active = (blockIdx.x * 256 + wave * 32) < p.Ntok;
-    const float sl2 = p.scale * LOG2E;
-
-    bf16x8 qf[4];
+__device__ __forceinline__ void load_q_frags(const AttnArgs& p, size_t rowbase, int qc, int h, int hf, bf16x8 (&qf)[4]) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const int d0 = ks * 16 + hf * 8;
@@ -189,86 +178,132 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnArgs p) {
         if (qc > 0) rope8(t, p.cos_t + (size_t)(qc - 1) * HD + d0, p.sin_t + (size_t)(qc - 1) * HD + d0);
         qf[ks] = t.h;
     }
+}
 
-    float m = -INFINITY, l = 0.f;
-    f32x16 o[2] = {zero16(), zero16()};
+// one key chunk against one 32-query tile: S^T = K Q^T, online-softmax update of (m, l), O^T += V^T P^T
+template <int CH>
+__device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, const bf16x8 (&qf)[4], int key0, int Ntok, float sl2,
+                                             int lane, bool first, float& m, float& l, f32x16 (&o)[2]) {
+    const int hf = lane >> 5, l31 = lane & 31;
     // fragment addressing (row = t*32 + l31): LDS row (row>>1), slot ((row&1)*8 | chunk) ^ ((row>>1)&15)
     const int k_base = (l31 >> 1) << 8, par8 = (l31 & 1) << 3, sw = l31 >> 1;
-
-    for (int key0 = 0; key0 < p.Ntok; key0 += CHK) {
-        __syncthreads();
-        stage_k<CHK>(p.qkv, rowbase, p.ldqkv, C + h * HD, key0, p.Ntok, p.cos_t, p.sin_t, Kl, tid);
-        stage_vt<CHK>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0, p.Ntok, Vt, tid);
-        __syncthreads();
-        if (!wave_active) continue;
-
-        f32x16 s[CH];
+    f32x16 s[CH];
 #pragma unroll
-        for (int t = 0; t < CH; ++t) {
-            s[t] = zero16();
+    for (int t = 0; t < CH; ++t) {
+        s[t] = zero16();
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kfrag = *(const bf16x8*)(Kl + t * (16 * 256) + k_base + (((par8 | (ks * 2 + hf)) ^ sw) << 4));
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], s[t], 0, 0, 0);
-            }
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kfrag = *(const bf16x8*)(Kl + t * (16 * 256) + k_base + (((par8 | (ks * 2 + hf)) ^ sw) << 4));
+            s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], s[t], 0, 0, 0);
         }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < CH; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = key0 + t * 32 + mfma32_row(e, lane);
-                if (key >= p.Ntok) s[t][e] = -INFINITY;
-                mx = fmaxf(mx, s[t][e]);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m, mx);
-        const float alpha = exp2f((m - m_new) * sl2);
-        const float msc = m_new * sl2;
-        float rs = 0.f;
-#pragma unroll
-        for (int t = 0; t < CH; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pv = exp2f(s[t][e] * sl2 - msc);
-                s[t][e] = pv;
-                rs += pv;
-            }
-        rs += __shfl_xor(rs, 32, 64);
-        l = l * alpha + rs;
-        m = m_new;
-        if (key0 > 0) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
-        }
-#pragma unroll
-        for (int t = 0; t < CH; ++t)
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                const bf16x8 pb = pack8_swapped(s[t], c2);
-                const int kb = t * 4 + c2 * 2 + hf;              // key block (8 keys) this half supplies
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int d = dt * 32 + l31;
-                    const bf16x8 vfrag = *(const bf16x8*)(Vt + d * VT_LD + ((kb ^ ((d >> 3) & 7)) << 3));
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pb, o[dt], 0, 0, 0);
-                }
-            }
     }
-
-    if (wave_active && q < p.Ntok) {
-        const float inv = 1.f / l;
-        __bf16* orow = p.out + (rowbase + q) * p.ldo + h * HD;
+    float mx = -INFINITY;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+    for (int t = 0; t < CH; ++t)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                U64 t;
+        for (int e = 0; e < 16; ++e) {
+            const int key = key0 + t * 32 + mfma32_row(e, lane);
+            if (key >= Ntok) s[t][e] = -INFINITY;
+            mx = fmaxf(mx, s[t][e]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = exp2f((m - m_new) * sl2);
+    const float msc = m_new * sl2;
+    float rs = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) t.e[i] = f2bf(o[dt][g4 * 4 + i] * inv);
-                *(uint2*)(orow + dt * 32 + g4 * 8 + hf * 4) = t.u;
+    for (int t = 0; t < CH; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pv = exp2f(s[t][e] * sl2 - msc);
+            s[t][e] = pv;
+            rs += pv;
+        }
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs;
+    m = m_new;
+    if (!first) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+    }
+#pragma unroll
+    for (int t = 0; t < CH; ++t)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const bf16x8 pb = pack8_swapped(s[t], c2);
+            const int kb = t * 4 + c2 * 2 + hf;              // key block (8 keys) this half supplies
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int d = dt * 32 + l31;
+                const bf16x8 vfrag = *(const bf16x8*)(Vt + d * VT_LD + ((kb ^ ((d >> 3) & 7)) << 3));
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pb, o[dt], 0, 0, 0);
             }
-        if (p.lse_out && hf == 0) p.lse_out[(size_t)bh * p.Ntok + q] = m * p.scale + logf(l);
+        }
+}
+
+__device__ __forceinline__ void store_o(const AttnArgs& p, size_t rowbase, int q, int h, int bh, int hf, float m, float l, const f32x16 (&o)[2]) {
+    const float inv = 1.f / l;
+    __bf16* orow = p.out + (rowbase + q) * p.ldo + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            U64 t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t.e[i] = f2bf(o[dt][g4 * 4 + i] * inv);
+            *(uint2*)(orow + dt * 32 + g4 * 8 + hf * 4) = t.u;
+        }
+    if (p.lse_out && hf == 0) p.lse_out[(size_t)bh * p.Ntok + q] = m * p.scale + logf(l);
+}
+
+// NW waves per workgroup, QTW 32-query tiles per wave (tile = wave + j*NW).  QTW > 1 requires the whole sequence in one key
+// chunk (Ntok <= CH*32: no state is carried between chunks); it lets 4-wave workgroups stage K/V once for up to 256
+// queries while two workgroups share a CU, so one workgroup's K/V staging overlaps the other's MFMA/softmax phase.
+template <int CH, int NW, int QTW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int CHK = CH * 32, NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kl = smem;
+    __bf16* Vt = (__bf16*)(smem + CHK * 128);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int C = p.H * HD;
+    const size_t rowbase = (size_t)b * p.Ntok;
+    const float sl2 = p.scale * LOG2E;
+    const int q_wg = blockIdx.x * (NW * QTW * 32);
+
+    if (QTW == 1) {
+        const int q0 = q_wg + wave * 32, q = q0 + l31, qc = min(q, p.Ntok - 1);
+        const bool active = q0 < p.Ntok;
+        bf16x8 qf[4];
+        load_q_frags(p, rowbase, qc, h, hf, qf);
+        float m = -INFINITY, l = 0.f;
+        f32x16 o[2] = {zero16(), zero16()};
+        for (int key0 = 0; key0 < p.Ntok; key0 += CHK) {
+            __syncthreads();
+            stage_k<CHK, NT>(p.qkv, rowbase, p.ldqkv, C + h * HD, key0, p.Ntok, p.cos_t, p.sin_t, Kl, tid);
+            stage_vt<CHK, NT>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0, p.Ntok, Vt, tid);
+            __syncthreads();
+            if (active) attend_chunk<CH>(Kl, Vt, qf, key0, p.Ntok, sl2, lane, key0 == 0, m, l, o);
+        }
+        if (active && q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
+    } else {
+        stage_k<CHK, NT>(p.qkv, rowbase, p.ldqkv, C + h * HD, 0, p.Ntok, p.cos_t, p.sin_t, Kl, tid);
+        stage_vt<CHK, NT>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, 0, p.Ntok, Vt, tid);
+        __syncthreads();
+#pragma nounroll
+        for (int j = 0; j < QTW; ++j) {
+            const int q0 = q_wg + (wave + j * NW) * 32;
+            if (q0 >= p.Ntok) break;
+            const int q = q0 + l31, qc = min(q, p.Ntok - 1);
+            bf16x8 qf[4];
+            load_q_frags(p, rowbase, qc, h, hf, qf);
+            float m = -INFINITY, l = 0.f;
+            f32x16 o[2] = {zero16(), zero16()};
+            attend_chunk<CH>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o);
+            if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
+        }
     }
 }
 
@@ -491,12 +526,18 @@ extern "C" int cs_attn_fwd(const void* qkv, const float* cos_t, const float* sin
     AttnArgs a{};
     a.qkv = (const __bf16*)qkv; a.cos_t = cos_t; a.sin_t = sin_t; a.out = (__bf16*)out; a.lse_out = lse;
     a.Ntok = Ntok; a.H = H; a.ldqkv = ldqkv; a.ldo = ldo; a.scale = scale;
-    dim3 grid((Ntok + 255) / 256, B * H), block(512);
     constexpr int CH = 7;
     const size_t lds = (size_t)CH * 32 * 128 + (size_t)HD * VT_LD * 2;
-    static bool once = (set_lds(attn_fwd_kernel<CH>, lds), true);
-    (void)once;
-    hipLaunchKernelGGL((attn_fwd_kernel<CH>), grid, block, lds, stream, a);
+    if (Ntok <= CH * 32) {
+        // whole sequence in one key chunk: 4-wave workgroups, 2 query tiles per wave, 2 workgroups per CU
+        static bool once = (set_lds(attn_fwd_kernel<CH, 4, 2>, lds), true);
+        (void)once;
+        hipLaunchKernelGGL((attn_fwd_kernel<CH, 4, 2>), dim3((Ntok + 255) / 256, B * H), dim3(256), lds, stream, a);
+    } else {
+        static bool once = (set_lds(attn_fwd_kernel<CH, 8, 1>, lds), true);
+        (void)once;
+        hipLaunchKernelGGL((attn_fwd_kernel<CH, 8, 1>), dim3((Ntok + 255) / 256, B * H), dim3(512), lds, stream, a);
+    }
     CS_LAUNCH_CHECK();
     return 0;
 }

@@ -275,21 +275,32 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
     const long ncols = (EPI == EPI_SWIGLU_BF16) ? 2L * a.group : a.N;
     const int ktiles = a.K / BK;
     auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((ncols + bn - 1) / bn); };
-    // split-K (atomic epilogue only): splits <= 0 asks for ~2 full rounds of workgroups with >= 4 K tiles per slice
-    auto auto_splits = [&](long t, int per_cu) {
-        if (splits > 0) return splits;
-        long s = (2L * 256 * per_cu + t - 1) / t;
-        s = s < 1 ? 1 : s;
-        if (s > ktiles / 4) s = ktiles / 4 > 0 ? ktiles / 4 : 1;
-        return (int)s;
+    // split-K (atomic epilogue only, splits <= 0 = automatic): per tile shape pick the slice count minimising a two-term
+    // cost -- MFMA time (rounds of resident workgroups x K tiles per slice + a fixed pro/epilogue) + the fp32 atomic
+    // traffic, which grows with the number of slices (every slice adds the whole tile to C).
+    const double out_bytes = 4.0 * (double)a.M * (double)ncols;
+    auto best_split = [&](int bm, int bn, int per_cu, double us_per_ktile, double& cost) {
+        const long t = tiles(bm, bn);
+        const long slots = 256L * per_cu;
+        int best = 1;
+        cost = 1e30;
+        const int lo = splits > 0 ? splits : 1, hi = splits > 0 ? splits : (ktiles < 64 ? ktiles : 64);
+        for (int s = lo; s <= hi; ++s) {
+            const long rounds = (t * s + slots - 1) / slots;
+            const int kper = (ktiles + s - 1) / s;
+            const double c = rounds * (kper * us_per_ktile + 5.0) + (EPI == EPI_ATOMIC_F32 ? s * out_bytes / 1.5e6 : 0.0);
+            if (c < cost) { cost = c; best = s; }
+        }
+        return best;
     };
-    const int sp[4] = {0, auto_splits(tiles(128, 128), 2), auto_splits(tiles(256, 128), 1), auto_splits(tiles(256, 256), 1)};
+    double c1, c2, c3;
+    // measured microseconds per K tile of one resident workgroup set (r01 profiles): 256x256 2.2, 256x128 1.4, 2 x 128x128 1.9
+    const int sp[4] = {0, best_split(128, 128, 2, 1.9, c1), best_split(256, 128, 1, 1.4, c2), best_split(256, 256, 1, 2.2, c3)};
     int cfg = force_cfg;
     if (cfg == 0) {
-        const double s_big = (a.M >= 256 && ncols >= 256) ? 1.00 * wave_eff(tiles(256, 256) * sp[3], 1) : 0.0;
-        const double s_mid = (a.M >= 256 && ncols >= 128) ? 0.85 * wave_eff(tiles(256, 128) * sp[2], 1) : 0.0;
-        const double s_small = 0.62 * wave_eff(tiles(128, 128) * sp[1], 2);
-        cfg = (s_big >= s_mid && s_big >= s_small) ? 3 : (s_mid >= s_small ? 2 : 1);
+        if (a.M < 256 || ncols < 256) c3 = 1e30;
+        if (a.M < 256 || ncols < 128) c2 = 1e30;
+        cfg = (c3 <= c2 && c3 <= c1) ? 3 : (c2 <= c1 ? 2 : 1);
     }
     const int ns = sp[cfg];
     a.ktiles_per_split = (ktiles + ns - 1) / ns;
