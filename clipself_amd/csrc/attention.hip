@@ -199,13 +199,15 @@ __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, c
     }
     float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < CH; ++t)
+    for (int t = 0; t < CH; ++t) {
+        if (key0 + t * 32 + 32 > Ntok) {                     // wave-uniform: only the ragged last key tile needs masking
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = key0 + t * 32 + mfma32_row(e, lane);
-            if (key >= Ntok) s[t][e] = -INFINITY;
-            mx = fmaxf(mx, s[t][e]);
+            for (int e = 0; e < 16; ++e)
+                if (key0 + t * 32 + mfma32_row(e, lane) >= Ntok) s[t][e] = -INFINITY;
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[t][e]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m, mx);
     const float alpha = exp2f((m - m_new) * sl2);
@@ -215,7 +217,7 @@ __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, c
     for (int t = 0; t < CH; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float pv = exp2f(s[t][e] * sl2 - msc);
+            const float pv = __builtin_amdgcn_exp2f(s[t][e] * sl2 - msc);     // raw v_exp_f32: argument <= 0, result in [0,1]
             s[t][e] = pv;
             rs += pv;
         }

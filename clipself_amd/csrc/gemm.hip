@@ -76,7 +76,7 @@ __device__ __forceinline__ void stage_tile(const __bf16* __restrict__ src, int l
 constexpr int EP_LD = 68;                       // fp32 row stride of the epilogue slab (64 + 4 pad)
 constexpr int EP_BYTES = 32 * EP_LD * 4;        // 32 rows per wave slab
 
-template <int EPI, int BM, int BN, int WM, int WN, bool GLDS>
+template <int EPI, int BM, int BN, int WM, int WN, bool GLDS, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;           // wave tile
@@ -141,16 +141,35 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
     const int a_base = ((wm * TM + l31) >> 1) << 8;
     const int b_base = ((wn * TN + l31) >> 1) << 8;
     const int par8 = (l31 & 1) << 3, sw = l31 >> 1;
+    if (NS == 3 && kt_begin + 1 < kt_end) {               // 3-stage ring: two tiles in flight before the first MFMA
+        stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt_begin + 1) * BK, smem + STAGE, wave * A_INSTR, lane, arow, achk);
+        stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt_begin + 1) * BK, smem + STAGE + A_BYTES, wave * B_INSTR, lane, brow, bchk);
+    }
+    int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        __syncthreads();            // tile kt landed (the barrier drains the LDS-DMA queue); buffer cur^1 is free
-        if (kt + 1 < kt_end) {
-            char* nxt = smem + (cur ^ 1) * STAGE;
-            stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 1) * BK, nxt, wave * A_INSTR, lane, arow, achk);
-            stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 1) * BK, nxt + A_BYTES, wave * B_INSTR, lane, brow, bchk);
+        if (NS == 3) {
+            // Counted wait: tile kt (older) must have landed, tile kt+1 (A_INSTR+B_INSTR newer DMA ops of this wave) may stay
+            // in flight across the barrier.  Raw s_barrier: __syncthreads() would drain the DMA queue (vmcnt(0)).
+            if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();     // everyone's tile kt landed; everyone finished reading buffer (cur+2)%3 = tile kt-1
+            if (kt + 2 < kt_end) {
+                char* nxt = smem + ((cur + 2) % 3) * STAGE;
+                stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 2) * BK, nxt, wave * A_INSTR, lane, arow, achk);
+                stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 2) * BK, nxt + A_BYTES, wave * B_INSTR, lane, brow, bchk);
+            }
+        } else {
+            __syncthreads();        // tile kt landed (the barrier drains the LDS-DMA queue); buffer cur^1 is free
+            if (kt + 1 < kt_end) {
+                char* nxt = smem + (cur ^ 1) * STAGE;
+                stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 1) * BK, nxt, wave * A_INSTR, lane, arow, achk);
+                stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 1) * BK, nxt + A_BYTES, wave * B_INSTR, lane, brow, bchk);
+            }
         }
         const char* la = smem + cur * STAGE + a_base;
         const char* lb = smem + cur * STAGE + A_BYTES + b_base;
+        const int cur_next = (NS == 3) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int off = ((par8 | (ks * 2 + hf)) ^ sw) << 4;
@@ -164,6 +183,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        cur = cur_next;
     }
 
     // ---- epilogue through a wave-private LDS slab [32][EP_LD] fp32 -------------------------------------------
@@ -240,24 +260,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
-template <int EPI, int BM, int BN, int WM, int WN>
+template <int EPI, int BM, int BN, int WM, int WN, int NS>
 int launch_cfg(GemmArgs a, int splits, int use_glds, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + BN / 2 - 1) / (BN / 2) : (a.N + BN - 1) / BN;
     constexpr int NW = WM * WN;
-    constexpr size_t stage = (size_t)(BM + BN) * BK * 2 * 2;
+    constexpr size_t stage = (size_t)(BM + BN) * BK * 2 * NS;
     constexpr size_t lds = stage > (size_t)NW * EP_BYTES ? stage : (size_t)NW * EP_BYTES;
     dim3 grid(a.tiles_m * a.tiles_n, splits), block(NW * 64);
     if (use_glds) {
-        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, true>,
+        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, true, NS>,
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, true>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, true, NS>), grid, block, lds, stream, a);
     } else {
-        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, false>,
+        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, false, NS>,
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, false>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, false, NS>), grid, block, lds, stream, a);
     }
     CS_LAUNCH_CHECK();
     return 0;
@@ -302,12 +322,13 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
         if (a.M < 256 || ncols < 128) c2 = 1e30;
         cfg = (c3 <= c2 && c3 <= c1) ? 3 : (c2 <= c1 ? 2 : 1);
     }
-    const int ns = sp[cfg];
+    const int ns = sp[cfg > 3 ? 2 : cfg];
     a.ktiles_per_split = (ktiles + ns - 1) / ns;
     switch (cfg) {
-        case 3: return launch_cfg<EPI, 256, 256, 2, 4>(a, ns, use_glds, stream);
-        case 2: return launch_cfg<EPI, 256, 128, 4, 2>(a, ns, use_glds, stream);
-        default: return launch_cfg<EPI, 128, 128, 2, 2>(a, ns, use_glds, stream);
+        case 4: return launch_cfg<EPI, 256, 128, 4, 2, 3>(a, sp[2], use_glds, stream);   // 3-stage ring (experimental A/B)
+        case 3: return launch_cfg<EPI, 256, 256, 2, 4, 2>(a, ns, use_glds, stream);
+        case 2: return launch_cfg<EPI, 256, 128, 4, 2, 2>(a, ns, use_glds, stream);
+        default: return launch_cfg<EPI, 128, 128, 2, 2, 2>(a, ns, use_glds, stream);
     }
 }
 
@@ -319,7 +340,7 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 //      4 f32 atomic accumulate (split-K, C pre-zeroed or accumulating) |
 //      5 patch-embed: out row = row + row/group + 1, += extra[(row%group+1)*ldc + col]
 // flags bit0: 0 = global_load_lds staging, 1 = register staging (debug/fallback A-B switch)
-//       bits 4-5: force tile shape (1 = 128x128, 2 = 256x128, 3 = 256x256; 0 = heuristic)
+//       bits 4-6: force tile shape (1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x128 with a 3-stage LDS ring; 0 = heuristic)
 extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
                           int lda, int ldb, int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
     CS_CHECK_ARG(M > 0 && N > 0 && K > 0, "cs_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
@@ -339,7 +360,7 @@ extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bi
     if (epi == EPI_PATCH_F32) CS_CHECK_ARG(group > 0, "cs_gemm_nt: patch epilogue needs group");
     a.ktiles_per_split = K / BK;
     const int glds = (flags & 1) ? 0 : 1;
-    const int force = (flags >> 4) & 3;
+    const int force = (flags >> 4) & 7;
     switch (epi) {
         case EPI_BF16: return launch<EPI_BF16>(a, splits, glds, force, stream);
         case EPI_F32: return launch<EPI_F32>(a, splits, glds, force, stream);
