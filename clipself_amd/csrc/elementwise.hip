@@ -62,9 +62,32 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const __bf16* __res
                                                              long ld_out, int R, int Cc) {
     __shared__ uint16_t tile[64][66];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;    // ty 0..3
     const uint16_t* src = (const uint16_t*)in;
     uint16_t* dst = (uint16_t*)out;
+    const bool vec = ((ld_in | ld_out) & 7) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && c0 + 64 <= Cc && r0 + 64 <= ld_out;
+    if (vec) {
+        // 16-byte global accesses both ways: 8 row-vectors in, 8 column-vectors out per thread pair of passes
+#pragma unroll
+        for (int pss = 0; pss < 2; ++pss) {
+            const int v = threadIdx.x + pss * 256, r = v >> 3, cv = (v & 7) * 8;      // 64 rows x 8 vectors
+            U128 t;
+            if (r0 + r < R) t.u = *(const uint4*)(src + (size_t)(r0 + r) * ld_in + c0 + cv);
+            else t.u = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[r][cv + e] = ((const uint16_t*)&t)[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pss = 0; pss < 2; ++pss) {
+            const int v = threadIdx.x + pss * 256, c = v >> 3, rv = (v & 7) * 8;      // 64 out rows x 8 vectors
+            U128 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ((uint16_t*)&o)[e] = tile[rv + e][c];
+            *(uint4*)(dst + (size_t)(c0 + c) * ld_out + r0 + rv) = o.u;
+        }
+        return;
+    }
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;    // ty 0..3
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int r = r0 + ty * 16 + i, c = c0 + tx;
@@ -82,17 +105,32 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const __bf16* __res
 // column pair, grid.y splits rows; partial sums combined with hardware float atomics (out pre-zeroed by the step).
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ x, long ldx, float* __restrict__ out, int M, int N,
                                                           int rows_per_block) {
-    const int n = (blockIdx.x * 256 + threadIdx.x) * 2;
-    if (n >= N) return;
+    // 64 column-vectors (8 bf16 = 16 bytes each) x 4 row phases per workgroup; LDS combine, then one atomic per column
+    __shared__ float red[4][512];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + tx) * 8;
     const int m_begin = blockIdx.y * rows_per_block, m_end = min(M, m_begin + rows_per_block);
-    float s0 = 0.f, s1 = 0.f;
-    for (int m = m_begin; m < m_end; ++m) {
-        const uint32_t v = *(const uint32_t*)(x + (size_t)m * ldx + n);
-        s0 += __uint_as_float(v << 16);
-        s1 += __uint_as_float(v & 0xffff0000u);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool vec = (ldx & 7) == 0 && ((uintptr_t)x & 15) == 0;
+    if (n + 8 <= N && vec) {
+        for (int m = m_begin + ty; m < m_end; m += 4) {
+            U128 v;
+            v.u = *(const uint4*)(x + (size_t)m * ldx + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += bf2f(v.e[e]);
+        }
+    } else {
+        for (int m = m_begin + ty; m < m_end; m += 4)
+            for (int e = 0; e < 8; ++e)
+                if (n + e < N) s[e] += bf2f(x[(size_t)m * ldx + n + e]);
     }
-    unsafeAtomicAdd(out + n, s0);
-    if (n + 1 < N) unsafeAtomicAdd(out + n + 1, s1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = s[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int col = blockIdx.x * 512 + c;
+        if (col < N) unsafeAtomicAdd(out + col, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    }
 }
 
 // im2row for the patch-embed conv as a GEMM (reference: nn.Conv2d(3,C,p,stride=p), eva_vit_model.py:348,355).
@@ -161,9 +199,9 @@ extern "C" int cs_transpose_bf16(const void* in, long ld_in, void* out, long ld_
     return 0;
 }
 extern "C" int cs_colsum_bf16(const void* x, long ldx, float* out, int M, int N, hipStream_t stream) {
-    CS_CHECK_ARG(M > 0 && N > 0 && N % 2 == 0 && ldx % 2 == 0, "cs_colsum_bf16: N and ldx must be even");
-    const int rows_per_block = 128;
-    dim3 grid((N / 2 + 255) / 256, (M + rows_per_block - 1) / rows_per_block);
+    CS_CHECK_ARG(M > 0 && N > 0, "cs_colsum_bf16: empty input");
+    const int rows_per_block = 256;
+    dim3 grid((N + 511) / 512, (M + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, stream, (const __bf16*)x, ldx, out, M, N, rows_per_block);
     CS_LAUNCH_CHECK();
     return 0;

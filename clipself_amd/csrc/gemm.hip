@@ -196,7 +196,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) slab[mfma32_row(e, lane) * EP_LD + j * 32 + l31] = acc[i][j][e];
-        __syncthreads();
+        // The slab is wave-private and a wave's DS operations execute in order, so no workgroup barrier is needed
+        // (a __syncthreads() here would also wait for every outstanding global store: one HBM round trip per slab).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int row_base = m0 + wm * TM + i * 32;
         if (EPI == EPI_SWIGLU_BF16) {
             // slab columns [0,32) = x1, [32,64) = x2 of hidden units hcol0 .. hcol0+31; 8 lanes per row, 4 hidden units per lane
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
                 }
             }
         }
-        if (i + 1 < FM) __syncthreads();                // slab is rewritten by the next 32-row block
+        if (i + 1 < FM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next block rewrites it
     }
 }
 
