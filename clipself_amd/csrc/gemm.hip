@@ -43,6 +43,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int ktiles_per_split;
     int group;            // EPI_PATCH: tokens-1 per image ; EPI_SWIGLU: hidden width Hd
+    int gm;               // M panels per raster group
 };
 
 // LDS byte offset of (tile row r, 16-byte chunk c) inside an operand tile of 128-byte rows
@@ -96,7 +97,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tn = swz % p.tiles_n, tm = swz / p.tiles_n;
+    // grouped raster inside the XCD's range: `gm` M panels share each B tile before the next N tile is touched, so
+    // the 32 workgroups in flight on an XCD work on ~gm A panels + 32/gm B tiles (fits the 4 MiB L2) instead of
+    // 2 A panels + 16 B tiles.
+    int tn, tm;
+    {
+        const int per_group = p.gm * p.tiles_n;
+        const int grp = swz / per_group, rem = swz - grp * per_group;
+        const int rows = min(p.gm, p.tiles_m - grp * p.gm);
+        tn = rem / rows;
+        tm = grp * p.gm + (rem - tn * rows);
+    }
     const int m0 = tm * BM;
     const int n0 = tn * BN;
 
@@ -357,6 +368,7 @@ extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bi
     a.A = (const __bf16*)A; a.B = (const __bf16*)B; a.C = C; a.bias = bias; a.extra = extra;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.group = group;
     a.tiles_m = a.tiles_n = 0;
+    a.gm = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 8;      // flags bits 8-11: raster group height override (A/B knob)
     if (epi == EPI_SWIGLU_BF16) CS_CHECK_ARG(group > 0 && N == 2 * group, "cs_gemm_nt: swiglu epilogue needs N == 2*group");
     if (epi == EPI_PATCH_F32 || epi == EPI_RESID_F32) CS_CHECK_ARG(extra != nullptr && ((uintptr_t)extra % 16) == 0, "cs_gemm_nt: epilogue %d needs 16-byte aligned extra", epi);
     if (epi == EPI_PATCH_F32) CS_CHECK_ARG(group > 0, "cs_gemm_nt: patch epilogue needs group");

@@ -30,8 +30,8 @@ def main():
         else:
             C, extra, group = torch.empty(M, N // 2, dtype=BF, device="cuda"), None, N // 2
         line = f"{name} M={M}: "
-        for cfg in (1, 2, 3, 4):
-            flags = cfg << 4
+        for cfg, gm in ((3, 1), (3, 2), (3, 4), (3, 8), (3, 15), (4, 4), (2, 4)):
+            flags = (cfg << 4) | (gm << 8)
             for _ in range(3):
                 ops.gemm_nt(A, B, C, bias, extra, epi=epi, group=group, flags=flags)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,7 +41,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / 20
-            line += f" cfg{cfg}: {us:7.1f} us {2.0 * M * N * K / us / 1e6:6.0f} TF/s |"
+            line += f" cfg{cfg}/gm{gm}: {us:7.1f} us {2.0 * M * N * K / us / 1e6:6.0f} TF/s |"
         print(line, flush=True)
 
 
