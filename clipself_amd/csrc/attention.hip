@@ -291,20 +291,72 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
         }
         if (active && q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
     } else {
-        stage_k<CHK, NT>(p.qkv, rowbase, p.ldqkv, C + h * HD, 0, p.Ntok, p.cos_t, p.sin_t, Kl, tid);
-        stage_vt<CHK, NT>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, 0, p.Ntok, Vt, tid);
+        // The kernel is latency-bound (profile: 64 % of wave cycles parked at s_waitcnt/s_barrier), so every global load
+        // of the workgroup -- K rows, the V block, and the Q fragments of BOTH query tiles of this wave -- is issued before
+        // the first dependent instruction; V's flight time then hides behind K's RoPE work, Q's behind the whole staging.
+        constexpr int KI = (CHK * 8 + NT - 1) / NT;
+        U128 kr[KI], vin[8], qraw[QTW][4];
+        const __bf16* kbase = p.qkv + C + h * HD;
+        const __bf16* vbase = p.qkv + 2 * C + h * HD;
+#pragma unroll
+        for (int it = 0; it < KI; ++it) {
+            const int idx = tid + it * NT, tok = idx >> 3;
+            if (idx < CHK * 8 && tok < p.Ntok) kr[it].u = *(const uint4*)(kbase + (rowbase + tok) * p.ldqkv + (idx & 7) * 8);
+            else kr[it].u = make_uint4(0, 0, 0, 0);
+        }
+        const int vkb = tid >> 3, vc = tid & 7;                // one (key block, dim chunk) item per thread (CHK <= NT)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tok = vkb * 8 + i;
+            if (tid < CHK && tok < p.Ntok) vin[i].u = *(const uint4*)(vbase + (rowbase + tok) * p.ldqkv + vc * 8);
+            else vin[i].u = make_uint4(0, 0, 0, 0);
+        }
+        int qcs[QTW];
+#pragma unroll
+        for (int j = 0; j < QTW; ++j) {
+            qcs[j] = min(q_wg + (wave + j * NW) * 32 + l31, p.Ntok - 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                qraw[j][ks].u = *(const uint4*)(p.qkv + (rowbase + qcs[j]) * p.ldqkv + h * HD + ks * 16 + hf * 8);
+        }
+        // K: rotate + swizzled LDS image
+#pragma unroll
+        for (int it = 0; it < KI; ++it) {
+            const int idx = tid + it * NT, r = idx >> 3, c = idx & 7;
+            if (idx < CHK * 8) {
+                if (r > 0 && r < p.Ntok) rope8(kr[it], p.cos_t + (size_t)(r - 1) * HD + c * 8, p.sin_t + (size_t)(r - 1) * HD + c * 8);
+                *(uint4*)(Kl + k_off(r, c)) = kr[it].u;
+            }
+        }
+        // V: 8x8 in-register transpose -> V^T image
+        if (tid < CHK) {
+            const int pos = (vkb ^ vc) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                U128 o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o.e[i] = vin[i].e[j];
+                *(uint4*)(Vt + (vc * 8 + j) * VT_LD + pos) = o.u;
+            }
+        }
         __syncthreads();
-#pragma nounroll
+#pragma unroll
         for (int j = 0; j < QTW; ++j) {
             const int q0 = q_wg + (wave + j * NW) * 32;
-            if (q0 >= p.Ntok) break;
-            const int q = q0 + l31, qc = min(q, p.Ntok - 1);
-            bf16x8 qf[4];
-            load_q_frags(p, rowbase, qc, h, hf, qf);
-            float m = -INFINITY, l = 0.f;
-            f32x16 o[2] = {zero16(), zero16()};
-            attend_chunk<CH>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o);
-            if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
+            if (q0 < p.Ntok) {
+                const int q = q0 + l31, qc = qcs[j];
+                bf16x8 qf[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int d0 = ks * 16 + hf * 8;
+                    if (qc > 0) rope8(qraw[j][ks], p.cos_t + (size_t)(qc - 1) * HD + d0, p.sin_t + (size_t)(qc - 1) * HD + d0);
+                    qf[ks] = qraw[j][ks].h;
+                }
+                float m = -INFINITY, l = 0.f;
+                f32x16 o[2] = {zero16(), zero16()};
+                attend_chunk<CH>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o);
+                if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
+            }
         }
     }
 }
