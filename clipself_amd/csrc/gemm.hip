@@ -10,26 +10,32 @@
 //   wgrad    dW = dy^T x        A = dy^T [N',Mp], B = x^T [K',Mp] (explicit transposes, split-K)
 //
 // Structure (MI355X: 256 CUs x 4 SIMDs, 64-lane waves, 160 KiB LDS/CU, 8 XCDs with private L2):
-//   * workgroup tile BM x BN x 64, three shapes: 256x256 (8 waves, 128x64 per wave, 1 WG/CU), 256x128 (8 waves,
-//     64x64 per wave) and 128x128 (4 waves); MFMA 32x32x16 bf16, fp32 accumulators in registers.
-//     The large tiles exist to cut LDS traffic per MFMA (operand re-use across the wave tile and across waves):
-//     at 128x128 the LDS-DMA fill + fragment reads cost about as many LDS cycles as the MFMAs themselves.
-//   * operands go global -> LDS with the 16-byte `global_load_lds` DMA (no VGPR round trip), double buffered,
-//     one barrier per K tile.  The LDS image is lane-linear by construction of that instruction, so the bank
-//     swizzle is applied to the per-lane SOURCE address: two 128-byte tile rows share one 256-byte LDS row whose
-//     sixteen 16-byte slots are XOR-permuted by (lds_row & 15) -> every ds_read_b128 lane group hits 16 distinct
-//     slots (conflict free).
-//   * epilogue through LDS: each wave parks a 32 x TN fp32 slab of its accumulators in a private LDS region and
-//     reads it back row-wise, so global stores/loads (bias, residual, pos-embed) are 16-byte per lane and cover
-//     whole 256-byte row segments instead of 2-byte scattered stores.
-//   * workgroup ids are remapped so that each XCD owns a contiguous range of M panels and walks the N tiles of a
-//     panel back to back (the A panel is fetched from HBM once per XCD L2).
+//   * workgroup tile BM x BN x 64: 256x256 (8 waves, 128x64 per wave, 1 WG/CU), 256x128 (8 waves, 64x64 per wave) and
+//     128x128 (4 waves, 2 WG/CU); MFMA 32x32x16 bf16, fp32 accumulators in registers.  The large tiles exist to cut LDS
+//     traffic per MFMA (operand re-use across the wave tile and across waves).
+//   * operands go global -> LDS with the 16-byte `global_load_lds` DMA (no VGPR round trip), double buffered.
+//     The LDS image is lane-linear by construction of that instruction, so the bank swizzle is applied to the per-lane
+//     SOURCE address: two 128-byte tile rows share one 256-byte LDS row whose sixteen 16-byte slots are XOR-permuted
+//     by (lds_row & 15) -> every ds_read_b128 lane group hits 16 distinct slots (conflict free; SQ_LDS_BANK_CONFLICT
+//     < 2 % of wave cycles in profiles/).
+//   * two main-loop schedules:
+//       - "lockstep": one barrier per K tile, all 8 waves read fragments and issue MFMAs together (any tile shape);
+//       - "ping-pong" (256x256 only): the two 4-wave row groups run half a K tile out of phase, separated by raw
+//         s_barriers, so in every barrier interval one group issues 16 MFMAs per wave while the other reads its
+//         next fragments from LDS / issues the next tile's DMA -- each SIMD hosts one wave of either group, so its
+//         matrix pipe alternates between them instead of idling during fragment loads.
+//   * epilogue through LDS: each wave parks a 32 x 64 fp32 slab of its accumulators in a private LDS region and reads
+//     it back row-wise, so global stores/loads (bias, residual, pos-embed) are 16-byte per lane and cover whole
+//     256-byte row segments.
+//   * workgroup ids are remapped so that each XCD owns a contiguous range of tiles, rasterised in groups of 8 M panels
+//     (B tiles stay in that XCD's 4 MiB L2 while 8 A panels stream past).
 #include "cs_common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
 
 constexpr int BK = 64;
+constexpr bool PP_DEFAULT = false;     // make the ping-pong schedule the default for 256x256 tiles (A/B knob, see tools/gemm_bench.py)
 enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID_F32 = 2, EPI_SWIGLU_BF16 = 3, EPI_ATOMIC_F32 = 4, EPI_PATCH_F32 = 5 };
 
 struct GemmArgs {
@@ -46,11 +52,9 @@ struct GemmArgs {
     int gm;               // M panels per raster group
 };
 
-// LDS byte offset of (tile row r, 16-byte chunk c) inside an operand tile of 128-byte rows
-__device__ __forceinline__ int lds_off(int r, int c) { return ((r >> 1) << 8) + (((((r & 1) << 3) | c) ^ ((r >> 1) & 15)) << 4); }
-
 // One wave instruction fills 1 KiB = 8 tile rows (row group rg).  Lane l lands at rg*1024 + l*16, i.e. LDS row
-// rg*4 + (l>>4), slot l&15, and must therefore fetch the chunk that lds_off() maps to that slot.
+// rg*4 + (l>>4), slot l&15; element (tile row r, 16-byte chunk c) lives at LDS row r>>1, slot ((r&1)*8 | c) ^ ((r>>1)&15),
+// so the lane must fetch the chunk that this map sends to its slot.
 __device__ __forceinline__ void lane_source(int rg, int lane, int& tile_row, int& chunk) {
     const int lrow = rg * 4 + (lane >> 4);
     const int c16 = (lane & 15) ^ (lrow & 15);
@@ -74,45 +78,21 @@ __device__ __forceinline__ void stage_tile(const __bf16* __restrict__ src, int l
     }
 }
 
-constexpr int EP_LD = 68;                       // fp32 row stride of the epilogue slab (64 + 4 pad)
-constexpr int EP_BYTES = 32 * EP_LD * 4;        // 32 rows per wave slab
-
-template <int EPI, int BM, int BN, int WM, int WN, bool GLDS, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
-    constexpr int NW = WM * WN;
-    constexpr int TM = BM / WM, TN = BN / WN;           // wave tile
-    constexpr int FM = TM / 32, FN = TN / 32;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
-    static_assert(TN == 64, "epilogue assumes 64-column wave tiles");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int hf = lane >> 5, l31 = lane & 31;
-
-    // ---- XCD-aware bijective remap of the 1-D workgroup id (block b runs on XCD b % 8)
+// XCD-aware, grouped-raster tile assignment (block b runs on XCD b % 8; bijective for any grid size)
+__device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& tn) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    // grouped raster inside the XCD's range: `gm` M panels share each B tile before the next N tile is touched, so
-    // the 32 workgroups in flight on an XCD work on ~gm A panels + 32/gm B tiles (fits the 4 MiB L2) instead of
-    // 2 A panels + 16 B tiles.
-    int tn, tm;
-    {
-        const int per_group = p.gm * p.tiles_n;
-        const int grp = swz / per_group, rem = swz - grp * per_group;
-        const int rows = min(p.gm, p.tiles_m - grp * p.gm);
-        tn = rem / rows;
-        tm = grp * p.gm + (rem - tn * rows);
-    }
-    const int m0 = tm * BM;
-    const int n0 = tn * BN;
+    const int per_group = p.gm * p.tiles_n;
+    const int grp = swz / per_group, rem = swz - grp * per_group;
+    const int rows = min(p.gm, p.tiles_m - grp * p.gm);
+    tn = rem / rows;
+    tm = grp * p.gm + (rem - tn * rows);
+}
 
-    // ---- per-lane source rows/chunks of this wave's staging instructions
-    int arow[A_INSTR], achk[A_INSTR], brow[B_INSTR], bchk[B_INSTR];
+template <int EPI, int BM, int BN, int NW, int A_INSTR, int B_INSTR>
+__device__ __forceinline__ void source_rows(const GemmArgs& p, int wave, int lane, int m0, int n0, int tn, int (&arow)[A_INSTR],
+                                            int (&achk)[A_INSTR], int (&brow)[B_INSTR], int (&bchk)[B_INSTR]) {
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
         int tr;
@@ -132,6 +112,111 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
             brow[i] = min(n0 + tr, p.N - 1);
         }
     }
+}
+
+constexpr int EP_LD = 68;                       // fp32 row stride of the epilogue slab (64 + 4 pad)
+constexpr int EP_BYTES = 32 * EP_LD * 4;        // 32 rows per wave slab
+
+// Epilogue through a wave-private LDS slab [32][EP_LD] fp32.  The slab is wave-private and a wave's DS operations execute in
+// order, so no workgroup barrier is needed inside (a __syncthreads() would also wait for every outstanding global store).
+template <int EPI, int FM, int FN, int BN>
+__device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[FM][FN], char* smem, int wave, int lane, int row0,
+                                         int n0, int tn, int wn) {
+    static_assert(FN == 2, "epilogue assumes 64-column wave tiles");
+    const int l31 = lane & 31;
+    float* slab = (float*)(smem + wave * EP_BYTES);
+    const int rrow = lane >> 4, rcol = (lane & 15) * 4;  // read-out: 16 lanes per row, 4 consecutive columns per lane
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slab[mfma32_row(e, lane) * EP_LD + j * 32 + l31] = acc[i][j][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int row_base = row0 + i * 32;
+        if (EPI == EPI_SWIGLU_BF16) {
+            // slab columns [0,32) = x1, [32,64) = x2 of hidden units hcol .. ; 8 lanes per row, 4 hidden units per lane
+            const int hr = lane >> 3, hc = (lane & 7) * 4;
+            const int hcol = tn * (BN / 2) + wn * 32 + hc;
+            if (hcol < p.group) {
+                float b1[4] = {0, 0, 0, 0}, b2[4] = {0, 0, 0, 0};
+                if (p.bias) {
+                    const float4 t1 = *(const float4*)(p.bias + hcol), t2 = *(const float4*)(p.bias + p.group + hcol);
+                    b1[0] = t1.x; b1[1] = t1.y; b1[2] = t1.z; b1[3] = t1.w; b2[0] = t2.x; b2[1] = t2.y; b2[2] = t2.z; b2[3] = t2.w;
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int rl = hr + it * 8, row = row_base + rl;
+                    if (row < p.M) {
+                        const float4 x1 = *(const float4*)(slab + rl * EP_LD + hc), x2 = *(const float4*)(slab + rl * EP_LD + 32 + hc);
+                        const float u[4] = {x1.x + b1[0], x1.y + b1[1], x1.z + b1[2], x1.w + b1[3]};
+                        const float v[4] = {x2.x + b2[0], x2.y + b2[1], x2.z + b2[2], x2.w + b2[3]};
+                        U64 o;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o.e[t] = f2bf(u[t] / (1.f + __expf(-u[t])) * v[t]);
+                        *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + hcol) = o.u;
+                    }
+                }
+            }
+        } else {
+            const int col = n0 + wn * 64 + rcol;
+            if (col < p.N) {
+                float bv[4] = {0, 0, 0, 0};
+                if (p.bias) { const float4 t = *(const float4*)(p.bias + col); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int rl = rrow + it * 4, row = row_base + rl;
+                    if (row >= p.M) continue;
+                    const float4 s = *(const float4*)(slab + rl * EP_LD + rcol);
+                    float v[4] = {s.x + bv[0], s.y + bv[1], s.z + bv[2], s.w + bv[3]};
+                    if (EPI == EPI_BF16) {
+                        U64 o;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o.e[t] = f2bf(v[t]);
+                        *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + col) = o.u;
+                    } else if (EPI == EPI_F32) {
+                        *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else if (EPI == EPI_RESID_F32) {
+                        const size_t o = (size_t)row * p.ldc + col;
+                        const float4 x = *(const float4*)(p.extra + o);
+                        *(float4*)((float*)p.C + o) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
+                    } else if (EPI == EPI_ATOMIC_F32) {
+                        float* d = (float*)p.C + (size_t)row * p.ldc + col;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) unsafeAtomicAdd(d + t, v[t]);
+                    } else if (EPI == EPI_PATCH_F32) {
+                        const int img = row / p.group, t = row - img * p.group;
+                        const float4 x = *(const float4*)(p.extra + (size_t)(t + 1) * p.ldc + col);
+                        *(float4*)((float*)p.C + (size_t)(row + img + 1) * p.ldc + col) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
+                    }
+                }
+            }
+        }
+        if (i + 1 < FM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next block rewrites it
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ lockstep schedule
+template <int EPI, int BM, int BN, int WM, int WN, bool GLDS, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;           // wave tile
+    constexpr int FM = TM / 32, FN = TN / 32;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int hf = lane >> 5, l31 = lane & 31;
+    int tm, tn;
+    tile_of_block(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    int arow[A_INSTR], achk[A_INSTR], brow[B_INSTR], bchk[B_INSTR];
+    source_rows<EPI, BM, BN, NW, A_INSTR, B_INSTR>(p, wave, lane, m0, n0, tn, arow, achk, brow, bchk);
 
     const int kt_begin = blockIdx.y * p.ktiles_per_split;
     const int kt_end = min(kt_begin + p.ktiles_per_split, p.K / BK);
@@ -180,7 +265,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
         }
         const char* la = smem + cur * STAGE + a_base;
         const char* lb = smem + cur * STAGE + A_BYTES + b_base;
-        const int cur_next = (NS == 3) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int off = ((par8 | (ks * 2 + hf)) ^ sw) << 4;
@@ -194,85 +278,120 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        cur = cur_next;
+        cur = (NS == 3) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
     }
-
-    // ---- epilogue through a wave-private LDS slab [32][EP_LD] fp32 -------------------------------------------
     __syncthreads();                                    // every wave is done reading the operand buffers
-    float* slab = (float*)(smem + wave * EP_BYTES);
-    const int rrow = lane >> 4, rcol = (lane & 15) * 4;  // read-out: 16 lanes per row, 4 consecutive columns per lane
+    epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + wm * TM, n0, tn, wn);
+}
+
+// ------------------------------------------------------------------------------------------------ ping-pong schedule
+// 256x256x64 tile, 8 waves = 2 row groups (g = wave>>2) x 4 column waves, wave tile 128x64.  Barrier intervals:
+//   group 0:  L(kt,0) | C(kt,0) | L(kt,1) | C(kt,1) | L(kt+1,0) ...        L(kt,h): 12 ds_read_b128 (fragments of k-steps
+//   group 1:     -    | L(kt,0) | C(kt,0) | L(kt,1) | C(kt,1)   ...                 2h,2h+1);  C(kt,h): the 16 MFMAs on them
+// Tile kt+1's DMA is issued during interval 4kt (group 0 in L(kt,0), group 1 in C(kt-1,1)): the buffer it overwrites was last
+// read in interval 4kt-1.  It is waited for (vmcnt(0)) just before the barrier that ends interval 4kt+3.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256, NW = 8, WN = 4, TM = 128, FM = 4, FN = 2;
+    constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
+    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wn = wave & 3;
+    const int hf = lane >> 5, l31 = lane & 31;
+    int tm, tn;
+    tile_of_block(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    int arow[A_INSTR], achk[A_INSTR], brow[B_INSTR], bchk[B_INSTR];
+    source_rows<EPI, BM, BN, NW, A_INSTR, B_INSTR>(p, wave, lane, m0, n0, tn, arow, achk, brow, bchk);
+
+    const int kt_begin = blockIdx.y * p.ktiles_per_split;
+    const int kt_end = min(kt_begin + p.ktiles_per_split, p.K / BK);
+
+    f32x16 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) slab[mfma32_row(e, lane) * EP_LD + j * 32 + l31] = acc[i][j][e];
-        // The slab is wave-private and a wave's DS operations execute in order, so no workgroup barrier is needed
-        // (a __syncthreads() here would also wait for every outstanding global store: one HBM round trip per slab).
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int row_base = m0 + wm * TM + i * 32;
-        if (EPI == EPI_SWIGLU_BF16) {
-            // slab columns [0,32) = x1, [32,64) = x2 of hidden units hcol0 .. hcol0+31; 8 lanes per row, 4 hidden units per lane
-            const int hr = lane >> 3, hc = (lane & 7) * 4;
-            const int hcol = tn * (BN / 2) + wn * 32 + hc;
-            if (hcol < p.group) {
-                float b1[4] = {0, 0, 0, 0}, b2[4] = {0, 0, 0, 0};
-                if (p.bias) {
-                    const float4 t1 = *(const float4*)(p.bias + hcol), t2 = *(const float4*)(p.bias + p.group + hcol);
-                    b1[0] = t1.x; b1[1] = t1.y; b1[2] = t1.z; b1[3] = t1.w; b2[0] = t2.x; b2[1] = t2.y; b2[2] = t2.z; b2[3] = t2.w;
-                }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int a_base = ((g * TM + l31) >> 1) << 8;
+    const int b_base = ((wn * 64 + l31) >> 1) << 8;
+    const int par8 = (l31 & 1) << 3, sw = l31 >> 1;
+
+    auto issue = [&](int kt, int buf) {
+        char* dst = smem + buf * STAGE;
+        stage_tile<A_INSTR, true>(p.A, p.lda, kt * BK, dst, wave * A_INSTR, lane, arow, achk);
+        stage_tile<B_INSTR, true>(p.B, p.ldb, kt * BK, dst + A_BYTES, wave * B_INSTR, lane, brow, bchk);
+    };
+    bf16x8 fa[2][FM], fb[2][FN];
+    auto load_frags = [&](int buf, int h) {
+        const char* la = smem + buf * STAGE + a_base;
+        const char* lb = smem + buf * STAGE + A_BYTES + b_base;
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int rl = hr + it * 8, row = row_base + rl;
-                    if (row < p.M) {
-                        const float4 x1 = *(const float4*)(slab + rl * EP_LD + hc), x2 = *(const float4*)(slab + rl * EP_LD + 32 + hc);
-                        const float u[4] = {x1.x + b1[0], x1.y + b1[1], x1.z + b1[2], x1.w + b1[3]};
-                        const float v[4] = {x2.x + b2[0], x2.y + b2[1], x2.z + b2[2], x2.w + b2[3]};
-                        U64 o;
+        for (int s = 0; s < 2; ++s) {
+            const int off = ((par8 | ((h * 2 + s) * 2 + hf)) ^ sw) << 4;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) o.e[t] = f2bf(u[t] / (1.f + __expf(-u[t])) * v[t]);
-                        *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + hcol) = o.u;
-                    }
-                }
-            }
-        } else {
-            const int col = n0 + wn * TN + rcol;
-            if (col < p.N) {
-                float bv[4] = {0, 0, 0, 0};
-                if (p.bias) { const float4 t = *(const float4*)(p.bias + col); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
+            for (int i = 0; i < FM; ++i) fa[s][i] = *(const bf16x8*)(la + i * (16 * 256) + off);
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int rl = rrow + it * 4, row = row_base + rl;
-                    if (row >= p.M) continue;
-                    const float4 s = *(const float4*)(slab + rl * EP_LD + rcol);
-                    float v[4] = {s.x + bv[0], s.y + bv[1], s.z + bv[2], s.w + bv[3]};
-                    if (EPI == EPI_BF16) {
-                        U64 o;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) o.e[t] = f2bf(v[t]);
-                        *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + col) = o.u;
-                    } else if (EPI == EPI_F32) {
-                        *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else if (EPI == EPI_RESID_F32) {
-                        const size_t o = (size_t)row * p.ldc + col;
-                        const float4 x = *(const float4*)(p.extra + o);
-                        *(float4*)((float*)p.C + o) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
-                    } else if (EPI == EPI_ATOMIC_F32) {
-                        float* d = (float*)p.C + (size_t)row * p.ldc + col;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) unsafeAtomicAdd(d + t, v[t]);
-                    } else if (EPI == EPI_PATCH_F32) {
-                        const int img = row / p.group, t = row - img * p.group;
-                        const float4 x = *(const float4*)(p.extra + (size_t)(t + 1) * p.ldc + col);
-                        *(float4*)((float*)p.C + (size_t)(row + img + 1) * p.ldc + col) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
-                    }
-                }
-            }
+            for (int j = 0; j < FN; ++j) fb[s][j] = *(const bf16x8*)(lb + j * (16 * 256) + off);
         }
-        if (i + 1 < FM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next block rewrites it
+    };
+    auto mfma_half = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+    };
+    // sched_barrier(0): MFMAs are register-only, nothing else stops the scheduler from moving them across the s_barrier
+#define PP_BARRIER()                                        \
+    do {                                                    \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+        __builtin_amdgcn_s_barrier();                       \
+        __builtin_amdgcn_sched_barrier(0);                  \
+    } while (0)
+
+    if (kt_begin < kt_end) {
+        issue(kt_begin, 0);
+        if (g == 1 && kt_begin + 1 < kt_end) issue(kt_begin + 1, 1);   // group 1 has no C(-1,1) part to issue tile 1 from
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (group 1 also waits for its tile-1 share: prologue only)
     }
+    PP_BARRIER();                       // tile 0 visible to everyone
+    if (g == 1) PP_BARRIER();           // interval 0: group 1 idles one interval behind
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_begin) & 1;
+        // ---- L(kt,0)
+        if (g == 0 && kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
+        load_frags(cur, 0);
+        PP_BARRIER();
+        // ---- C(kt,0)
+        mfma_half();
+        PP_BARRIER();
+        // ---- L(kt,1)
+        load_frags(cur, 1);
+        if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 (issued in C(kt-1,1)) has landed
+        PP_BARRIER();
+        // ---- C(kt,1)
+        if (g == 1 && kt + 2 < kt_end) issue(kt + 2, cur);               // buffer `cur` was last read in this group's L(kt,1)
+        mfma_half();
+        if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 (issued in L(kt,0)) has landed
+        PP_BARRIER();
+    }
+    if (g == 0) PP_BARRIER();           // group 0 waits for group 1's last interval
+#undef PP_BARRIER
+    __syncthreads();
+    epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + g * TM, n0, tn, wn);
 }
 
+// ------------------------------------------------------------------------------------------------ launch
 template <int EPI, int BM, int BN, int WM, int WN, int NS>
 int launch_cfg(GemmArgs a, int splits, int use_glds, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -296,11 +415,16 @@ int launch_cfg(GemmArgs a, int splits, int use_glds, hipStream_t stream) {
     return 0;
 }
 
-// tile-shape choice: prefer the big tiles (less LDS traffic per MFMA) unless the grid would leave CUs idle
-inline double wave_eff(long tiles, int per_cu) {
-    const long slots = 256L * per_cu;
-    const long rounds = (tiles + slots - 1) / slots;
-    return (double)tiles / (double)(rounds * slots);
+template <int EPI>
+int launch_pp(GemmArgs a, int splits, hipStream_t stream) {
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + 127) / 128 : (a.N + 255) / 256;
+    constexpr size_t lds = (size_t)512 * BK * 2 * 2;
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
+    CS_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int EPI>
@@ -334,11 +458,13 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
         if (a.M < 256 || ncols < 256) c3 = 1e30;
         if (a.M < 256 || ncols < 128) c2 = 1e30;
         cfg = (c3 <= c2 && c3 <= c1) ? 3 : (c2 <= c1 ? 2 : 1);
+        if (cfg == 3 && use_glds && PP_DEFAULT) cfg = 5;
     }
-    const int ns = sp[cfg > 3 ? 2 : cfg];
+    const int ns = sp[cfg == 4 ? 2 : (cfg == 5 ? 3 : cfg)];
     a.ktiles_per_split = (ktiles + ns - 1) / ns;
     switch (cfg) {
-        case 4: return launch_cfg<EPI, 256, 128, 4, 2, 3>(a, sp[2], use_glds, stream);   // 3-stage ring (experimental A/B)
+        case 5: return launch_pp<EPI>(a, ns, stream);                                  // 256x256 ping-pong
+        case 4: return launch_cfg<EPI, 256, 128, 4, 2, 3>(a, ns, use_glds, stream);     // 256x128, 3-stage ring
         case 3: return launch_cfg<EPI, 256, 256, 2, 4, 2>(a, ns, use_glds, stream);
         case 2: return launch_cfg<EPI, 256, 128, 4, 2, 2>(a, ns, use_glds, stream);
         default: return launch_cfg<EPI, 128, 128, 2, 2, 2>(a, ns, use_glds, stream);
@@ -353,7 +479,9 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 //      4 f32 atomic accumulate (split-K, C pre-zeroed or accumulating) |
 //      5 patch-embed: out row = row + row/group + 1, += extra[(row%group+1)*ldc + col]
 // flags bit0: 0 = global_load_lds staging, 1 = register staging (debug/fallback A-B switch)
-//       bits 4-6: force tile shape (1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x128 with a 3-stage LDS ring; 0 = heuristic)
+//       bits 4-6: force schedule (1 = 128x128, 2 = 256x128, 3 = 256x256 lockstep, 4 = 256x128 3-stage ring,
+//                 5 = 256x256 ping-pong; 0 = heuristic)
+//       bits 8-11: raster group height override (0 = 8)
 extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
                           int lda, int ldb, int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
     CS_CHECK_ARG(M > 0 && N > 0 && K > 0, "cs_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
@@ -368,13 +496,14 @@ extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bi
     a.A = (const __bf16*)A; a.B = (const __bf16*)B; a.C = C; a.bias = bias; a.extra = extra;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.group = group;
     a.tiles_m = a.tiles_n = 0;
-    a.gm = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 8;      // flags bits 8-11: raster group height override (A/B knob)
+    a.gm = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 8;
     if (epi == EPI_SWIGLU_BF16) CS_CHECK_ARG(group > 0 && N == 2 * group, "cs_gemm_nt: swiglu epilogue needs N == 2*group");
     if (epi == EPI_PATCH_F32 || epi == EPI_RESID_F32) CS_CHECK_ARG(extra != nullptr && ((uintptr_t)extra % 16) == 0, "cs_gemm_nt: epilogue %d needs 16-byte aligned extra", epi);
     if (epi == EPI_PATCH_F32) CS_CHECK_ARG(group > 0, "cs_gemm_nt: patch epilogue needs group");
     a.ktiles_per_split = K / BK;
     const int glds = (flags & 1) ? 0 : 1;
     const int force = (flags >> 4) & 7;
+    CS_CHECK_ARG(!(force == 5 && !glds), "cs_gemm_nt: the ping-pong schedule only exists with LDS-DMA staging");
     switch (epi) {
         case EPI_BF16: return launch<EPI_BF16>(a, splits, glds, force, stream);
         case EPI_F32: return launch<EPI_F32>(a, splits, glds, force, stream);
