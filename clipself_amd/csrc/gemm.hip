@@ -197,7 +197,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
 }
 
 // ------------------------------------------------------------------------------------------------ lockstep schedule
-template <int EPI, int BM, int BN, int WM, int WN, bool GLDS, int NS>
+template <int EPI, int BM, int BN, int WM, int WN, bool GLDS, int NS, bool PF>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;           // wave tile
@@ -242,6 +242,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
         stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt_begin + 1) * BK, smem + STAGE + A_BYTES, wave * B_INSTR, lane, brow, bchk);
     }
     int cur = 0;
+    bool pf_pending = false;
+    const __bf16* pf_base = p.A;
+    if (PF) {                                           // the operand line this lane warms up in L2 (see main loop)
+        const int L = wave * 64 + lane;
+        if (L < BM) {
+            pf_base = p.A + (size_t)min(m0 + L, p.M - 1) * p.lda;
+        } else {
+            const int tr = min(L - BM, BN - 1);
+            int br = min(n0 + tr, p.N - 1);
+            if (EPI == EPI_SWIGLU_BF16) br = ((tr >> 5) & 1) * p.group + min(tn * (BN / 2) + (tr >> 6) * 32 + (tr & 31), p.group - 1);
+            pf_base = p.B + (size_t)br * p.ldb;
+        }
+    }
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         if (NS == 3) {
             // Counted wait: tile kt (older) must have landed, tile kt+1 (A_INSTR+B_INSTR newer DMA ops of this wave) may stay
@@ -254,6 +267,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
                 char* nxt = smem + ((cur + 2) % 3) * STAGE;
                 stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 2) * BK, nxt, wave * A_INSTR, lane, arow, achk);
                 stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 2) * BK, nxt + A_BYTES, wave * B_INSTR, lane, brow, bchk);
+            }
+        } else if (PF && GLDS) {
+            // 2-stage ring + L2 warm-up: besides tile kt+1's DMA, each wave touches one 16-byte piece of 64 distinct
+            // 128-byte lines of tile kt+2 (the 8 waves cover all 512 operand lines) with a throw-away LDS-DMA into a
+            // scratch slot, so that tile kt+2's real DMA one iteration later hits L2 instead of the fabric.  The
+            // throw-away op is the newest VMEM op of the wave: vmcnt(1) waits for tile kt only.
+            if (pf_pending) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < kt_end) {
+                char* nxt = smem + (cur ^ 1) * STAGE;
+                stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 1) * BK, nxt, wave * A_INSTR, lane, arow, achk);
+                stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 1) * BK, nxt + A_BYTES, wave * B_INSTR, lane, brow, bchk);
+            }
+            pf_pending = kt + 2 < kt_end;
+            if (pf_pending) {
+                const __bf16* g = pf_base + (size_t)(kt + 2) * BK;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(smem + 2 * STAGE + wave * 1024), 16, 0, 0);
             }
         } else {
             __syncthreads();        // tile kt landed (the barrier drains the LDS-DMA queue); buffer cur^1 is free
@@ -392,24 +425,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------ launch
-template <int EPI, int BM, int BN, int WM, int WN, int NS>
+template <int EPI, int BM, int BN, int WM, int WN, int NS, bool PF = false>
 int launch_cfg(GemmArgs a, int splits, int use_glds, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + BN / 2 - 1) / (BN / 2) : (a.N + BN - 1) / BN;
     constexpr int NW = WM * WN;
-    constexpr size_t stage = (size_t)(BM + BN) * BK * 2 * NS;
+    constexpr size_t stage = (size_t)(BM + BN) * BK * 2 * NS + (PF ? (size_t)NW * 1024 : 0);
     constexpr size_t lds = stage > (size_t)NW * EP_BYTES ? stage : (size_t)NW * EP_BYTES;
     dim3 grid(a.tiles_m * a.tiles_n, splits), block(NW * 64);
     if (use_glds) {
-        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, true, NS>,
+        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, true, NS, PF>,
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, true, NS>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, true, NS, PF>), grid, block, lds, stream, a);
     } else {
-        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, false, NS>,
+        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, false, NS, false>,
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, false, NS>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, false, NS, false>), grid, block, lds, stream, a);
     }
     CS_LAUNCH_CHECK();
     return 0;
@@ -460,9 +493,10 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
         cfg = (c3 <= c2 && c3 <= c1) ? 3 : (c2 <= c1 ? 2 : 1);
         if (cfg == 3 && use_glds && PP_DEFAULT) cfg = 5;
     }
-    const int ns = sp[cfg == 4 ? 2 : (cfg == 5 ? 3 : cfg)];
+    const int ns = sp[cfg == 4 ? 2 : (cfg >= 5 ? 3 : cfg)];
     a.ktiles_per_split = (ktiles + ns - 1) / ns;
     switch (cfg) {
+        case 6: return launch_cfg<EPI, 256, 256, 2, 4, 2, true>(a, ns, use_glds, stream);   // 256x256 lockstep + L2 warm-up of tile kt+2
         case 5: return launch_pp<EPI>(a, ns, stream);                                  // 256x256 ping-pong
         case 4: return launch_cfg<EPI, 256, 128, 4, 2, 3>(a, ns, use_glds, stream);     // 256x128, 3-stage ring
         case 3: return launch_cfg<EPI, 256, 256, 2, 4, 2>(a, ns, use_glds, stream);
@@ -480,7 +514,7 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 //      5 patch-embed: out row = row + row/group + 1, += extra[(row%group+1)*ldc + col]
 // flags bit0: 0 = global_load_lds staging, 1 = register staging (debug/fallback A-B switch)
 //       bits 4-6: force schedule (1 = 128x128, 2 = 256x128, 3 = 256x256 lockstep, 4 = 256x128 3-stage ring,
-//                 5 = 256x256 ping-pong; 0 = heuristic)
+//                 5 = 256x256 ping-pong, 6 = 256x256 lockstep + L2 warm-up; 0 = heuristic)
 //       bits 8-11: raster group height override (0 = 8)
 extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
                           int lda, int ldb, int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {

@@ -174,3 +174,28 @@ def test_full_size_properties():
         t_b = teacher.encode_image(crops[:300])
         assert torch.equal(t_a, t_b)
         assert torch.isfinite(t_a).all()
+
+
+def test_non_native_grid_multichunk_attention_matches_oracle():
+    """student on a larger-than-native image (448^2 -> 28x28+1 = 785 tokens: bicubic pos-embed rescale,
+    regenerated RoPE tables, 4 key chunks in the attention kernels) against the CPU oracle, forward and one gradient."""
+    from oracle import eva_ref
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    student, teacher = _pair(cfg, 0)
+    sd = seeded_visual_state(cfg, 0)
+    images, boxes, _ = synthetic_batch(1, 6, 448, 224, seed=11)
+    rois = [b[:, :4] for b in boxes]
+    with torch.no_grad():
+        want = eva_ref.encode_pseudo_boxes(sd, cfg, images, rois)
+    got = student.encode_pseudo_boxes(images.cuda(), [r.cuda() for r in rois])
+    _log(f"b16@448 roi rel={rel(got, want):.3e} 1-cos={one_minus_cos(got, want):.2e}")
+    assert rel(got, want) < 2e-2 and one_minus_cos(got, want) < 1e-3
+    # gradient of sum(roi feats * w) w.r.t. one early and one late parameter
+    w = torch.randn(want.shape, generator=torch.Generator().manual_seed(0))
+    (got * w.cuda()).sum().backward()
+    ref = {k: v.clone().requires_grad_(k in ("visual.blocks.0.attn.q_bias", "visual.blocks.10.mlp.w3.bias")) for k, v in sd.items()}
+    (eva_ref.encode_pseudo_boxes(ref, cfg, images, rois) * w).sum().backward()
+    for n in ("visual.blocks.0.attn.q_bias", "visual.blocks.10.mlp.w3.bias"):
+        r = rel(dict(student.named_parameters())[n].grad, ref[n].grad)
+        _log(f"b16@448 grad {n} rel={r:.3e}")
+        assert r < 6e-2, (n, r)

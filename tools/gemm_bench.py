@@ -30,7 +30,7 @@ def main():
         else:
             C, extra, group = torch.empty(M, N // 2, dtype=BF, device="cuda"), None, N // 2
         line = f"{name} M={M}: "
-        for cfg, gm in ((3, 8), (5, 8), (4, 8), (2, 8), (1, 8)):
+        for cfg, gm in ((3, 8), (6, 8), (5, 8), (3, 8), (6, 8)):
             flags = (cfg << 4) | (gm << 8)
             for _ in range(3):
                 ops.gemm_nt(A, B, C, bias, extra, epi=epi, group=group, flags=flags)
