@@ -91,5 +91,12 @@ def tiny_cfg() -> TowerCfg:
                     text_width=32, text_heads=2, text_layers=1)
 
 
+def tiny14_cfg() -> TowerCfg:
+    """A small tower with the awkward dimensions of EVA02-CLIP-L-14-336: patch 14 (3*14*14 = 588, padded to 640 in
+    storage) and mlp_ratio 2.6667 (hidden int(128*2.6667) = 341, padded to 384) -- exercises every zero-padding path."""
+    return TowerCfg(name="EVA02-tiny14-test", embed_dim=64, image_size=42, patch_size=14, width=128, layers=2,
+                    head_width=64, mlp_ratio=2.6667, text_width=32, text_heads=2, text_layers=1)
+
+
 def cfg_dict(cfg: TowerCfg) -> dict:
     return asdict(cfg)

@@ -156,6 +156,24 @@ __global__ __launch_bounds__(256) void im2row_kernel(const TI* __restrict__ img,
     }
 }
 
+// generic patch size (e.g. 14): one thread per output element, zero-fills the padding columns [3*p*p, ldo)
+template <typename TI>
+__global__ __launch_bounds__(256) void im2row_generic_kernel(const TI* __restrict__ img, __bf16* __restrict__ out, int B, int S, int p, int g, int ldo) {
+    const long total = (long)B * g * g * ldo;
+    const int kk = 3 * p * p;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % ldo);
+        const long row = i / ldo;
+        float v = 0.f;
+        if (col < kk) {
+            const int ix = col % p, iy = (col / p) % p, c = col / (p * p);
+            const int px = (int)(row % g), py = (int)((row / g) % g), b = (int)(row / ((long)g * g));
+            v = (float)img[(((size_t)b * 3 + c) * S + (py * p + iy)) * S + px * p + ix];
+        }
+        out[i] = f2bf(v);
+    }
+}
+
 // x[b, 0, :] = cls + pos[0, :]   (eva_vit_model.py:540-543)
 __global__ void cls_row_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos, int B, int Ntok, int C) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,13 +226,21 @@ extern "C" int cs_colsum_bf16(const void* x, long ldx, float* out, int M, int N,
 }
 // img_dtype: 0 = f32, 1 = bf16
 extern "C" int cs_im2row(const void* img, int img_dtype, void* out, int B, int S, int p, int ldo, hipStream_t stream) {
-    CS_CHECK_ARG(p % 8 == 0 && S % p == 0 && B > 0, "cs_im2row: patch size must be a multiple of 8 and divide S (p=%d S=%d)", p, S);
+    CS_CHECK_ARG(S % p == 0 && B > 0 && ldo >= 3 * p * p, "cs_im2row: patch size must divide S and ldo >= 3*p*p (p=%d S=%d ldo=%d)", p, S, ldo);
     const int g = S / p;
-    const long total = (long)B * g * g * 3 * p * (p / 8);
-    if (img_dtype == 0)
-        hipLaunchKernelGGL((im2row_kernel<float>), dim3(grid_for(total)), dim3(256), 0, stream, (const float*)img, (__bf16*)out, B, S, p, g, ldo);
-    else
-        hipLaunchKernelGGL((im2row_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, stream, (const __bf16*)img, (__bf16*)out, B, S, p, g, ldo);
+    if (p % 8 == 0 && ldo == 3 * p * p) {
+        const long total = (long)B * g * g * 3 * p * (p / 8);
+        if (img_dtype == 0)
+            hipLaunchKernelGGL((im2row_kernel<float>), dim3(grid_for(total)), dim3(256), 0, stream, (const float*)img, (__bf16*)out, B, S, p, g, ldo);
+        else
+            hipLaunchKernelGGL((im2row_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, stream, (const __bf16*)img, (__bf16*)out, B, S, p, g, ldo);
+    } else {
+        const long total = (long)B * g * g * ldo;
+        if (img_dtype == 0)
+            hipLaunchKernelGGL((im2row_generic_kernel<float>), dim3(grid_for(total)), dim3(256), 0, stream, (const float*)img, (__bf16*)out, B, S, p, g, ldo);
+        else
+            hipLaunchKernelGGL((im2row_generic_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, stream, (const __bf16*)img, (__bf16*)out, B, S, p, g, ldo);
+    }
     CS_LAUNCH_CHECK();
     return 0;
 }

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, l
         const int c = (g * 64 + lane) * 4;
         if (g < ng && c < C) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const float d = v[g][i] - mean; q += d * d; }
+            for (int i = 0; i < 4; ++i) { const float d = v[g][i] - mean; if (c + i < C) q += d * d; }   // C may end inside a vector (padded rows)
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
             if (g < ng && c < C) {
                 float o[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = rstd * (gy[g][i] - m1 - xh[g][i] * m2);
+                for (int i = 0; i < 4; ++i) o[i] = (c + i < C) ? rstd * (gy[g][i] - m1 - xh[g][i] * m2) : 0.f;
                 if (DXMODE == DX_BF16) {
                     store_bf16x4((__bf16*)dx + (size_t)row * lddx + c, o);
                 } else {
@@ -247,7 +247,9 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 // x_dtype: 0 = f32, 1 = bf16.  mean/rstd may be null (teacher, no backward).
 extern "C" int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, void* y, long ldy,
                                 float* mean, float* rstd, int M, int C, float eps, hipStream_t stream) {
-    CS_CHECK_ARG(C % 4 == 0 && C <= MAXC, "cs_layernorm_fwd: C=%d must be a multiple of 4 and <= %d", C, MAXC);
+    // C % 4 != 0 is allowed for zero-padded rows: x, y, gamma, beta must then be readable/writable up to the next multiple of 4
+    // (padding zero in x/gamma/beta -> the padding of y comes out zero).
+    CS_CHECK_ARG(C <= MAXC && (C % 4 == 0 || (ldx >= ((C + 3) & ~3) && ldy >= ((C + 3) & ~3))), "cs_layernorm_fwd: C=%d unsupported (ld too small for a padded row, or > %d)", C, MAXC);
     CS_CHECK_ARG(M > 0, "cs_layernorm_fwd: empty input");
     dim3 grid((M + ROWS_PER_WG - 1) / ROWS_PER_WG), block(256);
 #define LNF(TX, NG) hipLaunchKernelGGL((ln_fwd_kernel<TX, NG>), grid, block, 0, stream, (const TX*)x, ldx, gamma, beta, (__bf16*)y, ldy, mean, rstd, M, C, eps)
@@ -267,7 +269,7 @@ extern "C" size_t cs_layernorm_bwd_workspace(int M, int C) {
 extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
                                 const float* rstd, void* dx, int dx_mode, long lddx, float* dgamma, float* dbeta,
                                 int accumulate_params, void* workspace, int M, int C, hipStream_t stream) {
-    CS_CHECK_ARG(C % 4 == 0 && C <= MAXC, "cs_layernorm_bwd: C=%d unsupported", C);
+    CS_CHECK_ARG(C <= MAXC && (C % 4 == 0 || (ldx >= ((C + 3) & ~3) && lddy >= ((C + 3) & ~3) && lddx >= ((C + 3) & ~3))), "cs_layernorm_bwd: C=%d unsupported", C);
     CS_CHECK_ARG(M > 0, "cs_layernorm_bwd: empty input");
     CS_CHECK_ARG(dx_mode >= 0 && dx_mode <= 2, "cs_layernorm_bwd: bad dx_mode");
     CS_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "cs_layernorm_bwd: dgamma/dbeta must both be given or both null");

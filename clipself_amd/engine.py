@@ -46,28 +46,37 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def padded_hidden(cfg: TowerCfg) -> int:
+    return _round_up(cfg.hidden, 64)
+
+
 def param_groups_layout(cfg: TowerCfg, prefix: str = "visual."):
     """Allocation groups (tensors of a group are contiguous, group starts are 64-aligned), in layer order.
-    Names are the reference state-dict keys; names starting with '_' inside a block are private padding."""
+    Entries are (name, logical shape, storage shape): names/logical shapes are the reference's state-dict entries; the
+    storage of the SwiGLU hidden dimension and of the patch-embed contraction is zero-padded to a multiple of 64 so
+    that every GEMM sees K % 64 == 0 and 16-byte rows (EVA02-L/14: hidden 2730 -> 2752, 3*14*14 = 588 -> 640; for
+    B/16 both are already multiples of 64 and storage == logical).  Names containing '._' are private padding."""
     C, Hd, E, p = cfg.width, cfg.hidden, cfg.embed_dim, cfg.patch_size
-    groups = [[(prefix + "cls_token", (1, 1, C))], [(prefix + "pos_embed", (1, cfg.tokens, C))],
-              [(prefix + "patch_embed.proj.weight", (C, 3, p, p))], [(prefix + "patch_embed.proj.bias", (C,))]]
+    Hp, Kpe, Kp = padded_hidden(cfg), 3 * p * p, _round_up(3 * p * p, 64)
+    t = lambda name, shape, storage=None: (name, shape, storage if storage is not None else shape)
+    groups = [[t(prefix + "cls_token", (1, 1, C))], [t(prefix + "pos_embed", (1, cfg.tokens, C))],
+              [t(prefix + "patch_embed.proj.weight", (C, 3, p, p), (C, Kp))], [t(prefix + "patch_embed.proj.bias", (C,))]]
     for i in range(cfg.layers):
         b = f"{prefix}blocks.{i}."
         groups += [
-            [(b + "norm1.weight", (C,))], [(b + "norm1.bias", (C,))],
-            [(b + "attn.q_proj.weight", (C, C)), (b + "attn.k_proj.weight", (C, C)), (b + "attn.v_proj.weight", (C, C))],
-            [(b + "attn.q_bias", (C,)), (b + "attn._k_bias_zero", (C,)), (b + "attn.v_bias", (C,))],
-            [(b + "attn.inner_attn_ln.weight", (C,))], [(b + "attn.inner_attn_ln.bias", (C,))],
-            [(b + "attn.proj.weight", (C, C))], [(b + "attn.proj.bias", (C,))],
-            [(b + "norm2.weight", (C,))], [(b + "norm2.bias", (C,))],
-            [(b + "mlp.w1.weight", (Hd, C)), (b + "mlp.w2.weight", (Hd, C))],
-            [(b + "mlp.w1.bias", (Hd,)), (b + "mlp.w2.bias", (Hd,))],
-            [(b + "mlp.ffn_ln.weight", (Hd,))], [(b + "mlp.ffn_ln.bias", (Hd,))],
-            [(b + "mlp.w3.weight", (C, Hd))], [(b + "mlp.w3.bias", (C,))],
+            [t(b + "norm1.weight", (C,))], [t(b + "norm1.bias", (C,))],
+            [t(b + "attn.q_proj.weight", (C, C)), t(b + "attn.k_proj.weight", (C, C)), t(b + "attn.v_proj.weight", (C, C))],
+            [t(b + "attn.q_bias", (C,)), t(b + "attn._k_bias_zero", (C,)), t(b + "attn.v_bias", (C,))],
+            [t(b + "attn.inner_attn_ln.weight", (C,))], [t(b + "attn.inner_attn_ln.bias", (C,))],
+            [t(b + "attn.proj.weight", (C, C))], [t(b + "attn.proj.bias", (C,))],
+            [t(b + "norm2.weight", (C,))], [t(b + "norm2.bias", (C,))],
+            [t(b + "mlp.w1.weight", (Hd, C), (Hp, C)), t(b + "mlp.w2.weight", (Hd, C), (Hp, C))],
+            [t(b + "mlp.w1.bias", (Hd,), (Hp,)), t(b + "mlp.w2.bias", (Hd,), (Hp,))],
+            [t(b + "mlp.ffn_ln.weight", (Hd,), (Hp,))], [t(b + "mlp.ffn_ln.bias", (Hd,), (Hp,))],
+            [t(b + "mlp.w3.weight", (C, Hd), (C, Hp))], [t(b + "mlp.w3.bias", (C,))],
         ]
-    groups += [[(prefix + "norm.weight", (C,))], [(prefix + "norm.bias", (C,))],
-               [(prefix + "head.weight", (E, C))], [(prefix + "head.bias", (E,))]]
+    groups += [[t(prefix + "norm.weight", (C,))], [t(prefix + "norm.bias", (C,))],
+               [t(prefix + "head.weight", (E, C))], [t(prefix + "head.bias", (E,))]]
     return groups
 
 
@@ -79,7 +88,8 @@ def is_no_decay(name: str, ndim: int) -> bool:
 class EvaEngine:
     def __init__(self, cfg: TowerCfg, ops, trainable: bool = False, prefix: str = "visual."):
         self.cfg, self.ops, self.prefix, self.trainable = cfg, ops, prefix, trainable
-        self.offsets = OrderedDict()          # name -> (offset, shape)
+        self.offsets = OrderedDict()          # name -> (offset, storage shape)
+        self.logical = {}                     # name -> logical (reference) shape
         off = 0
         self.block_ranges = []                # flat [begin, end) of each block (contiguous all-reduce buckets)
         cur_block, blk_begin = None, 0
@@ -91,15 +101,18 @@ class EvaEngine:
                 if cur_block is not None:
                     self.block_ranges.append((blk_begin, off))
                 cur_block, blk_begin = blk, off
-            for name, shape in grp:
-                self.offsets[name] = (off, shape)
-                off += math.prod(shape)
+            for name, shape, storage in grp:
+                self.offsets[name] = (off, storage)
+                self.logical[name] = shape
+                off += math.prod(storage)
         self.numel = _round_up(off, 256)
         self.master = ops.zeros((self.numel,), F32)
         self.shadow = ops.zeros((self.numel,), BF16)
         self.device = self.master.device
-        self.p = {n: self.master[o:o + math.prod(s)].view(s) for n, (o, s) in self.offsets.items()}
-        self.w = {n: self.shadow[o:o + math.prod(s)].view(s) for n, (o, s) in self.offsets.items()}
+        self.Hp = padded_hidden(cfg)
+        self.Kpe = _round_up(3 * cfg.patch_size * cfg.patch_size, 64)
+        self.p = {n: self.view_of(self.master, n) for n in self.offsets}
+        self.w = {n: self.view_of(self.shadow, n) for n in self.offsets}
         self._tables = {}
         self._pos_cache = {}
         self.grad = self.exp_avg = self.exp_avg_sq = self.flags = None
@@ -112,10 +125,32 @@ class EvaEngine:
             self.grad = ops.zeros((self.numel,), F32)
             self.exp_avg = ops.zeros((self.numel,), F32)
             self.exp_avg_sq = ops.zeros((self.numel,), F32)
-            self.g = {n: self.grad[o:o + math.prod(s)].view(s) for n, (o, s) in self.offsets.items()}
+            self.g = {n: self.view_of(self.grad, n) for n in self.offsets}
             self.flags = torch.zeros(self.numel // 64, dtype=torch.uint8, device=self.device)
 
     # ------------------------------------------------------------------------------------------ parameters
+    def storage_of(self, buf, name):
+        """The (possibly zero-padded) storage block of `name` inside a flat buffer, in its storage shape."""
+        o, st = self.offsets[name]
+        return buf[o:o + math.prod(st)].view(st)
+
+    def view_of(self, buf, name):
+        """The reference-shaped tensor of `name` inside a flat buffer: a plain view, or a strided view of the leading
+        block when the storage is padded."""
+        o, st = self.offsets[name]
+        shape = self.logical[name]
+        flat = buf[o:o + math.prod(st)]
+        if tuple(st) == tuple(shape) or math.prod(st) == math.prod(shape):
+            return flat.view(shape)
+        if len(st) == 1:
+            return flat[:shape[0]]
+        if len(shape) == 2:
+            return flat.view(st)[:shape[0], :shape[1]]
+        inner = [1]
+        for d in reversed(shape[2:]):
+            inner.insert(0, inner[0] * d)                 # contiguous strides of the trailing dims
+        return torch.as_strided(flat, shape, (st[1], *inner))
+
     def public_names(self):
         return [n for n in self.offsets if "._" not in n]
 
@@ -148,7 +183,7 @@ class EvaEngine:
 
     def sync_transposed(self, blocks=None):
         """W^T shadows for the dgrad GEMMs (dx = dy . W needs W with the contraction dimension contiguous)."""
-        cfg, C, Hd = self.cfg, self.cfg.width, self.cfg.hidden
+        cfg, C, Hd = self.cfg, self.cfg.width, self.Hp
         for i in (range(self.first_trainable, cfg.layers) if blocks is None else blocks):
             b = f"{self.prefix}blocks.{i}."
             o = self.offsets[b + "attn.q_proj.weight"][0]
@@ -156,7 +191,7 @@ class EvaEngine:
             self.ops.transpose_bf16(self.w[b + "attn.proj.weight"], self._wt_alloc((i, "proj"), C, C))
             o = self.offsets[b + "mlp.w1.weight"][0]
             self.ops.transpose_bf16(self.shadow[o:o + 2 * Hd * C].view(2 * Hd, C), self._wt_alloc((i, "w12"), 2 * Hd, C))
-            self.ops.transpose_bf16(self.w[b + "mlp.w3.weight"], self._wt_alloc((i, "w3"), C, Hd))
+            self.ops.transpose_bf16(self.storage_of(self.shadow, b + "mlp.w3.weight"), self._wt_alloc((i, "w3"), C, Hd))
         self.ops.transpose_bf16(self.w[self.prefix + "head.weight"], self._wt_alloc("head", self.cfg.embed_dim, C))
 
     def set_trainable_blocks(self, unlocked_groups: int):
@@ -221,12 +256,12 @@ class EvaEngine:
         B, _, S, _ = images.shape
         p, C = cfg.patch_size, cfg.width
         g = S // p
-        N, Kpe = g * g + 1, 3 * p * p
+        N, Kpe = g * g + 1, self.Kpe                       # contraction zero-padded to a multiple of 64 (3*14*14 -> 640)
         A = ops.empty((B * g * g, Kpe), BF16)
-        ops.im2row(images.contiguous(), A, p)
+        ops.im2row(images.contiguous(), A, p)              # writes the zero padding columns too
         x = ops.empty((B, N, C), F32)
         pos = self.pos_for(g)
-        ops.gemm_nt(A, self.w[P + "patch_embed.proj.weight"].view(C, Kpe), x.view(B * N, C),
+        ops.gemm_nt(A, self.storage_of(self.shadow, P + "patch_embed.proj.weight"), x.view(B * N, C),
                     bias=self.p[P + "patch_embed.proj.bias"], extra=pos, epi=EPI_PATCH_F32, group=g * g)
         ops.cls_row(x, self.p[P + "cls_token"].view(C), pos)
         return x, g
@@ -238,7 +273,7 @@ class EvaEngine:
         return self.shadow[o:o + 3 * C * C].view(3 * C, C), self.master[ob:ob + 3 * C]
 
     def _w12(self, b):
-        C, Hd = self.cfg.width, self.cfg.hidden
+        C, Hd = self.cfg.width, self.Hp
         o = self.offsets[b + "mlp.w1.weight"][0]
         ob = self.offsets[b + "mlp.w1.bias"][0]
         return self.shadow[o:o + 2 * Hd * C].view(2 * Hd, C), self.master[ob:ob + 2 * Hd]
@@ -246,7 +281,8 @@ class EvaEngine:
     def _block_fwd(self, i, x, B, N, cos, sin, with_attn=True, save=None, inplace=True):
         """x: fp32 [B*N, C].  Returns the block output (x itself when inplace)."""
         ops, cfg = self.ops, self.cfg
-        C, Hd, H, eps = cfg.width, cfg.hidden, cfg.heads, cfg.ln_eps
+        C, Hd, Hl, H, eps = cfg.width, self.Hp, cfg.hidden, cfg.heads, cfg.ln_eps      # Hd: padded storage width, Hl: logical
+        padded = Hd != Hl
         b = f"{self.prefix}blocks.{i}."
         M = B * N
         keep = save is not None
@@ -284,11 +320,12 @@ class EvaEngine:
             ops.swiglu_fwd(x12, hid)
         else:
             ops.gemm_nt(ln2, w12, hid, bias=b12, epi=EPI_SWIGLU_BF16, group=Hd)
-        fln = ops.empty((M, Hd), BF16)
+        fln = (ops.zeros if padded else ops.empty)((M, Hd), BF16)     # padding columns feed the W3 GEMM: must be exact zeros
         m4, r4 = st()
-        ops.layernorm_fwd(hid, self.p[b + "mlp.ffn_ln.weight"], self.p[b + "mlp.ffn_ln.bias"], fln, m4, r4, eps)
+        ops.layernorm_fwd(hid[:, :Hl], self.p[b + "mlp.ffn_ln.weight"], self.p[b + "mlp.ffn_ln.bias"], fln[:, :Hl], m4, r4, eps)
         x2 = x1 if inplace else ops.empty((M, C), F32)
-        ops.gemm_nt(fln, self.w[b + "mlp.w3.weight"], x2, bias=self.p[b + "mlp.w3.bias"], extra=x1, epi=EPI_RESID_F32)
+        ops.gemm_nt(fln, self.storage_of(self.shadow, b + "mlp.w3.weight"), x2, bias=self.p[b + "mlp.w3.bias"], extra=x1,
+                    epi=EPI_RESID_F32)
         if keep:
             save.update(x0=x, ln1=ln1, st1=(m1, r1), qkv=qkv, lse=lse, att=att, iln=iln, st2=(m2, r2), x1=x1, ln2=ln2,
                         st3=(m3, r3), x12=x12, hid=hid, fln=fln, st4=(m4, r4), with_attn=with_attn)
@@ -375,7 +412,8 @@ class EvaEngine:
     def _block_bwd(self, i, s, g, B, N, cos, sin, ws):
         """g: fp32 [M,C] gradient w.r.t. the block output; updated in place to the gradient w.r.t. its input."""
         ops, cfg = self.ops, self.cfg
-        C, Hd, H = cfg.width, cfg.hidden, cfg.heads
+        C, Hd, Hl, H = cfg.width, self.Hp, cfg.hidden, cfg.heads
+        padded = Hd != Hl
         b = f"{self.prefix}blocks.{i}."
         M = B * N
         G = self.g
@@ -383,11 +421,11 @@ class EvaEngine:
         gb = ops.empty((M, C), BF16)
         ops.cast_f32_bf16(g, gb)
         ops.colsum_bf16(gb, G[b + "mlp.w3.bias"])
-        self._wgrad(gb, self._transposed(s["fln"]), G[b + "mlp.w3.weight"])
+        self._wgrad(gb, self._transposed(s["fln"]), self.storage_of(self.grad, b + "mlp.w3.weight"))
         d_fln = ops.empty((M, Hd), BF16)
         ops.gemm_nt(gb, self.wt[(i, "w3")][:, :C], d_fln, epi=EPI_BF16)                     # [M,C] . W3[C,Hd]
-        d_hid = ops.empty((M, Hd), BF16)
-        ops.layernorm_bwd(d_fln, s["hid"], self.p[b + "mlp.ffn_ln.weight"], *s["st4"], d_hid, DX_BF16,
+        d_hid = (ops.zeros if padded else ops.empty)((M, Hd), BF16)
+        ops.layernorm_bwd(d_fln[:, :Hl], s["hid"][:, :Hl], self.p[b + "mlp.ffn_ln.weight"], *s["st4"], d_hid[:, :Hl], DX_BF16,
                           G[b + "mlp.ffn_ln.weight"], G[b + "mlp.ffn_ln.bias"], True, ws)
         d_x12 = ops.empty((M, 2 * Hd), BF16)
         ops.swiglu_bwd(d_hid, s["x12"], d_x12)
@@ -441,7 +479,7 @@ class EvaEngine:
         ops.gemm_nt(d_feats, self.wt["head"][:, :E], d_lnf, epi=EPI_BF16)                  # head frozen: dgrad only
         g = ops.empty((M, C), F32)
         ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "norm.weight"], *c["stf"], g, DX_F32_ASSIGN)   # final norm frozen
-        ws_bytes = max(ops.layernorm_bwd_workspace(M, max(C, cfg.hidden)), ops.attn_bwd_workspace(B, N, cfg.heads))
+        ws_bytes = max(ops.layernorm_bwd_workspace(M, max(C, self.Hp)), ops.attn_bwd_workspace(B, N, cfg.heads))
         ws = ops.empty((ws_bytes,), torch.uint8)
         for i in range(cfg.layers - 1, self.first_trainable - 1, -1):
             self._block_bwd(i, c["saves"].pop(i), g, B, N, c["cos"], c["sin"], ws)

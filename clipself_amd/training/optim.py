@@ -69,12 +69,10 @@ class FlatAdamW:
             full = by_id.get(id(p))
             if full is None or self.step_count == 0:
                 continue
-            o, shape = eng.offsets[full]
-            if not bool(active[o // 64]):
+            if not bool(active[eng.offsets[full][0] // 64]):
                 continue
-            n = p.numel()
-            state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=eng.exp_avg[o:o + n].view(shape).clone(),
-                            exp_avg_sq=eng.exp_avg_sq[o:o + n].view(shape).clone())
+            state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=eng.view_of(eng.exp_avg, full).clone(),
+                            exp_avg_sq=eng.view_of(eng.exp_avg_sq, full).clone())
         groups, i = [], 0
         for grp in self.param_groups:
             g = {k: v for k, v in grp.items() if k != "params"}
@@ -91,10 +89,8 @@ class FlatAdamW:
             full = by_id.get(id(p))
             if st is None or full is None:
                 continue
-            o, shape = eng.offsets[full]
-            n = p.numel()
-            eng.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
-            eng.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            eng.view_of(eng.exp_avg, full).copy_(st["exp_avg"].reshape(eng.logical[full]))
+            eng.view_of(eng.exp_avg_sq, full).copy_(st["exp_avg_sq"].reshape(eng.logical[full]))
             self.step_count = int(st["step"])
         for grp, saved in zip(self.param_groups, sd["param_groups"]):
             grp.update({k: v for k, v in saved.items() if k != "params"})

@@ -34,7 +34,7 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
-from clipself_amd.config import tiny_cfg, get_tower_cfg          # noqa: E402
+from clipself_amd.config import tiny_cfg, tiny14_cfg, get_tower_cfg          # noqa: E402
 from clipself_amd.init import seeded_visual_state, synthetic_batch  # noqa: E402
 from oracle.ref_import import import_reference                   # noqa: E402
 
@@ -45,9 +45,9 @@ TINY = dict(seed_w=1, seed_b=5, batch=2, boxes=3, steps=3, lr=1e-3, wd=0.1, warm
 B16 = dict(seed_w=0, seed_b=1234, batch=2, boxes=8, steps=4, lr=1e-5, wd=0.1, warmup=1000, total=10000)
 
 
-def _register_tiny(oc):
+def _register_tiny(oc, c=None):
     from open_clip.eva_clip import factory as eva_factory
-    c = tiny_cfg()
+    c = c or tiny_cfg()
     eva_factory._MODEL_CONFIGS[c.name] = {
         "embed_dim": c.embed_dim,
         "vision_cfg": {"image_size": c.image_size, "layers": c.layers, "width": c.width,
@@ -151,6 +151,28 @@ def gen_tiny(oc):
     print("tiny losses", out["losses"], "grad_none", none)
 
 
+def gen_tiny14(oc):
+    """L/14-shaped miniature (patch 14, hidden 341): pins the zero-padded storage paths."""
+    cfg = _register_tiny(oc, tiny14_cfg())
+    rec = dict(TINY, seed_w=2, seed_b=9, steps=2)
+    student, teacher, out, first, groups = _run_steps(oc, cfg, rec, cfg.image_size, cfg.image_size)
+    blob = {"losses": np.array(out["losses"], np.float64), "lrs": np.array(out["lrs"], np.float64),
+            "teacher": first["teacher"].numpy(), "student_roi": first["student_roi"].numpy(), "dense": first["dense"].numpy()}
+    none = []
+    for n, g in first["grads"].items():
+        if g is None:
+            none.append(n)
+        else:
+            blob["grad/" + n] = g.numpy()
+    for n, p in student.named_parameters():
+        if n.startswith("visual.") and p.requires_grad:
+            blob["final/" + n] = p.detach().numpy()
+    blob["grad_none"] = np.array(none)
+    blob["recipe"] = np.array(json.dumps(rec))
+    np.savez_compressed(GOLD / "tiny14_step.npz", **blob)
+    print("tiny14 losses", out["losses"])
+
+
 def gen_b16(oc):
     cfg = get_tower_cfg("EVA02-CLIP-B-16")
     rec = B16
@@ -188,7 +210,11 @@ def main():
     torch.set_num_threads(os.cpu_count() or 1)
     oc = import_reference()
     GOLD.mkdir(parents=True, exist_ok=True)
+    if "--tiny14-only" in sys.argv:
+        gen_tiny14(oc)
+        return
     gen_tiny(oc)
+    gen_tiny14(oc)
     if "--tiny-only" not in sys.argv:
         gen_b16(oc)
 

@@ -194,6 +194,7 @@ class RefOps:
         g = S // p
         patches = img.float().reshape(B, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B * g * g, 3 * p * p)
         out[:, :3 * p * p] = patches.to(torch.bfloat16)
+        out[:, 3 * p * p:] = 0                      # zero the K padding (p=14: 588 -> 640)
 
     def cls_row(self, x, cls, pos):
         x[:, 0, :] = cls + pos[0]

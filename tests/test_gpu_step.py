@@ -199,3 +199,11 @@ def test_non_native_grid_multichunk_attention_matches_oracle():
         r = rel(dict(student.named_parameters())[n].grad, ref[n].grad)
         _log(f"b16@448 grad {n} rel={r:.3e}")
         assert r < 6e-2, (n, r)
+
+
+def test_l14_shaped_tower_with_padded_storage_on_gpu(golden_dir):
+    """patch 14 / hidden 341 (the L/14-336 dimension classes) through the HIP kernels: zero-padded K of the patch embed
+    and of W3, LayerNorm over a row that ends inside a vector, padded SwiGLU width."""
+    from clipself_amd.hip import HipOps
+    from test_padded_dims_cpu import run_tiny14
+    run_tiny14(HipOps, "cuda", golden_dir, _log)
