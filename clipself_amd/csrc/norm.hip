@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
     float* red = (float*)smem_raw;                 // [3 waves][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ng = (C + 255) >> 8;
+    const int Cp = (C + 3) & ~3;                   // partial rows are laid out [2][Cp] so that float4 accesses stay aligned
     float dg[MAXG][4], db[MAXG][4], ga[MAXG][4];
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) {
@@ -151,19 +152,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
     if (part == nullptr) return;
     // cross-wave reduction of dgamma/dbeta: waves 1..3 publish, wave 0 sums (fixed order -> deterministic)
     if (wave > 0) {
-        float* mine = red + (size_t)(wave - 1) * 2 * C;
+        float* mine = red + (size_t)(wave - 1) * 2 * Cp;
 #pragma unroll
         for (int g = 0; g < MAXG; ++g) {
             const int c = (g * 64 + lane) * 4;
             if (g < ng && c < C) {
                 *(float4*)(mine + c) = make_float4(dg[g][0], dg[g][1], dg[g][2], dg[g][3]);
-                *(float4*)(mine + C + c) = make_float4(db[g][0], db[g][1], db[g][2], db[g][3]);
+                *(float4*)(mine + Cp + c) = make_float4(db[g][0], db[g][1], db[g][2], db[g][3]);
             }
         }
     }
     __syncthreads();
     if (wave == 0) {
-        float* outp = part + (size_t)blockIdx.x * 2 * C;
+        float* outp = part + (size_t)blockIdx.x * 2 * Cp;
 #pragma unroll
         for (int g = 0; g < MAXG; ++g) {
             const int c = (g * 64 + lane) * 4;
@@ -171,13 +172,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
                 float a[4] = {dg[g][0], dg[g][1], dg[g][2], dg[g][3]};
                 float b[4] = {db[g][0], db[g][1], db[g][2], db[g][3]};
                 for (int w = 0; w < 3; ++w) {
-                    const float4 t = *(const float4*)(red + (size_t)w * 2 * C + c);
-                    const float4 u = *(const float4*)(red + (size_t)w * 2 * C + C + c);
+                    const float4 t = *(const float4*)(red + (size_t)w * 2 * Cp + c);
+                    const float4 u = *(const float4*)(red + (size_t)w * 2 * Cp + Cp + c);
                     a[0] += t.x; a[1] += t.y; a[2] += t.z; a[3] += t.w;
                     b[0] += u.x; b[1] += u.y; b[2] += u.z; b[3] += u.w;
                 }
                 *(float4*)(outp + c) = make_float4(a[0], a[1], a[2], a[3]);
-                *(float4*)(outp + C + c) = make_float4(b[0], b[1], b[2], b[3]);
+                *(float4*)(outp + Cp + c) = make_float4(b[0], b[1], b[2], b[3]);
             }
         }
     }
@@ -189,15 +190,17 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
                                                               float* __restrict__ dbeta, int accumulate) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int Cp = (C + 3) & ~3;
+    const int c = blockIdx.x * 64 + lane;            // index into a [2][Cp] partial row
+    const bool live = c < 2 * Cp && (c < Cp ? c : c - Cp) < C;
     float s = 0.f;
-    if (c < 2 * C)
-        for (int p = w; p < nparts; p += 4) s += part[(size_t)p * 2 * C + c];
+    if (live)
+        for (int p = w; p < nparts; p += 4) s += part[(size_t)p * 2 * Cp + c];
     red[w][lane] = s;
     __syncthreads();
-    if (w == 0 && c < 2 * C) {
+    if (w == 0 && live) {
         s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-        float* dst = c < C ? dgamma + c : dbeta + (c - C);
+        float* dst = c < Cp ? dgamma + c : dbeta + (c - Cp);
         *dst = accumulate ? *dst + s : s;
     }
 }
@@ -264,7 +267,7 @@ extern "C" int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const floa
 // dgamma/dbeta may be null (frozen LN); otherwise `workspace` must hold cs_layernorm_bwd_workspace(M,C) bytes.
 extern "C" size_t cs_layernorm_bwd_workspace(int M, int C) {
     const int nwg = min(512, (M + 3) / 4);
-    return (size_t)nwg * 2 * C * sizeof(float);
+    return (size_t)nwg * 2 * ((C + 3) & ~3) * sizeof(float);
 }
 extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
                                 const float* rstd, void* dx, int dx_mode, long lddx, float* dgamma, float* dbeta,
@@ -276,7 +279,7 @@ extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_
     CS_CHECK_ARG(dgamma == nullptr || workspace != nullptr, "cs_layernorm_bwd: workspace required for dgamma/dbeta");
     const int nwg = min(512, (M + 3) / 4);
     float* part = dgamma ? (float*)workspace : nullptr;
-    const size_t lds = (size_t)3 * 2 * C * sizeof(float);
+    const size_t lds = (size_t)3 * 2 * ((C + 3) & ~3) * sizeof(float);
     dim3 grid(nwg), block(256);
 #define LNB3(TX, MODE, NG)                                                                                                  \
     do {                                                                                                                    \
@@ -294,7 +297,7 @@ extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_
 #undef LNB3
     CS_LAUNCH_CHECK();
     if (dgamma) {
-        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, stream, part, nwg, C, dgamma, dbeta, accumulate_params);
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * ((C + 3) & ~3) + 63) / 64), dim3(256), 0, stream, part, nwg, C, dgamma, dbeta, accumulate_params);
         CS_LAUNCH_CHECK();
     }
     return 0;

@@ -207,3 +207,31 @@ def test_l14_shaped_tower_with_padded_storage_on_gpu(golden_dir):
     from clipself_amd.hip import HipOps
     from test_padded_dims_cpu import run_tiny14
     run_tiny14(HipOps, "cuda", golden_dir, _log)
+
+
+def test_eva02_l14_336_real_config():
+    """BASELINE configs[3] model (EVA02-CLIP-L-14-336: 24 layers, width 1024, hidden 2730 -> 2752 padded, patch 14, 577 tokens):
+    teacher / student forward against the CPU oracle on one image with two boxes, and a finite backward + AdamW step."""
+    from oracle import eva_ref
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.train import train_step
+    cfg = get_tower_cfg("EVA02-CLIP-L-14-336")
+    student, teacher = _pair(cfg, 0)
+    sd = seeded_visual_state(cfg, 0)
+    batch = synthetic_batch(1, 2, 336, 336, seed=21)
+    images, boxes, crops = batch
+    with torch.no_grad():
+        want_t = eva_ref.encode_image(sd, cfg, crops[0])
+        want_s = eva_ref.encode_pseudo_boxes(sd, cfg, images, [boxes[0][:, :4]])
+        got_t = teacher.encode_image(crops[0].cuda())
+        got_s = student.encode_pseudo_boxes(images.cuda(), [boxes[0][:, :4].cuda()])
+    _log(f"l14 teacher rel={rel(got_t, want_t):.3e} 1-cos={one_minus_cos(got_t, want_t):.2e}; roi rel={rel(got_s, want_s):.3e} 1-cos={one_minus_cos(got_s, want_s):.2e}")
+    assert rel(got_t, want_t) < 3e-2 and one_minus_cos(got_t, want_t) < 1e-3
+    assert rel(got_s, want_s) < 3e-2 and one_minus_cos(got_s, want_s) < 1e-3
+    opt = FlatAdamW(student, lr=1e-5, weight_decay=0.1)
+    out, bs, _ = train_step(student, CLIPSelf(), batch, opt, None, 0, teacher, _args(skip_scheduler=True))
+    assert torch.isfinite(out["loss"]).item()
+    g = student.visual.engine.grad
+    assert torch.isfinite(g).all().item() and float(g.abs().sum()) > 0
+    assert torch.isfinite(student.visual.engine.master).all().item()

@@ -17,7 +17,7 @@ from oracle.ops_ref import RefOps
 
 
 def rel(a, b):
-    a, b = torch.as_tensor(a).detach().double(), torch.as_tensor(b).detach().double()
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
