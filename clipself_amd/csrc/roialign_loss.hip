@@ -186,3 +186,72 @@ extern "C" int cs_cosine_loss_bwd(const float* student, const float* teacher, co
     CS_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- RegionCLIP federated BCE (src/training/region_clip.py:47-56) --------------------------------------------
+// z = logits * temp over the `ns` sampled noun columns; target = one-hot at tgt[k] (column index inside the sample,
+// -1 = none); row loss = sum_c [max(z,0) - z*t + log(1 + exp(-|z|))]; loss = weight * mean_k row loss.
+namespace {
+
+__global__ __launch_bounds__(256) void fed_bce_rows_kernel(const float* __restrict__ logits, long ldz, const int* __restrict__ tgt,
+                                                           float* __restrict__ rowloss, int K, int ns, float temp) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= K) return;
+    const int t = tgt[k];
+    float s = 0.f;
+    for (int c = lane; c < ns; c += 64) {
+        const float z = logits[(size_t)k * ldz + c] * temp;
+        s += fmaxf(z, 0.f) - (c == t ? z : 0.f) + log1pf(__expf(-fabsf(z)));
+    }
+    s = wave_sum(s);
+    if (lane == 0) rowloss[k] = s;
+}
+
+__global__ __launch_bounds__(256) void fed_bce_reduce_kernel(const float* __restrict__ rowloss, float* __restrict__ loss, int K, float weight) {
+    __shared__ float part[256];
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) s += rowloss[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = weight * part[0] / (float)K;
+}
+
+// dz[k,c] = coef * (sigmoid(z) - t) * temp  for c < ns, 0 for the padding columns [ns, ldd)   (bf16: dgrad GEMM operand)
+__global__ __launch_bounds__(256) void fed_bce_bwd_kernel(const float* __restrict__ logits, long ldz, const int* __restrict__ tgt,
+                                                          __bf16* __restrict__ dz, long ldd, int K, int ns, float temp, float coef,
+                                                          const float* __restrict__ upstream) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)K * ldd) return;
+    const int k = (int)(i / ldd), c = (int)(i - (long)k * ldd);
+    float v = 0.f;
+    if (c < ns) {
+        if (upstream) coef *= upstream[0];
+        const float z = logits[(size_t)k * ldz + c] * temp;
+        v = coef * temp * (1.f / (1.f + __expf(-z)) - (c == tgt[k] ? 1.f : 0.f));
+    }
+    dz[i] = f2bf(v);
+}
+
+}  // namespace
+
+extern "C" int cs_fed_bce_fwd(const float* logits, long ldz, const int* tgt, float* rowloss, float* loss, int K, int ns, float temp,
+                              float weight, hipStream_t stream) {
+    CS_CHECK_ARG(K > 0 && ns > 0 && ldz >= ns, "cs_fed_bce_fwd: bad shape");
+    hipLaunchKernelGGL(fed_bce_rows_kernel, dim3((K + 3) / 4), dim3(256), 0, stream, logits, ldz, tgt, rowloss, K, ns, temp);
+    CS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fed_bce_reduce_kernel, dim3(1), dim3(256), 0, stream, rowloss, loss, K, weight);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cs_fed_bce_bwd(const float* logits, long ldz, const int* tgt, void* dz_bf16, long ldd, int K, int ns, float temp,
+                              float weight, const float* upstream, hipStream_t stream) {
+    CS_CHECK_ARG(K > 0 && ns > 0 && ldz >= ns && ldd >= ns, "cs_fed_bce_bwd: bad shape");
+    hipLaunchKernelGGL(fed_bce_bwd_kernel, dim3((int)(((long)K * ldd + 255) / 256)), dim3(256), 0, stream, logits, ldz, tgt, (__bf16*)dz_bf16,
+                       ldd, K, ns, temp, weight / (float)K, upstream);
+    CS_LAUNCH_CHECK();
+    return 0;
+}

@@ -45,6 +45,8 @@ SIGNATURES = {
     "cs_roialign_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_cosine_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "cs_cosine_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
+    "cs_fed_bce_fwd": (_i, [_vp, _l, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
+    "cs_fed_bce_bwd": (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _f, _f, _vp, _vp]),
     "cs_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp]),
 }
 
@@ -238,6 +240,17 @@ class HipOps:
         K, E = student.shape
         self._ok(self.lib.cs_cosine_loss_bwd(_p(student), _p(teacher), _p(stats), _p(dstudent), K, E, weight, grad_scale,
                                              _p(upstream), self._stream()), "cs_cosine_loss_bwd")
+
+    def fed_bce_fwd(self, logits, tgt, rowloss, loss, ns, temp, weight):
+        self._chk(logits, tgt, rowloss, loss)
+        assert tgt.dtype == torch.int32
+        self._ok(self.lib.cs_fed_bce_fwd(_p(logits), logits.stride(0), _p(tgt), _p(rowloss), _p(loss), logits.shape[0], ns, temp, weight,
+                                         self._stream()), "cs_fed_bce_fwd")
+
+    def fed_bce_bwd(self, logits, tgt, dz, ns, temp, weight, upstream=None):
+        self._chk(logits, tgt, dz, upstream)
+        self._ok(self.lib.cs_fed_bce_bwd(_p(logits), logits.stride(0), _p(tgt), _p(dz), dz.stride(0), logits.shape[0], ns, temp, weight,
+                                         _p(upstream), self._stream()), "cs_fed_bce_bwd")
 
     def adamw_step(self, p, g, m, v, shadow, flags, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
         self._chk(p, g, m, v, shadow, flags)

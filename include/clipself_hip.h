@@ -84,6 +84,14 @@ int cs_cosine_loss_fwd(const float* student, const float* teacher, float* stats,
 int cs_cosine_loss_bwd(const float* student, const float* teacher, const float* stats, float* dstudent, int K, int E,
                        float weight, float grad_scale, const float* upstream, cs_stream_t stream);
 
+/* --- RegionCLIP federated BCE over the sampled noun columns: src/training/region_clip.py:47-56
+ *     (F.binary_cross_entropy_with_logits(...).sum(-1).mean() on logits * temp; one-hot target at tgt[k], -1 = none).
+ * bwd writes d(logits) as bf16 [K, ldd] with zeroed padding columns (operand of the d(features) GEMM). */
+int cs_fed_bce_fwd(const float* logits, long ldz, const int* tgt, float* rowloss, float* loss, int K, int ns, float temp,
+                   float weight, cs_stream_t stream);
+int cs_fed_bce_bwd(const float* logits, long ldz, const int* tgt, void* dz_bf16, long ldd, int K, int ns, float temp,
+                   float weight, const float* upstream, cs_stream_t stream);
+
 /* --- optimizer: torch.optim.AdamW built at src/training/main.py:198-213, stepped at src/training/train.py:115.
  * Flat fp32 master/grad/moment buffers; flags[n/64]: bit0 = tensor has a gradient this step, bit1 = weight decay applies. */
 int cs_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, const uint8_t* flags, long n, float lr,

@@ -173,6 +173,43 @@ def gen_tiny14(oc):
     print("tiny14 losses", out["losses"])
 
 
+def regionclip_inputs(cfg, n_nouns=150, batch=5, boxes=24, seed=31):
+    """Seeded RegionCLIP batch: (images, boxes [B,k,6] = xyxy, label, valid) with >= 100 distinct labels so that the
+    federated column set is deterministic (no multinomial draw), and a seeded noun-embedding bank."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    images, nb, _ = synthetic_batch(batch, boxes, cfg.image_size, cfg.image_size, seed=seed)
+    labels = torch.from_numpy(g.permutation(n_nouns)[: batch * boxes].astype(np.float32)).reshape(batch, boxes, 1)
+    bx = torch.cat([nb[..., :4], labels, nb[..., 4:5]], dim=-1)
+    bx[0, 3, -1] = 0.0                                   # one invalid box
+    nouns = torch.from_numpy(g.standard_normal((n_nouns, cfg.embed_dim)).astype(np.float32))
+    return images, bx, nouns
+
+
+def gen_regionclip(oc):
+    """RegionCLIP.__call__ (src/training/region_clip.py:28-67) on the tiny tower."""
+    import tempfile
+    from training.region_clip import RegionCLIP
+    cfg = _register_tiny(oc)
+    student = _build(oc, cfg, 4)
+    student.lock_image_tower(unlocked_groups=cfg.layers)
+    student.train()
+    images, bx, nouns = regionclip_inputs(cfg)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "nouns.npy")
+        np.save(path, nouns.numpy())
+        method = RegionCLIP(SimpleNamespace(train_embed_path=path))
+    args = SimpleNamespace(extract_type="v2", contrast_weight=1.0)
+    losses, bs, temp = method((images, bx), student, None, None, "cpu", None, False, args)
+    total = sum(losses.values())
+    total.backward()
+    blob = {"loss": np.float64(total.detach()), "temp": np.float64(temp), "bs": np.int64(bs)}
+    for n in ("visual.blocks.0.norm1.weight", "visual.blocks.1.mlp.w3.weight", "visual.blocks.0.attn.q_proj.weight",
+              "visual.blocks.1.attn.v_bias"):
+        blob["grad/" + n] = dict(student.named_parameters())[n].grad.numpy()
+    np.savez_compressed(GOLD / "tiny_regionclip.npz", **blob)
+    print("regionclip loss", float(total))
+
+
 def gen_b16(oc):
     cfg = get_tower_cfg("EVA02-CLIP-B-16")
     rec = B16
@@ -213,8 +250,12 @@ def main():
     if "--tiny14-only" in sys.argv:
         gen_tiny14(oc)
         return
+    if "--regionclip-only" in sys.argv:
+        gen_regionclip(oc)
+        return
     gen_tiny(oc)
     gen_tiny14(oc)
+    gen_regionclip(oc)
     if "--tiny-only" not in sys.argv:
         gen_b16(oc)
 

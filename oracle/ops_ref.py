@@ -235,6 +235,25 @@ class RefOps:
         cos, i_s, i_t = stats[:, 0:1], stats[:, 1:2], stats[:, 2:3]
         dstudent.copy_((-weight * grad_scale / K) * (teacher * i_t - cos * student * i_s) * i_s)
 
+    def fed_bce_fwd(self, logits, tgt, rowloss, loss, ns, temp, weight):
+        z = logits[:, :ns] * temp
+        t = torch.zeros_like(z)
+        rows = torch.nonzero(tgt >= 0)[:, 0]
+        t[rows, tgt[rows].long()] = 1.0
+        rl = F.binary_cross_entropy_with_logits(z, t, reduction="none").sum(-1)
+        rowloss.copy_(rl)
+        loss[0] = weight * rl.mean()
+
+    def fed_bce_bwd(self, logits, tgt, dz, ns, temp, weight, upstream=None):
+        K = logits.shape[0]
+        z = logits[:, :ns] * temp
+        t = torch.zeros_like(z)
+        rows = torch.nonzero(tgt >= 0)[:, 0]
+        t[rows, tgt[rows].long()] = 1.0
+        coef = weight / K * (float(upstream.reshape(-1)[0]) if upstream is not None else 1.0)
+        dz.zero_()
+        dz[:, :ns] = (coef * temp * (torch.sigmoid(z) - t)).to(torch.bfloat16)
+
     def adamw_step(self, p, g, m, v, shadow, flags, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
         act = (flags & 1).bool().repeat_interleave(64)
         dec = (flags & 2).bool().repeat_interleave(64)

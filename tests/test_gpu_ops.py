@@ -350,3 +350,21 @@ def test_adamw_matches_torch(hip, ref):
     check("adamw.p", pd, want, 1e-6)
     act = (flags & 1).bool().repeat_interleave(64)
     assert torch.equal(sh.cpu()[act], pd.cpu().to(BF)[act]) and float(sh.cpu()[~act].abs().max()) == 0.0
+
+
+def test_fed_bce(hip, ref):
+    K, ns, ld = 77, 100, 128
+    logits = rnd((K, ld), F32, 3.0, seed=80)
+    tgt = torch.randint(-1, ns, (K,), generator=torch.Generator().manual_seed(81)).to(torch.int32)
+    up = torch.tensor([0.7])
+    rl_r, l_r, dz_r = torch.empty(K), torch.empty(1), torch.empty(K, ld, dtype=BF)
+    ref.fed_bce_fwd(logits, tgt, rl_r, l_r, ns, 14.3, 1.0)
+    ref.fed_bce_bwd(logits, tgt, dz_r, ns, 14.3, 1.0, up)
+    rl_d, l_d = torch.empty(K, device="cuda"), torch.empty(1, device="cuda")
+    dz_d = torch.full((K, ld), float("nan"), dtype=BF, device="cuda")
+    hip.fed_bce_fwd(logits.cuda(), tgt.cuda(), rl_d, l_d, ns, 14.3, 1.0)
+    hip.fed_bce_bwd(logits.cuda(), tgt.cuda(), dz_d, ns, 14.3, 1.0, up.cuda())
+    check("fed_bce.rowloss", rl_d, rl_r, 1e-5)
+    check("fed_bce.loss", l_d, l_r, 1e-5)
+    check("fed_bce.dz", dz_d, dz_r, TOL_BF)
+    assert float(dz_d[:, ns:].abs().max()) == 0.0

@@ -235,3 +235,11 @@ def test_eva02_l14_336_real_config():
     g = student.visual.engine.grad
     assert torch.isfinite(g).all().item() and float(g.abs().sum()) > 0
     assert torch.isfinite(student.visual.engine.master).all().item()
+
+
+def test_regionclip_method_on_gpu(golden_dir):
+    """BASELINE configs[4] method (RegionCLIP: federated BCE against a noun bank) through the HIP kernels, against the golden
+    captured from the reference's own RegionCLIP.__call__."""
+    from clipself_amd.hip import HipOps
+    from test_regionclip_cpu import run_regionclip
+    run_regionclip(HipOps, "cuda", golden_dir)
