@@ -20,9 +20,14 @@ class _SyntheticLoader:
         self.device, self.rank, self.seed, self.valid_prob, self.resident = device, rank, seed, valid_prob, resident
         self.epoch = 0
         self._cache = None
+        self.region_clip = False
 
     def _make(self, i):
         b = synthetic_batch(*self.args, seed=self.seed + 1000 * self.epoch + i, rank=self.rank * 7919, valid_prob=self.valid_prob)
+        if self.region_clip:                      # COCORegionCLIPDataset contract (data.py:390-459): (images, boxes[B,k,6] = xyxy,label,valid)
+            g = torch.Generator().manual_seed(self.seed + i)
+            labels = torch.randint(0, 4764, (*b[1].shape[:2], 1), generator=g).float()
+            return b[0].to(self.device), torch.cat([b[1][..., :4], labels, b[1][..., 4:5]], dim=-1).to(self.device)
         return tuple(t.to(self.device) for t in b)
 
     def __len__(self):
@@ -55,4 +60,5 @@ def get_data(args, preprocess_fns=None, epoch=0, tokenizer=None):
     loader = _SyntheticLoader(args.synthetic_steps, args.batch_size, args.max_boxes, size, args.input_size,
                               args.device, args.rank, args.world_size, seed=1234 + args.seed,
                               valid_prob=0.7 if args.dataset_type == "proposals_distill" else 1.0, resident=False)
+    loader.region_clip = args.dataset_type == "region_clip"
     return {"train": DataInfo(loader)}

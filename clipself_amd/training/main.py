@@ -81,8 +81,18 @@ def main(argv):
         dist_model = create_model(args.model, args.pretrained, device=device, precision=args.precision,
                                   cache_dir=args.cache_dir, trainable=False)
         dist_model.visual.teacher_chunk = args.teacher_chunk
+    elif args.dataset_type == "region_clip":
+        from .region_clip import RegionCLIP
+        nouns = None
+        if not (args.train_embed_path and os.path.exists(args.train_embed_path)):
+            # the reference's noun-embedding files are not shipped (.MISSING_LARGE_BLOBS): seeded unit vectors stand in
+            g = torch.Generator().manual_seed(4764)
+            nouns = torch.randn(4764, model.embed_dim, generator=g)
+            logging.info("region_clip: --train-embed-path not found, using a seeded synthetic noun bank [4764, E]")
+        method = RegionCLIP(args, noun_embeddings=nouns).to(device)
+        dist_model = None                                       # main.py:145-147: no teacher for RegionCLIP
     else:
-        raise NotImplementedError(f"--dataset-type {args.dataset_type}: RegionCLIP is a later row of the hot-path plan (SURVEY.md §8 N4)")
+        raise NotImplementedError(args.dataset_type)
     random_seed(args.seed, args.rank)
     if args.lock_image:
         model.lock_image_tower(unlocked_groups=args.lock_image_unlocked_groups, freeze_bn_stats=args.lock_image_freeze_bn_stats)
@@ -95,7 +105,7 @@ def main(argv):
                 f.write(f"{name}: {getattr(args, name)}\n")
     if args.distributed:
         model = StudentDataParallel(model)
-        dist_model = FrozenDataParallel(dist_model)
+        dist_model = FrozenDataParallel(dist_model) if dist_model is not None else None
 
     optimizer = build_optimizer(model, args) if args.train_data else None
     start_epoch = 0
@@ -127,7 +137,13 @@ def main(argv):
         completed_epoch = epoch + 1
         student_sd = (model.module if args.distributed else model).state_dict()
         if args.alpha < 1.0:
-            teacher_sd = (dist_model.module if args.distributed else dist_model).state_dict()
+            if dist_model is None:                              # main.py:285-293: re-create the pretrained model for the ensemble
+                ref_model = create_model(args.model, args.pretrained, device=device, precision=args.precision,
+                                         cache_dir=args.cache_dir, trainable=False)
+                teacher_sd = ref_model.state_dict()
+                del ref_model
+            else:
+                teacher_sd = (dist_model.module if args.distributed else dist_model).state_dict()
             target_sd = student_teacher_ensemble(student_sd, teacher_sd, args.alpha)
         else:
             target_sd = student_sd
