@@ -126,14 +126,31 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
     const int l31 = lane & 31;
     float* slab = (float*)(smem + wave * EP_BYTES);
     const int rrow = lane >> 4, rcol = (lane & 15) * 4;  // read-out: 16 lanes per row, 4 consecutive columns per lane
+    const int col = n0 + wn * 64 + rcol;                 // non-SwiGLU epilogues
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+        const int row_base = row0 + i * 32;
+        // All residual / pos-embed reads of the 32-row block are issued before the accumulators go through the slab (clamped
+        // rows instead of predicates): a load->add->store chain per row would serialise 8 memory round trips per block
+        // (vmcnt also counts the previous store), and here their latency hides behind the LDS transposition.
+        float4 xin[8];
+        if ((EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) && col < p.N) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = min(row_base + rrow + it * 4, p.M - 1);
+                if (EPI == EPI_RESID_F32) {
+                    xin[it] = *(const float4*)(p.extra + (size_t)row * p.ldc + col);
+                } else {
+                    const int img = row / p.group, t = row - img * p.group;
+                    xin[it] = *(const float4*)(p.extra + (size_t)(t + 1) * p.ldc + col);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) slab[mfma32_row(e, lane) * EP_LD + j * 32 + l31] = acc[i][j][e];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int row_base = row0 + i * 32;
         if (EPI == EPI_SWIGLU_BF16) {
             // slab columns [0,32) = x1, [32,64) = x2 of hidden units hcol .. ; 8 lanes per row, 4 hidden units per lane
             const int hr = lane >> 3, hc = (lane & 7) * 4;
@@ -159,14 +176,14 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                 }
             }
         } else {
-            const int col = n0 + wn * 64 + rcol;
             if (col < p.N) {
                 float bv[4] = {0, 0, 0, 0};
                 if (p.bias) { const float4 t = *(const float4*)(p.bias + col); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
+                const bool full = row_base + 32 <= p.M;              // wave-uniform
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int rl = rrow + it * 4, row = row_base + rl;
-                    if (row >= p.M) continue;
+                    if (!full && row >= p.M) continue;
                     const float4 s = *(const float4*)(slab + rl * EP_LD + rcol);
                     float v[4] = {s.x + bv[0], s.y + bv[1], s.z + bv[2], s.w + bv[3]};
                     if (EPI == EPI_BF16) {
@@ -177,16 +194,15 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                     } else if (EPI == EPI_F32) {
                         *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                     } else if (EPI == EPI_RESID_F32) {
-                        const size_t o = (size_t)row * p.ldc + col;
-                        const float4 x = *(const float4*)(p.extra + o);
-                        *(float4*)((float*)p.C + o) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
+                        const float4 x = xin[it];
+                        *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
                     } else if (EPI == EPI_ATOMIC_F32) {
                         float* d = (float*)p.C + (size_t)row * p.ldc + col;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) unsafeAtomicAdd(d + t, v[t]);
                     } else if (EPI == EPI_PATCH_F32) {
-                        const int img = row / p.group, t = row - img * p.group;
-                        const float4 x = *(const float4*)(p.extra + (size_t)(t + 1) * p.ldc + col);
+                        const int img = row / p.group;
+                        const float4 x = xin[it];
                         *(float4*)((float*)p.C + (size_t)(row + img + 1) * p.ldc + col) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
                     }
                 }

@@ -243,3 +243,31 @@ def test_regionclip_method_on_gpu(golden_dir):
     from clipself_amd.hip import HipOps
     from test_regionclip_cpu import run_regionclip
     run_regionclip(HipOps, "cuda", golden_dir)
+
+
+def test_training_main_entrypoint_end_to_end(tmp_path):
+    """`python -m clipself_amd.training.main` with the reference's flags (scripts/train_clipself_coco_image_patches_eva_vitb16.sh shape,
+    synthetic data): trains 3 steps, writes the alpha-ensembled checkpoint {epoch,name,state_dict,optimizer}; the checkpoint
+    loads back through create_model(cache_dir=...) and resumes."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    base = [sys.executable, "-m", "clipself_amd.training.main", "--model", "EVA02-CLIP-B-16", "--pretrained", "eva", "--train-data", "synthetic",
+            "--dataset-type", "grid_distill", "--batch-size", "4", "--max-boxes", "4", "--det-image-size", "224", "--synthetic-steps", "3",
+            "--epochs", "1", "--lock-image", "--lock-image-unlocked-groups", "12", "--alpha", "0.7", "--lr", "1e-5", "--wd", "0.1",
+            "--warmup", "10", "--log-every-n-steps", "1", "--logs", str(tmp_path), "--cache-dir", "none.pt"]
+    r = subprocess.run(base + ["--name", "run1"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Train Epoch: 0" in r.stderr and "Loss_cosine" in r.stderr
+    ckpt = tmp_path / "run1" / "checkpoints" / "epoch_1.pt"
+    blob = torch.load(ckpt, map_location="cpu", weights_only=False)
+    assert set(blob) == {"epoch", "name", "state_dict", "optimizer"} and blob["epoch"] == 1
+    assert "visual.blocks.11.mlp.w3.weight" in blob["state_dict"] and "text.token_embedding.weight" in blob["state_dict"]
+    assert len(blob["optimizer"]["param_groups"]) == 2 and len(blob["optimizer"]["state"]) == 249
+    from clipself_amd.open_clip import create_model
+    m = create_model("EVA02-CLIP-B-16", "eva", cache_dir=str(ckpt), trainable=False)
+    assert rel(m.state_dict()["visual.blocks.3.attn.proj.weight"], blob["state_dict"]["visual.blocks.3.attn.proj.weight"]) == 0.0
+    r2 = subprocess.run(base + ["--name", "run2", "--resume", str(ckpt), "--epochs", "2"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "resuming checkpoint" in r2.stderr and "Start epoch 1" in r2.stderr
