@@ -33,13 +33,15 @@ BATCH, CROPS, SIZE = 64, 32, 224
 PEAK_BF16_TFLOPS = 2500.0
 
 
-def flops_per_image(cfg, k):
-    """2*MACs of the matmuls only."""
+def flops_per_image(cfg, k, cls_only=True):
+    """2*MACs of the matmuls the step executes."""
     N, C, Hd, E, L, p = cfg.tokens, cfg.width, cfg.hidden, cfg.embed_dim, cfg.layers, cfg.patch_size
     pe = 2 * (N - 1) * (3 * p * p) * C
     blk = 2 * N * C * C * 4 + 4 * N * N * C + 6 * N * C * Hd
     blk_na = 4 * N * C * C + 6 * N * C * Hd
-    T = pe + L * blk + 2 * C * E
+    # teacher: the last block serves the CLS query only (k/v projections over all tokens, everything else on one row)
+    blk_cls = 4 * N * C * C + 2 * C * C * 2 + 4 * N * C + 6 * C * Hd
+    T = pe + (L - 1) * blk + (blk_cls if cls_only else blk) + 2 * C * E
     Sf = pe + (L - 1) * blk + blk_na + 2 * (N - 1) * C * E
     Sb = 2 * ((L - 1) * blk + blk_na) + 2 * (N - 1) * C * E
     return k * T + Sf + Sb
@@ -48,14 +50,14 @@ def flops_per_image(cfg, k):
 class KernelTimer:
     """HIP-event timing of one kernel class on its launch stream (our launches go to torch's current stream)."""
 
-    def __init__(self, ops, epi, max_events=4096):
-        self.ops, self.epi, self.on, self.pairs, self.flops = ops, epi, False, [], 0.0
+    def __init__(self, ops, epi, min_rows=0, max_events=4096):
+        self.ops, self.epi, self.min_rows, self.on, self.pairs, self.flops = ops, epi, min_rows, False, [], 0.0
         self._inner = ops.gemm_nt
         self._pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max_events)]
         ops.gemm_nt = self._wrapped
 
     def _wrapped(self, A, B, C, bias=None, extra=None, epi=0, splits=1, group=0, flags=0):
-        if self.on and epi == self.epi and len(self.pairs) < len(self._pool):
+        if self.on and epi == self.epi and A.shape[0] >= self.min_rows and len(self.pairs) < len(self._pool):
             e0, e1 = self._pool[len(self.pairs)]
             e0.record()
             self._inner(A, B, C, bias, extra, epi, splits, group, flags)
@@ -120,6 +122,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--teacher-chunk", type=int, default=512)
+    ap.add_argument("--full-last-block", action="store_true",
+                    help="run the teacher's last block over every token instead of the CLS query only (same outputs, more work)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
@@ -146,6 +150,7 @@ def main():
     student = create_model(MODEL, "eva", precision="amp_bf16", device=device, cache_dir=None)
     teacher = create_model(MODEL, "eva", precision="amp_bf16", device=device, cache_dir=None, trainable=False)
     teacher.visual.teacher_chunk = a.teacher_chunk
+    teacher.visual.engine.cls_only_last_block = not a.full_last_block
     cfg = student.visual.cfg
     student.lock_image_tower(unlocked_groups=cfg.layers)
     student.train()
@@ -159,7 +164,8 @@ def main():
                            multiscale=False, extract_type="v2", cosine_weight=1.0)
     batch = tuple(t.to(device) for t in synthetic_batch(BATCH, CROPS, SIZE, SIZE, seed=1234, rank=rank))
     method = CLIPSelf()
-    timer = KernelTimer(teacher.visual.engine.ops, epi=3)     # the fused SwiGLU GEMM is launched by the teacher's engine
+    # the fused SwiGLU GEMM is launched by the teacher's engine; the full-token launches (M = chunk*197) are the dominant kernel
+    timer = KernelTimer(teacher.visual.engine.ops, epi=3, min_rows=min(a.teacher_chunk, BATCH * CROPS) * cfg.tokens)
 
     def sync():
         if distributed:
@@ -188,7 +194,7 @@ def main():
 
     if rank == 0:
         ips = world * BATCH * a.steps / elapsed
-        F = flops_per_image(cfg, CROPS)
+        F = flops_per_image(cfg, CROPS, cls_only=not a.full_last_block)
         kt = timer.result()
         out = {
             "metric": "images/sec (student+teacher distill step), ViT-B/16 32 crops/img",
@@ -197,7 +203,8 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{MODEL} CLIPSelf image-patches step, {BATCH} images x {CROPS} crops per GPU, {SIZE}^2 (BASELINE configs[1])",
                        "global_batch": BATCH * world, "crops_per_image": CROPS, "image_size": SIZE,
-                       "parallelism": f"dp{world}", "teacher_chunk": a.teacher_chunk, "loss_last_step": loss},
+                       "parallelism": f"dp{world}", "teacher_chunk": a.teacher_chunk,
+                       "teacher_last_block": "full" if a.full_last_block else "cls_query_only", "loss_last_step": loss},
             "step_tflops": F * ips / 1e12, "step_mfma_frac": F * ips / 1e12 / (PEAK_BF16_TFLOPS * world),
         }
         if kt:

@@ -569,6 +569,80 @@ int check_common(const char* who, int B, int Ntok, int H, int ldqkv, int ldo) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ CLS-query attention
+// One workgroup per (crop, head): the CLS query against all keys.  Used by the frozen teacher's last block, whose
+// output is consumed at the CLS row only (eva_vit_model.py:505-519 returns x[:, 0]).  HBM-bound: K and V are read once.
+// Arithmetic mirrors attn_fwd_kernel: keys 1.. rotated and rounded to bf16, fp32 scores, exp2(s - max) rounded to bf16
+// for the P.V product, fp32 row sum of the unrounded exponentials.
+__global__ __launch_bounds__(256) void attn_cls_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ kv,
+                                                       const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                       __bf16* __restrict__ out, int Ntok, int H, int ldq, int ldkv, int ldo, float scale) {
+    extern __shared__ float sm[];                 // [Npad] scores -> probabilities | [32][64] partial outputs | [8] reductions
+    const int Npad = (Ntok + 3) & ~3;
+    float* part = sm + Npad;
+    float* red = part + 32 * HD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const __bf16* kbase = kv + (size_t)b * Ntok * ldkv + h * HD;
+    const __bf16* vbase = kbase + H * HD;
+    float qf[HD];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        U128 t;
+        t.u = *(const uint4*)(q + (size_t)b * ldq + h * HD + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[c * 8 + j] = bf2f(t.e[j]);
+    }
+    const float sl2 = scale * LOG2E;
+    float mx = -INFINITY;
+    for (int key = tid; key < Ntok; key += 256) {
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            U128 kk;
+            kk.u = *(const uint4*)(kbase + (size_t)key * ldkv + c * 8);
+            if (key > 0) rope8(kk, cos_t + (size_t)(key - 1) * HD + c * 8, sin_t + (size_t)(key - 1) * HD + c * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += qf[c * 8 + j] * bf2f(kk.e[j]);
+        }
+        const float s = dot * sl2;
+        sm[key] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int key = tid; key < Ntok; key += 256) {
+        const float e = __builtin_amdgcn_exp2f(sm[key] - mx);
+        sum += e;
+        sm[key] = bf2f(f2bf(e));
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = red[4] + red[5] + red[6] + red[7];
+    const int c = tid & 7, kg = tid >> 3;         // 8 lanes cover one 128-byte V row; 32 key groups
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int key = kg; key < Ntok; key += 32) {
+        U128 vv;
+        vv.u = *(const uint4*)(vbase + (size_t)key * ldkv + c * 8);
+        const float pk = sm[key];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += pk * bf2f(vv.e[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[kg * HD + c * 8 + j] = acc[j];
+    __syncthreads();
+    if (tid < HD) {
+        float o = 0.f;
+#pragma unroll 8
+        for (int g = 0; g < 32; ++g) o += part[g * HD + tid];
+        out[(size_t)b * ldo + h * HD + tid] = f2bf(o / sum);
+    }
+}
+
 }  // namespace
 
 // C ABI ------------------------------------------------------------------------------------------
@@ -620,6 +694,23 @@ extern "C" int cs_attn_bwd(const void* qkv, const void* o, const void* dout, con
     hipLaunchKernelGGL((attn_bwd_dq_kernel<CH>), grid, block, lds_dq, stream, a);
     CS_LAUNCH_CHECK();
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<CH>), grid, block, lds_dkv, stream, a);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+
+// q [B, ldq] bf16: the CLS-token queries (H*64 wide, bias added; token 0 is never rotated); kv [B*N, ldkv] bf16 = k|v
+// (un-rotated, bias added); out [B, ldo] bf16 = the CLS row of softmax(q k^T * scale) v.
+extern "C" int cs_attn_cls_fwd(const void* q, const void* kv, const float* cos_t, const float* sin_t, void* out, int B, int Ntok, int H,
+                               int ldq, int ldkv, int ldo, float scale, hipStream_t stream) {
+    CS_CHECK_ARG(q && kv && cos_t && sin_t && out, "cs_attn_cls_fwd: null pointer");
+    CS_CHECK_ARG(B > 0 && Ntok > 1 && H > 0, "cs_attn_cls_fwd: bad sizes B=%d Ntok=%d H=%d", B, Ntok, H);
+    CS_CHECK_ARG(ldq % 8 == 0 && ldkv % 8 == 0 && ldq >= H * HD && ldkv >= 2 * H * HD && ldo >= H * HD,
+                 "cs_attn_cls_fwd: row strides must be multiples of 8 and cover the heads (ldq=%d ldkv=%d ldo=%d)", ldq, ldkv, ldo);
+    CS_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0, "cs_attn_cls_fwd: q/kv must be 16-byte aligned");
+    const size_t lds = ((size_t)((Ntok + 3) & ~3) + 32 * HD + 8) * sizeof(float);
+    CS_CHECK_ARG(lds <= 64 * 1024, "cs_attn_cls_fwd: Ntok=%d too large", Ntok);
+    hipLaunchKernelGGL(attn_cls_kernel, dim3(B * H), dim3(256), lds, stream, (const __bf16*)q, (const __bf16*)kv, cos_t, sin_t,
+                       (__bf16*)out, Ntok, H, ldq, ldkv, ldo, scale);
     CS_LAUNCH_CHECK();
     return 0;
 }

@@ -121,6 +121,9 @@ class EvaEngine:
         self.first_trainable = cfg.layers      # no block trainable until lock()/unlock is applied
         self.grad_ready_hook = None            # callable(block_index) fired when a block's grads are complete
         self._ctx = None
+        # encode_image() consumes only the CLS row, so the last block runs its query/proj/MLP for that row alone (keys and
+        # values still span all tokens); False runs the last block over every token -- same outputs, ~1/L more work.
+        self.cls_only_last_block = True
         if trainable:
             self.grad = ops.zeros((self.numel,), F32)
             self.exp_avg = ops.zeros((self.numel,), F32)
@@ -302,6 +305,17 @@ class EvaEngine:
         else:
             att = ops.empty((M, C), BF16)      # v only: every token "attends" to itself (proj_without_attn)
             ops.gemm_nt(ln1, wqkv[2 * C:], att, bias=bqkv[2 * C:], epi=EPI_BF16)
+        x2 = self._block_post(b, x, att, M, st, save, inplace)
+        if keep:
+            save.update(x0=x, ln1=ln1, st1=(m1, r1), qkv=qkv, lse=lse, att=att, with_attn=with_attn)
+        return x2
+
+    def _block_post(self, b, x, att, M, st, save, inplace):
+        """Everything after the attention core: inner_attn_ln -> proj (+x) -> norm2 -> SwiGLU -> ffn_ln -> w3 (+x1)."""
+        ops, cfg = self.ops, self.cfg
+        C, Hd, Hl, eps = cfg.width, self.Hp, cfg.hidden, cfg.ln_eps
+        padded = Hd != Hl
+        keep = save is not None
         iln = ops.empty((M, C), BF16)
         m2, r2 = st()
         ops.layernorm_fwd(att, self.p[b + "attn.inner_attn_ln.weight"], self.p[b + "attn.inner_attn_ln.bias"], iln, m2, r2, eps)
@@ -327,9 +341,28 @@ class EvaEngine:
         ops.gemm_nt(fln, self.storage_of(self.shadow, b + "mlp.w3.weight"), x2, bias=self.p[b + "mlp.w3.bias"], extra=x1,
                     epi=EPI_RESID_F32)
         if keep:
-            save.update(x0=x, ln1=ln1, st1=(m1, r1), qkv=qkv, lse=lse, att=att, iln=iln, st2=(m2, r2), x1=x1, ln2=ln2,
-                        st3=(m3, r3), x12=x12, hid=hid, fln=fln, st4=(m4, r4), with_attn=with_attn)
+            save.update(iln=iln, st2=(m2, r2), x1=x1, ln2=ln2, st3=(m3, r3), x12=x12, hid=hid, fln=fln, st4=(m4, r4))
         return x2
+
+    def _block_fwd_cls(self, i, x, B, N, cos, sin):
+        """Last teacher block restricted to what encode_image() consumes: the CLS row.  x fp32 [B*N, C] -> fp32 [B, C].
+        forward_features() returns x[:, 0] after the final norm (eva_vit_model.py:505-519), so only the CLS *query* of the
+        last block is live; keys and values still come from every token.  Row-for-row the same arithmetic as _block_fwd."""
+        ops, cfg = self.ops, self.cfg
+        C, H, eps = cfg.width, cfg.heads, cfg.ln_eps
+        b = f"{self.prefix}blocks.{i}."
+        M = B * N
+        ln1 = ops.empty((M, C), BF16)
+        ops.layernorm_fwd(x, self.p[b + "norm1.weight"], self.p[b + "norm1.bias"], ln1, None, None, eps)
+        wqkv, bqkv = self._qkv_w(b)
+        kv = ops.empty((M, 2 * C), BF16)
+        ops.gemm_nt(ln1, wqkv[C:], kv, bias=bqkv[C:], epi=EPI_BF16)
+        q = ops.empty((B, C), BF16)
+        ops.gemm_nt(ln1.view(B, N, C)[:, 0, :], wqkv[:C], q, bias=bqkv[:C], epi=EPI_BF16)
+        att = ops.empty((B, C), BF16)
+        ops.attn_cls_fwd(q, kv, cos, sin, att, B, N, H, cfg.head_width ** -0.5)
+        xc = x.view(B, N, C)[:, 0, :].contiguous()
+        return self._block_post(b, xc, att, B, lambda: (None, None), None, True)
 
     # ------------------------------------------------------------------------------------------ teacher
     def encode_image(self, images, chunk: int = 256):
@@ -345,10 +378,12 @@ class EvaEngine:
             N = g * g + 1
             cos, sin = self.rope_tables(g)
             xf = x.view(B * N, cfg.width)
-            for i in range(cfg.layers):
+            last = cfg.layers - 1 if self.cls_only_last_block else cfg.layers
+            for i in range(last):
                 self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
+            xc = self._block_fwd_cls(last, xf, B, N, cos, sin) if last < cfg.layers else x[:, 0, :]
             cls = ops.empty((B, cfg.width), BF16)
-            ops.layernorm_fwd(x[:, 0, :], self.p[P + "norm.weight"], self.p[P + "norm.bias"], cls, None, None, cfg.ln_eps)
+            ops.layernorm_fwd(xc, self.p[P + "norm.weight"], self.p[P + "norm.bias"], cls, None, None, cfg.ln_eps)
             ops.gemm_nt(cls, self.w[P + "head.weight"], out[k0:k0 + B], bias=self.p[P + "head.bias"], epi=EPI_F32)
         return out
 

@@ -32,6 +32,7 @@ SIGNATURES = {
     "cs_l2norm_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "cs_l2norm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "cs_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "cs_attn_cls_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_attn_bwd_workspace": (_sz, [_i, _i, _i]),
     "cs_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_swiglu_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
@@ -168,6 +169,11 @@ class HipOps:
         self._chk(qkv, cos, sin, out, lse)
         self._ok(self.lib.cs_attn_fwd(_p(qkv), _p(cos), _p(sin), _p(out), _p(lse), B, Ntok, H, qkv.stride(0), out.stride(0),
                                       scale, self._stream()), "cs_attn_fwd")
+
+    def attn_cls_fwd(self, q, kv, cos, sin, out, B, Ntok, H, scale):
+        self._chk(q, kv, cos, sin, out)
+        self._ok(self.lib.cs_attn_cls_fwd(_p(q), _p(kv), _p(cos), _p(sin), _p(out), B, Ntok, H, q.stride(0), kv.stride(0),
+                                          out.stride(0), scale, self._stream()), "cs_attn_cls_fwd")
 
     def attn_bwd_workspace(self, B, Ntok, H) -> int:
         return int(self.lib.cs_attn_bwd_workspace(B, Ntok, H))

@@ -55,6 +55,11 @@ int cs_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, void* 
  * lse [B*H, Ntok] f32 (nullable in inference). */
 int cs_attn_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* out, float* lse, int B, int Ntok, int H,
                 int ldqkv, int ldo, float scale, cs_stream_t stream);
+/* CLS-query attention for the frozen teacher's last block: VisionTransformer.forward_features returns x[:, 0]
+ * (eva_vit_model.py:505-519), so only that query row of the last block is live.  q [B, ldq] bf16 (CLS queries, never rotated);
+ * kv [B*Ntok, ldkv] bf16 = k|v; out [B, ldo] bf16. */
+int cs_attn_cls_fwd(const void* q, const void* kv, const float* cos_t, const float* sin_t, void* out, int B, int Ntok, int H,
+                    int ldq, int ldkv, int ldo, float scale, cs_stream_t stream);
 size_t cs_attn_bwd_workspace(int B, int Ntok, int H);
 int cs_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* cos_t, const float* sin_t,
                 void* dqkv, void* workspace, int B, int Ntok, int H, int ldqkv, int ldo, float scale, cs_stream_t stream);

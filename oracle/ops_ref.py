@@ -149,6 +149,17 @@ class RefOps:
         if lse is not None:
             lse.copy_(l.reshape(B * H, Ntok))
 
+    def attn_cls_fwd(self, q, kv, cos, sin, out, B, Ntok, H, scale):
+        C = H * 64
+        qh = q[:, :C].float().reshape(B, 1, H, 64).permute(0, 2, 1, 3)                       # CLS query: never rotated
+        k = kv[:, :C].float().reshape(B, Ntok, H, 64).permute(0, 2, 1, 3)
+        v = kv[:, C:2 * C].float().reshape(B, Ntok, H, 64).permute(0, 2, 1, 3)
+        k = self._r(_rope_rows(k, cos, sin))
+        s = (qh @ k.transpose(-1, -2)) * scale
+        e = torch.exp(s - s.max(-1, keepdim=True).values)
+        o = (self._r(e) @ v) / e.sum(-1, keepdim=True)
+        out.copy_(o.permute(0, 2, 1, 3).reshape(B, C).to(torch.bfloat16))
+
     def attn_bwd_workspace(self, B, Ntok, H):
         return 4
 

@@ -63,6 +63,21 @@ def test_forward_matches_bf16_oracle_and_reference(gold):
     assert one_minus_cos(pooled, g["student_roi"]) < 2e-4
 
 
+def test_cls_only_last_teacher_block_is_the_same_function(gold):
+    """encode_image() runs the last block for the CLS query only (engine.cls_only_last_block); the full-token last block
+    must give the same embedding -- every skipped row is dead in forward_features() (eva_vit_model.py:505-519)."""
+    g, rec = gold
+    cfg = tiny_cfg()
+    _, _, crops = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"])
+    eng = _engine(cfg, rec["seed_w"], False)
+    assert eng.cls_only_last_block
+    fast = eng.encode_image(crops.flatten(0, 1), chunk=3)
+    eng.cls_only_last_block = False
+    full = eng.encode_image(crops.flatten(0, 1), chunk=3)
+    assert rel(fast, full) < 1e-6
+    assert rel(fast, g["teacher"]) < 2e-2
+
+
 def test_backward_chain_is_the_gradient(gold):
     g, rec = gold
     cfg = tiny_cfg()

@@ -230,6 +230,33 @@ def test_attention_fwd_bwd(hip, ref, B, Ntok, H, qscale):
     check(tag + ".dv", dq_d[:, 2 * C:], dq_r[:, 2 * C:], 1.5e-2)
 
 
+@pytest.mark.parametrize("B,Ntok,H,qscale", [(5, 197, 12, 1.0), (3, 17, 2, 3.0), (2, 577, 16, 2.0), (2, 785, 3, 4.0)])
+def test_attention_cls_query(hip, ref, B, Ntok, H, qscale):
+    """cs_attn_cls_fwd (teacher's last block: CLS query only) against the reference op and against the CLS rows of the
+    full attention kernel on the same q|k|v."""
+    C = H * 64
+    qkv = rnd((B * Ntok, 3 * C + 8), F32, 1.0, seed=33)       # padded row stride
+    qkv[:, :2 * C] *= qscale
+    qkv = qkv.to(BF)
+    cos, sin = _rope(Ntok, 0)
+    scale = 64 ** -0.5
+    q = qkv.view(B, Ntok, -1)[:, 0, :C].contiguous()
+    kv = qkv[:, C:3 * C]
+    o_r = torch.empty(B, C, dtype=BF)
+    ref.attn_cls_fwd(q, kv, cos, sin, o_r, B, Ntok, H, scale)
+    full_r = torch.empty(B * Ntok, C, dtype=BF)
+    ref.attn_fwd(qkv[:, :3 * C], cos, sin, full_r, None, B, Ntok, H, scale)
+    assert torch.equal(o_r, full_r.view(B, Ntok, C)[:, 0])     # the two reference ops agree exactly
+    qkv_d, cd, sd = both([qkv, cos, sin])
+    o_d = torch.full((B, C), float("nan"), dtype=BF, device="cuda")
+    hip.attn_cls_fwd(qkv_d.view(B, Ntok, -1)[:, 0, :C], qkv_d[:, C:3 * C], cd, sd, o_d, B, Ntok, H, scale)
+    tag = f"attn_cls[{B},{Ntok},{H},x{qscale}]"
+    check(tag + ".o", o_d, o_r, 6e-3)
+    full_d = torch.empty(B * Ntok, C, dtype=BF, device="cuda")
+    hip.attn_fwd(qkv_d[:, :3 * C], cd, sd, full_d, None, B, Ntok, H, scale)
+    check(tag + ".vs_full_kernel", o_d, full_d.view(B, Ntok, C)[:, 0], 4e-3)
+
+
 # ------------------------------------------------------------------------------------------------ elementwise
 def test_swiglu_cast_transpose_colsum_im2row(hip, ref):
     M, Hd = 333, 2048

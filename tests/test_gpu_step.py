@@ -174,6 +174,12 @@ def test_full_size_properties():
         t_b = teacher.encode_image(crops[:300])
         assert torch.equal(t_a, t_b)
         assert torch.isfinite(t_a).all()
+        # the CLS-only last block (default) and the full-token last block are the same function of the crops
+        teacher.visual.engine.cls_only_last_block = False
+        t_c = teacher.encode_image(crops[:300])
+        teacher.visual.engine.cls_only_last_block = True
+        _log(f"b16 teacher cls-only vs full last block: rel={rel(t_a, t_c):.3e} 1-cos={one_minus_cos(t_a, t_c):.2e}")
+        assert rel(t_a, t_c) < 2e-3 and one_minus_cos(t_a, t_c) < 1e-5
 
 
 def test_non_native_grid_multichunk_attention_matches_oracle():
