@@ -570,76 +570,98 @@ int check_common(const char* who, int B, int Ntok, int H, int ldqkv, int ldo) {
 }
 
 // ------------------------------------------------------------------------------------------------ CLS-query attention
-// One workgroup per (crop, head): the CLS query against all keys.  Used by the frozen teacher's last block, whose
-// output is consumed at the CLS row only (eva_vit_model.py:505-519 returns x[:, 0]).  HBM-bound: K and V are read once.
-// Arithmetic mirrors attn_fwd_kernel: keys 1.. rotated and rounded to bf16, fp32 scores, exp2(s - max) rounded to bf16
-// for the P.V product, fp32 row sum of the unrounded exponentials.
+// The CLS query against all keys, for the frozen teacher's last block, whose output is consumed at the CLS row only
+// (eva_vit_model.py:505-519 returns x[:, 0]).  HBM-bound: K and V are streamed once, fully coalesced.
+//   * one workgroup per (crop, group of HG heads); a key's 64 head-dim values are spread over 8 lanes (16 B each), so a wave
+//     reads 8 whole 128-byte key rows per instruction and the RoPE table entries of a (key, chunk) are loaded once and
+//     reused across the HG heads;
+//   * arithmetic mirrors attn_fwd_kernel: keys 1.. rotated and rounded to bf16, fp32 scores, exp2(s - max) rounded to
+//     bf16 for the P.V product, fp32 row sum of the unrounded exponentials.
+template <int HG>
 __global__ __launch_bounds__(256) void attn_cls_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ kv,
                                                        const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                        __bf16* __restrict__ out, int Ntok, int H, int ldq, int ldkv, int ldo, float scale) {
-    extern __shared__ float sm[];                 // [Npad] scores -> probabilities | [32][64] partial outputs | [8] reductions
+    extern __shared__ float sm[];                 // [HG][Npad] scores -> probabilities | [HG] row sums | [32][HG*64] partial outputs
     const int Npad = (Ntok + 3) & ~3;
-    float* part = sm + Npad;
-    float* red = part + 32 * HD;
+    float* rsum = sm + HG * Npad;
+    float* part = rsum + 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-    const __bf16* kbase = kv + (size_t)b * Ntok * ldkv + h * HD;
+    const int b = blockIdx.x, h0 = blockIdx.y * HG;
+    const int c = tid & 7, kg = tid >> 3;         // 16-byte chunk of the head dim; key slot (32 per pass)
+    const __bf16* kbase = kv + (size_t)b * Ntok * ldkv + h0 * HD + c * 8;
     const __bf16* vbase = kbase + H * HD;
-    float qf[HD];
+    float qf[HG][8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int h = 0; h < HG; ++h) {
         U128 t;
-        t.u = *(const uint4*)(q + (size_t)b * ldq + h * HD + c * 8);
+        t.u = *(const uint4*)(q + (size_t)b * ldq + (h0 + h) * HD + c * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[c * 8 + j] = bf2f(t.e[j]);
+        for (int j = 0; j < 8; ++j) qf[h][j] = bf2f(t.e[j]);
     }
     const float sl2 = scale * LOG2E;
-    float mx = -INFINITY;
-    for (int key = tid; key < Ntok; key += 256) {
-        float dot = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            U128 kk;
-            kk.u = *(const uint4*)(kbase + (size_t)key * ldkv + c * 8);
-            if (key > 0) rope8(kk, cos_t + (size_t)(key - 1) * HD + c * 8, sin_t + (size_t)(key - 1) * HD + c * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dot += qf[c * 8 + j] * bf2f(kk.e[j]);
-        }
-        const float s = dot * sl2;
-        sm[key] = s;
-        mx = fmaxf(mx, s);
-    }
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float sum = 0.f;
-    for (int key = tid; key < Ntok; key += 256) {
-        const float e = __builtin_amdgcn_exp2f(sm[key] - mx);
-        sum += e;
-        sm[key] = bf2f(f2bf(e));
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) red[4 + wave] = sum;
-    __syncthreads();
-    sum = red[4] + red[5] + red[6] + red[7];
-    const int c = tid & 7, kg = tid >> 3;         // 8 lanes cover one 128-byte V row; 32 key groups
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int key = kg; key < Ntok; key += 32) {
-        U128 vv;
-        vv.u = *(const uint4*)(vbase + (size_t)key * ldkv + c * 8);
-        const float pk = sm[key];
+        U128 kk[HG];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += pk * bf2f(vv.e[j]);
+        for (int h = 0; h < HG; ++h) kk[h].u = *(const uint4*)(kbase + (size_t)key * ldkv + h * HD);
+        if (key > 0) {
+            const float* cs = cos_t + (size_t)(key - 1) * HD + c * 8;
+            const float* sn = sin_t + (size_t)(key - 1) * HD + c * 8;
+#pragma unroll
+            for (int h = 0; h < HG; ++h) rope8(kk[h], cs, sn);
+        }
+#pragma unroll
+        for (int h = 0; h < HG; ++h) {
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += qf[h][j] * bf2f(kk[h].e[j]);
+            dot += __shfl_xor(dot, 1);
+            dot += __shfl_xor(dot, 2);
+            dot += __shfl_xor(dot, 4);
+            if (c == 0) sm[h * Npad + key] = dot * sl2;
+        }
+    }
+    __syncthreads();
+    for (int h = wave; h < HG; h += 4) {          // one wave per head: max, exponentials, row sum
+        float* row = sm + h * Npad;
+        float mx = -INFINITY;
+        for (int key = lane; key < Ntok; key += 64) mx = fmaxf(mx, row[key]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int key = lane; key < Ntok; key += 64) {
+            const float e = __builtin_amdgcn_exp2f(row[key] - mx);
+            sum += e;
+            row[key] = bf2f(f2bf(e));
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) rsum[h] = sum;
+    }
+    __syncthreads();
+    float acc[HG][8];
+#pragma unroll
+    for (int h = 0; h < HG; ++h)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
+    for (int key = kg; key < Ntok; key += 32) {
+        U128 vv[HG];
+#pragma unroll
+        for (int h = 0; h < HG; ++h) vv[h].u = *(const uint4*)(vbase + (size_t)key * ldkv + h * HD);
+#pragma unroll
+        for (int h = 0; h < HG; ++h) {
+            const float pk = sm[h * Npad + key];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[h][j] += pk * bf2f(vv[h].e[j]);
+        }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) part[kg * HD + c * 8 + j] = acc[j];
+    for (int h = 0; h < HG; ++h)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[kg * (HG * HD) + h * HD + c * 8 + j] = acc[h][j];
     __syncthreads();
-    if (tid < HD) {
-        float o = 0.f;
+    for (int o = tid; o < HG * HD; o += 256) {
+        float v = 0.f;
 #pragma unroll 8
-        for (int g = 0; g < 32; ++g) o += part[g * HD + tid];
-        out[(size_t)b * ldo + h * HD + tid] = f2bf(o / sum);
+        for (int g = 0; g < 32; ++g) v += part[g * (HG * HD) + o];
+        out[(size_t)b * ldo + h0 * HD + o] = f2bf(v / rsum[o / HD]);
     }
 }
 
@@ -707,10 +729,25 @@ extern "C" int cs_attn_cls_fwd(const void* q, const void* kv, const float* cos_t
     CS_CHECK_ARG(ldq % 8 == 0 && ldkv % 8 == 0 && ldq >= H * HD && ldkv >= 2 * H * HD && ldo >= H * HD,
                  "cs_attn_cls_fwd: row strides must be multiples of 8 and cover the heads (ldq=%d ldkv=%d ldo=%d)", ldq, ldkv, ldo);
     CS_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0, "cs_attn_cls_fwd: q/kv must be 16-byte aligned");
-    const size_t lds = ((size_t)((Ntok + 3) & ~3) + 32 * HD + 8) * sizeof(float);
-    CS_CHECK_ARG(lds <= 64 * 1024, "cs_attn_cls_fwd: Ntok=%d too large", Ntok);
-    hipLaunchKernelGGL(attn_cls_kernel, dim3(B * H), dim3(256), lds, stream, (const __bf16*)q, (const __bf16*)kv, cos_t, sin_t,
-                       (__bf16*)out, Ntok, H, ldq, ldkv, ldo, scale);
+    const int HG = H % 6 == 0 ? 6 : (H % 4 == 0 ? 4 : (H % 3 == 0 ? 3 : (H % 2 == 0 ? 2 : 1)));
+    const size_t lds = ((size_t)HG * ((Ntok + 3) & ~3) + 8 + (size_t)32 * HG * HD) * sizeof(float);
+    CS_CHECK_ARG(lds <= 160 * 1024, "cs_attn_cls_fwd: Ntok=%d too large", Ntok);
+    const dim3 grid(B, H / HG), block(256);
+#define CS_CLS_LAUNCH(G)                                                                                                      \
+    {                                                                                                                         \
+        static bool once = (set_lds(attn_cls_kernel<G>, 160 * 1024), true);                                                   \
+        (void)once;                                                                                                           \
+        hipLaunchKernelGGL(attn_cls_kernel<G>, grid, block, lds, stream, (const __bf16*)q, (const __bf16*)kv, cos_t, sin_t,   \
+                           (__bf16*)out, Ntok, H, ldq, ldkv, ldo, scale);                                                     \
+    }
+    switch (HG) {
+        case 6: CS_CLS_LAUNCH(6) break;
+        case 4: CS_CLS_LAUNCH(4) break;
+        case 3: CS_CLS_LAUNCH(3) break;
+        case 2: CS_CLS_LAUNCH(2) break;
+        default: CS_CLS_LAUNCH(1) break;
+    }
+#undef CS_CLS_LAUNCH
     CS_LAUNCH_CHECK();
     return 0;
 }
