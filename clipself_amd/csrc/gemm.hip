@@ -30,6 +30,8 @@
 //   * workgroup ids are remapped so that each XCD owns a contiguous range of tiles, rasterised in groups of 8 M panels
 //     (B tiles stay in that XCD's 4 MiB L2 while 8 A panels stream past).
 #include "cs_common.h"
+#include <cstdio>
+#include <cstdlib>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
@@ -50,6 +52,7 @@ struct GemmArgs {
     int ktiles_per_split;
     int group;            // EPI_PATCH: tokens-1 per image ; EPI_SWIGLU: hidden width Hd
     int gm;               // M panels per raster group
+    int dbg;              // ablation switches for tools/gemm_bench.py: bit0 skip the in-loop operand DMA, bit1 skip ds_read+MFMA
 };
 
 // One wave instruction fills 1 KiB = 8 tile rows (row group rg).  Lane l lands at rg*1024 + l*16, i.e. LDS row
@@ -170,7 +173,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                         const float v[4] = {x2.x + b2[0], x2.y + b2[1], x2.z + b2[2], x2.w + b2[3]};
                         U64 o;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) o.e[t] = f2bf(u[t] / (1.f + __expf(-u[t])) * v[t]);
+                        for (int t = 0; t < 4; ++t)      // silu(u)*v with the hardware exp2/rcp (1 ulp each; the result is rounded to bf16)
+                            o.e[t] = f2bf(u[t] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u[t])) * v[t]);
                         *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + hcol) = o.u;
                     }
                 }
@@ -245,10 +249,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // NS == 32: split rings -- three A buffers (activations stream from HBM: two tiles of prefetch) and two B buffers
+    // (weights sit in L2: one tile of prefetch), 3*A_BYTES + 2*B_BYTES = the whole 160 KiB for the 256x256 tile.
+    constexpr bool AB = (NS == 32);
+    char* const b_ring = smem + 3 * A_BYTES;
     if (kt_begin < kt_end) {
         stage_tile<A_INSTR, GLDS>(p.A, p.lda, kt_begin * BK, smem, wave * A_INSTR, lane, arow, achk);
-        stage_tile<B_INSTR, GLDS>(p.B, p.ldb, kt_begin * BK, smem + A_BYTES, wave * B_INSTR, lane, brow, bchk);
+        stage_tile<B_INSTR, GLDS>(p.B, p.ldb, kt_begin * BK, AB ? b_ring : smem + A_BYTES, wave * B_INSTR, lane, brow, bchk);
     }
+    if (AB && kt_begin + 1 < kt_end)
+        stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt_begin + 1) * BK, smem + A_BYTES, wave * A_INSTR, lane, arow, achk);
     // fragment addressing: row = base + l31 with base a multiple of 32 -> (row>>1)&15 == l31>>1, row&1 == l31&1
     const int a_base = ((wm * TM + l31) >> 1) << 8;
     const int b_base = ((wn * TN + l31) >> 1) << 8;
@@ -272,7 +282,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
         }
     }
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        if (NS == 3) {
+        if (AB) {
+            // In issue order this wave's pending DMA is A(kt), B(kt), A(kt+1): everything but the newest A_INSTR ops must
+            // have landed.  Raw s_barrier (a __syncthreads() would drain the queue).
+            if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();     // tile kt landed everywhere; tile kt-1's buffers (A slot (kt+2)%3, B slot (kt+1)&1) are free
+            const int i = kt - kt_begin;
+            if (kt + 1 < kt_end)
+                stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 1) * BK, b_ring + ((i + 1) & 1) * B_BYTES, wave * B_INSTR, lane, brow, bchk);
+            if (kt + 2 < kt_end)
+                stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 2) * BK, smem + ((i + 2) % 3) * A_BYTES, wave * A_INSTR, lane, arow, achk);
+        } else if (NS == 3) {
             // Counted wait: tile kt (older) must have landed, tile kt+1 (A_INSTR+B_INSTR newer DMA ops of this wave) may stay
             // in flight across the barrier.  Raw s_barrier: __syncthreads() would drain the DMA queue (vmcnt(0)).
             if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR) : "memory");
@@ -306,14 +328,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
             }
         } else {
             __syncthreads();        // tile kt landed (the barrier drains the LDS-DMA queue); buffer cur^1 is free
-            if (kt + 1 < kt_end) {
+            if (kt + 1 < kt_end && !(p.dbg & 1)) {
                 char* nxt = smem + (cur ^ 1) * STAGE;
                 stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 1) * BK, nxt, wave * A_INSTR, lane, arow, achk);
                 stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 1) * BK, nxt + A_BYTES, wave * B_INSTR, lane, brow, bchk);
             }
         }
-        const char* la = smem + cur * STAGE + a_base;
-        const char* lb = smem + cur * STAGE + A_BYTES + b_base;
+        const char* la = (AB ? smem + cur * A_BYTES : smem + cur * STAGE) + a_base;
+        const char* lb = (AB ? b_ring + ((kt - kt_begin) & 1) * B_BYTES : smem + cur * STAGE + A_BYTES) + b_base;
+        if (p.dbg & 2) { cur = (NS == 3 || AB) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1); continue; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int off = ((par8 | (ks * 2 + hf)) ^ sw) << 4;
@@ -327,9 +350,94 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        cur = (NS == 3) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
+        cur = (NS == 3 || AB) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
     }
     __syncthreads();                                    // every wave is done reading the operand buffers
+    if (p.dbg & 4) return;
+    epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + wm * TM, n0, tn, wn);
+}
+
+// ------------------------------------------------------------------------------------------------ two-workgroups-per-CU schedule
+// 256x128 tile, K tiles of 32, 3-stage LDS-DMA ring (72 KiB), 8 waves of 64x64 (<=128 registers): TWO workgroups fit a CU, so one
+// workgroup's epilogue (an HBM-bound store phase that is 25-45 % of a lockstep 256x256 kernel on the K=768 shapes of the towers)
+// and prologue overlap the other's MFMA loop.  LDS image of a K-32 tile: row r (64 B) at r*64, 16-byte chunk c at slot
+// c ^ ((r>>2)&3) -- conflict-free for the ds_read_b128 lane groups, and lane-linear for global_load_lds (lane l of the
+// instruction covering rows 16g.. lands on row 16g + (l>>2), slot l&3, so it fetches chunk (l&3) ^ ((l>>4)&3)).
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_k32_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 128, WN = 2, TM = 64, TN = 64, FM = 2, FN = 2, KT = 32;
+    constexpr int A_BYTES = BM * KT * 2, B_BYTES = BN * KT * 2, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int hf = lane >> 5, l31 = lane & 31;
+    int tm, tn;
+    tile_of_block(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int lrow = lane >> 2, lchk = (lane & 3) ^ ((lane >> 4) & 3);
+    const __bf16* asrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asrc[i] = p.A + (size_t)min(m0 + (wave * 2 + i) * 16 + lrow, p.M - 1) * p.lda + lchk * 8;
+    const __bf16* bsrc;
+    {
+        const int tr = wave * 16 + lrow;
+        int br;
+        if (EPI == EPI_SWIGLU_BF16) br = ((tr >> 5) & 1) * p.group + min(tn * (BN / 2) + (tr >> 6) * 32 + (tr & 31), p.group - 1);
+        else br = min(n0 + tr, p.N - 1);
+        bsrc = p.B + (size_t)br * p.ldb + lchk * 8;
+    }
+    auto stage = [&](int kt, int slot) {
+        char* dst = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)kt * KT),
+                                             (__attribute__((address_space(3))) void*)(dst + (wave * 2 + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + (size_t)kt * KT),
+                                         (__attribute__((address_space(3))) void*)(dst + A_BYTES + wave * 1024), 16, 0, 0);
+    };
+
+    const int kt_begin = blockIdx.y * p.ktiles_per_split * 2;            // ktiles_per_split counts K-64 tiles
+    const int kt_end = min(kt_begin + p.ktiles_per_split * 2, p.K / KT);
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (kt_begin < kt_end) stage(kt_begin, 0);
+    if (kt_begin + 1 < kt_end) stage(kt_begin + 1, 1);
+    const int a_off = (wm * TM + l31) * 64, b_off = A_BYTES + (wn * TN + l31) * 64;
+    const int swz = (l31 >> 2) & 3;
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        // counted wait: tile kt landed, tile kt+1 (the 3 newest DMA ops of this wave) may stay in flight across the barrier
+        if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();         // everyone's tile kt landed; everyone finished reading slot (cur+2)%3 (tile kt-1)
+        if (kt + 2 < kt_end) stage(kt + 2, cur == 0 ? 2 : cur - 1);
+        const char* st = smem + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = ((ks * 2 + hf) ^ swz) << 4;
+            bf16x8 a[FM], b[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(st + a_off + i * 2048 + off);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(st + b_off + j * 2048 + off);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    __syncthreads();
+    if (p.dbg & 4) return;
     epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + wm * TM, n0, tn, wn);
 }
 
@@ -446,7 +554,7 @@ int launch_cfg(GemmArgs a, int splits, int use_glds, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + BN / 2 - 1) / (BN / 2) : (a.N + BN - 1) / BN;
     constexpr int NW = WM * WN;
-    constexpr size_t stage = (size_t)(BM + BN) * BK * 2 * NS + (PF ? (size_t)NW * 1024 : 0);
+    constexpr size_t stage = NS == 32 ? (size_t)(3 * BM + 2 * BN) * BK * 2 : (size_t)(BM + BN) * BK * 2 * NS + (PF ? (size_t)NW * 1024 : 0);
     constexpr size_t lds = stage > (size_t)NW * EP_BYTES ? stage : (size_t)NW * EP_BYTES;
     dim3 grid(a.tiles_m * a.tiles_n, splits), block(NW * 64);
     if (use_glds) {
@@ -472,6 +580,25 @@ int launch_pp(GemmArgs a, int splits, hipStream_t stream) {
     static bool once = ((void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int EPI>
+int launch_k32(GemmArgs a, int splits, hipStream_t stream) {
+    constexpr int BM = 256, BN = 128;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + BN / 2 - 1) / (BN / 2) : (a.N + BN - 1) / BN;
+    constexpr size_t lds = (size_t)(BM + BN) * 32 * 2 * 3;                  // 72 KiB: operand ring, reused by the epilogue slabs
+    static_assert(lds >= (size_t)8 * EP_BYTES, "epilogue slabs must fit the operand ring");
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_k32_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    if (getenv("CS_GEMM_DEBUG")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_k32_kernel<EPI>, 512, lds);
+        fprintf(stderr, "[cs_gemm] k32 epi=%d: %d resident workgroups per CU (lds %zu)\n", EPI, nb, lds);
+    }
+    hipLaunchKernelGGL(gemm_k32_kernel<EPI>, dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
     CS_LAUNCH_CHECK();
     return 0;
 }
@@ -507,11 +634,13 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
         if (a.M < 256 || ncols < 256) c3 = 1e30;
         if (a.M < 256 || ncols < 128) c2 = 1e30;
         cfg = (c3 <= c2 && c3 <= c1) ? 3 : (c2 <= c1 ? 2 : 1);
-        if (cfg == 3 && use_glds && PP_DEFAULT) cfg = 5;
+        if (cfg == 3 && use_glds) cfg = PP_DEFAULT ? 5 : 7;      // split rings: +1..3 % over the lockstep 2-stage ring on the tower shapes
     }
-    const int ns = sp[cfg == 4 ? 2 : (cfg >= 5 ? 3 : cfg)];
+    const int ns = sp[(cfg == 4 || cfg == 8) ? 2 : (cfg >= 5 ? 3 : cfg)];   // cfgs 5..7 are 256x256 variants
     a.ktiles_per_split = (ktiles + ns - 1) / ns;
     switch (cfg) {
+        case 8: return launch_k32<EPI>(a, ns, stream);                                          // 256x128, K-32 tiles, 3-stage ring, two workgroups per CU
+        case 7: return launch_cfg<EPI, 256, 256, 2, 4, 32>(a, ns, use_glds, stream);       // 256x256, A ring 3 / B ring 2 (160 KiB)
         case 6: return launch_cfg<EPI, 256, 256, 2, 4, 2, true>(a, ns, use_glds, stream);   // 256x256 lockstep + L2 warm-up of tile kt+2
         case 5: return launch_pp<EPI>(a, ns, stream);                                  // 256x256 ping-pong
         case 4: return launch_cfg<EPI, 256, 128, 4, 2, 3>(a, ns, use_glds, stream);     // 256x128, 3-stage ring
@@ -529,9 +658,11 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 //      4 f32 atomic accumulate (split-K, C pre-zeroed or accumulating) |
 //      5 patch-embed: out row = row + row/group + 1, += extra[(row%group+1)*ldc + col]
 // flags bit0: 0 = global_load_lds staging, 1 = register staging (debug/fallback A-B switch)
-//       bits 4-6: force schedule (1 = 128x128, 2 = 256x128, 3 = 256x256 lockstep, 4 = 256x128 3-stage ring,
-//                 5 = 256x256 ping-pong, 6 = 256x256 lockstep + L2 warm-up; 0 = heuristic)
+//       bits 4-7: force schedule (1 = 128x128, 2 = 256x128, 3 = 256x256 lockstep, 4 = 256x128 3-stage ring,
+//                 5 = 256x256 ping-pong, 6 = 256x256 lockstep + L2 warm-up, 7 = 256x256 split rings A3/B2,
+//                 8 = 256x128 K-32 ring, two workgroups per CU; 0 = heuristic)
 //       bits 8-11: raster group height override (0 = 8)
+//       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue
 extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
                           int lda, int ldb, int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
     CS_CHECK_ARG(M > 0 && N > 0 && K > 0, "cs_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
@@ -552,7 +683,8 @@ extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bi
     if (epi == EPI_PATCH_F32) CS_CHECK_ARG(group > 0, "cs_gemm_nt: patch epilogue needs group");
     a.ktiles_per_split = K / BK;
     const int glds = (flags & 1) ? 0 : 1;
-    const int force = (flags >> 4) & 7;
+    const int force = (flags >> 4) & 15;
+    a.dbg = (flags >> 12) & 7;
     CS_CHECK_ARG(!(force == 5 && !glds), "cs_gemm_nt: the ping-pong schedule only exists with LDS-DMA staging");
     switch (epi) {
         case EPI_BF16: return launch<EPI_BF16>(a, splits, glds, force, stream);

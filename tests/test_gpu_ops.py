@@ -52,7 +52,7 @@ def both(cpu_tensors):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x31, 0x40, 0x41, 0x50, 0x60])      # heuristic, register staging, forced 128x128 / 256x128 / 256x256 / 3-stage
+@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x31, 0x40, 0x41, 0x50, 0x60, 0x70, 0x71, 0x80])      # heuristic, register staging, forced 128x128 / 256x128 / 256x256 / 3-stage
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (3152, 768, 768), (300, 192, 64), (128, 64, 256), (1000, 2304, 768)])
 def test_gemm_bf16_bias(hip, ref, M, N, K, flags):
     A, B, bias = rnd((M, K), BF, seed=1), rnd((N, K), BF, 0.05, seed=2), rnd((N,), F32, seed=3)
@@ -64,7 +64,7 @@ def test_gemm_bf16_bias(hip, ref, M, N, K, flags):
     check(f"gemm_bf16[{M},{N},{K}] flags={flags}", Cd, Cr, TOL_BF)
 
 
-@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60])
+@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60, 0x70, 0x71, 0x80])
 def test_gemm_f32_resid_strided(hip, ref, flags):
     M, N, K = 788, 768, 2048
     Abig = rnd((M, K + 64), BF, seed=4)
@@ -83,7 +83,7 @@ def test_gemm_f32_resid_strided(hip, ref, flags):
     check(f"gemm_f32_nobias flags={flags}", Cd2, Cr2, TOL_F32)
 
 
-@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60])
+@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60, 0x70, 0x71, 0x80])
 @pytest.mark.parametrize("Hd,M", [(2048, 394), (256, 34), (96, 130)])
 def test_gemm_swiglu(hip, ref, Hd, M, flags):
     K = 128
@@ -102,7 +102,7 @@ def test_gemm_splitk_atomic_wgrad_shape(hip, ref):
     base = rnd((N, Kd), F32, seed=13)
     Cr = base.clone()
     ref.gemm_nt(A, B, Cr, epi=4)
-    for flags in (0, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60):
+    for flags in (0, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60, 0x70, 0x80):
         Cd = base.cuda()
         hip.gemm_nt(A.cuda(), B.cuda(), Cd, epi=4, splits=7, flags=flags)
         check(f"gemm_splitk_atomic flags={flags}", Cd, Cr, TOL_F32)

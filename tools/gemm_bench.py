@@ -30,8 +30,8 @@ def main():
         else:
             C, extra, group = torch.empty(M, N // 2, dtype=BF, device="cuda"), None, N // 2
         line = f"{name} M={M}: "
-        for cfg, gm in ((3, 8), (6, 8), (5, 8), (3, 8), (6, 8)):
-            flags = (cfg << 4) | (gm << 8)
+        for cfg, gm, dbg in ((3, 8, 0), (3, 8, 0), (7, 8, 0), (8, 8, 0), (3, 8, 4), (3, 8, 5)):   # dbg: 1 no DMA, 2 no MFMA, 3 neither
+            flags = (cfg << 4) | (gm << 8) | (dbg << 12)
             for _ in range(3):
                 ops.gemm_nt(A, B, C, bias, extra, epi=epi, group=group, flags=flags)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -41,7 +41,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / 20
-            line += f" cfg{cfg}/gm{gm}: {us:7.1f} us {2.0 * M * N * K / us / 1e6:6.0f} TF/s |"
+            line += f" cfg{cfg}/gm{gm}/dbg{dbg}: {us:7.1f} us {2.0 * M * N * K / us / 1e6:6.0f} TF/s |"
         print(line, flush=True)
         # race screen for the ping-pong schedule: it accumulates in the same order as the lockstep kernel -> bit-identical
         if epi != 2:
