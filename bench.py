@@ -141,10 +141,13 @@ def main():
 
     rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     distributed = world > 1
+    # CLIPSELF_DIST_BACKEND=gloo + fewer devices than ranks is the single-GPU rehearsal of the N-rank path used by
+    # tests/test_gpu_step.py (RCCL refuses two ranks on one device); the driver's runs use nccl (= RCCL), one rank per GPU.
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)
+        dist.init_process_group(backend=os.environ.get("CLIPSELF_DIST_BACKEND", "nccl"), init_method="env://", world_size=world, rank=rank)
     device = f"cuda:{local}"
 
     student = create_model(MODEL, "eva", precision="amp_bf16", device=device, cache_dir=None)

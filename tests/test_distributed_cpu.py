@@ -1,13 +1,15 @@
 """CPU, world_size 2 over gloo: the bucketed gradient all-reduce really averages (the failure mode of the reference,
 SURVEY.md D3), N ranks x batch B == 1 process x batch N*B, the never-reached tensors do not hang anything, and
-both ranks hold identical parameters after the step."""
+both ranks hold identical parameters after the step.
+
+`run_two_rank_equivalence(device, ...)` is shared with tests/test_gpu_step.py, which runs the same scenario through the HIP
+kernels with both ranks on cuda:0 (gloo moves the device buffers; RCCL refuses two ranks on one device)."""
 import os
 import socket
 import sys
 from pathlib import Path
 from types import SimpleNamespace
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -21,22 +23,26 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(cfg):
+def _build(cfg, device):
     from clipself_amd.init import seeded_visual_state
     from clipself_amd.open_clip.model import CustomCLIP
-    from oracle.ops_ref import RefOps
-    student, teacher = CustomCLIP(cfg, ops=RefOps(), trainable=True), CustomCLIP(cfg, ops=RefOps(), trainable=False)
+    if device == "cpu":
+        from oracle.ops_ref import RefOps as Ops
+    else:
+        from clipself_amd.hip import HipOps as Ops
+    student, teacher = CustomCLIP(cfg, ops=Ops(), trainable=True), CustomCLIP(cfg, ops=Ops(), trainable=False)
     return student, teacher, seeded_visual_state
 
 
-def _args(distributed):
-    return SimpleNamespace(device="cpu", precision="amp", distributed=distributed, skip_scheduler=True, grad_clip_norm=None,
+def _args(distributed, device):
+    return SimpleNamespace(device=device, precision="amp", distributed=distributed, skip_scheduler=True, grad_clip_norm=None,
                            multiscale=False, extract_type="v2", cosine_weight=1.0)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, device):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from clipself_amd.config import tiny_cfg
     from clipself_amd.init import synthetic_batch
@@ -46,7 +52,7 @@ def _worker(rank, world, port, out_dir):
     from clipself_amd.training.train import train_step
     torch.set_num_threads(2)
     cfg = tiny_cfg()
-    student, teacher, seeded = _build(cfg)
+    student, teacher, seeded = _build(cfg, device)
     # deliberately different initial weights per rank: the wrapper must broadcast rank 0's
     student.visual.engine.load_state(seeded(cfg, 1 + rank))
     teacher.visual.engine.load_state(seeded(cfg, 1 + rank))
@@ -54,16 +60,16 @@ def _worker(rank, world, port, out_dir):
     model, dist_model = StudentDataParallel(student), FrozenDataParallel(teacher)
     opt = FlatAdamW(student, lr=1e-3, weight_decay=0.1, grad_divisor=float(world))
     batch = synthetic_batch(2, 3, cfg.image_size, cfg.image_size, seed=40 + rank)
-    train_step(model, CLIPSelf(), batch, opt, None, 0, dist_model, _args(True))
+    train_step(model, CLIPSelf(), batch, opt, None, 0, dist_model, _args(True, device))
     eng = student.visual.engine
-    torch.save({"grad": eng.grad.clone(), "master": eng.master.clone()}, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save({"grad": eng.grad.cpu().clone(), "master": eng.master.cpu().clone()}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_process_on_the_union_batch(tmp_path):
+def run_two_rank_equivalence(device, tmp_path, tol):
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), device), nprocs=world, join=True)
     r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
     assert torch.equal(r0["master"], r1["master"]), "ranks diverged after the step"
     assert torch.equal(r0["grad"], r1["grad"]), "all-reduced gradients differ between ranks"
@@ -74,17 +80,22 @@ def test_two_rank_step_equals_single_process_on_the_union_batch(tmp_path):
     from clipself_amd.training.optim import FlatAdamW
     from clipself_amd.training.train import train_step
     cfg = tiny_cfg()
-    student, teacher, seeded = _build(cfg)
+    student, teacher, seeded = _build(cfg, device)
     student.visual.engine.load_state(seeded(cfg, 1))
     teacher.visual.engine.load_state(seeded(cfg, 1))
     student.lock_image_tower(unlocked_groups=cfg.layers)
     parts = [synthetic_batch(2, 3, cfg.image_size, cfg.image_size, seed=40 + r) for r in range(2)]
     union = tuple(torch.cat([p[i] for p in parts]) for i in range(3))
     opt = FlatAdamW(student, lr=1e-3, weight_decay=0.1)
-    train_step(student, CLIPSelf(), union, opt, None, 0, teacher, _args(False))
+    train_step(student, CLIPSelf(), union, opt, None, 0, teacher, _args(False, device))
     eng = student.visual.engine
-    g_single, g_dist = eng.grad, r0["grad"] / world          # SUM on the wire, 1/world applied inside AdamW
+    g_single, g_dist = eng.grad.cpu(), r0["grad"] / world          # SUM on the wire, 1/world applied inside AdamW
     rel = float((g_single - g_dist).norm() / g_single.norm())
-    assert rel < 1e-5, rel
-    relp = float((eng.master - r0["master"]).norm() / eng.master.norm())
-    assert relp < 1e-5, relp
+    assert rel < tol, rel
+    relp = float((eng.master.cpu() - r0["master"]).norm() / eng.master.norm())
+    assert relp < tol, relp
+    return rel, relp
+
+
+def test_two_rank_step_equals_single_process_on_the_union_batch(tmp_path):
+    run_two_rank_equivalence("cpu", tmp_path, 1e-5)

@@ -277,3 +277,31 @@ def test_training_main_entrypoint_end_to_end(tmp_path):
     r2 = subprocess.run(base + ["--name", "run2", "--resume", str(ckpt), "--epochs", "2"], cwd=root, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert "resuming checkpoint" in r2.stderr and "Start epoch 1" in r2.stderr
+
+
+def test_two_ranks_on_one_gpu_equal_single_process(tmp_path):
+    """SURVEY §8(e) on the real kernels: 2 ranks (both on cuda:0, gloo carrying the device buffers) x batch B with the per-block
+    asynchronous gradient all-reduce == 1 process on the union batch; both ranks end with identical parameters."""
+    from test_distributed_cpu import run_two_rank_equivalence
+    g, p = run_two_rank_equivalence("cuda", tmp_path, 2e-2)
+    _log(f"2-rank DP on one GPU vs union batch: grad rel={g:.3e} param rel={p:.3e}")
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py under torch.distributed.run with 2 ranks sharing cuda:0 (CLIPSELF_DIST_BACKEND=gloo): the N>1 code path of the
+    benchmark (broadcast, per-block all-reduce overlapped with backward, barrier + max-over-ranks timing, rank-0 JSON line)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, CLIPSELF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    _log(f"bench 2-rank rehearsal on one GPU: {out['value']:.1f} img/s loss={out['config']['loss_last_step']:.4f}")
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and 0.0 < out["config"]["loss_last_step"] < 2.0
