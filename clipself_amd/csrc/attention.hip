@@ -68,6 +68,8 @@ struct AttnArgs {
     const float* sin_t;
     const float* lse_in;   // bwd: [B*H, N]
     const float* dsum;     // bwd: rowsum(dO*O) [B*H, N]
+    float* stats_part;     // fwd, optional: [H][B*N][2] per-head (sum, sum of squares) of the output rows
+    long Mtot;             // B*N
     __bf16* out;           // fwd: O [B*N, ldo] ; bwd: dqkv [B*N, ldqkv]
     float* lse_out;        // fwd (nullable)
     int Ntok, H, ldqkv, ldo;
@@ -256,6 +258,22 @@ __device__ __forceinline__ void store_o(const AttnArgs& p, size_t rowbase, int q
             *(uint2*)(orow + dt * 32 + g4 * 8 + hf * 4) = t.u;
         }
     if (p.lse_out && hf == 0) p.lse_out[(size_t)bh * p.Ntok + q] = m * p.scale + logf(l);
+    if (p.stats_part) {
+        // (sum, sum of squares) of this row's 64 rounded outputs of head h: the two half-wave lanes of a query hold 32 each.
+        // cs_ln_stats_finalize() pools the H heads, so inner_attn_ln needs no pass of its own over the attention output.
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float r = bf2f(f2bf(o[dt][e] * inv));
+                ps += r;
+                pq += r * r;
+            }
+        ps += __shfl_xor(ps, 32);
+        pq += __shfl_xor(pq, 32);
+        if (hf == 0) *(float2*)(p.stats_part + ((size_t)h * p.Mtot + rowbase + q) * 2) = make_float2(ps, pq);
+    }
 }
 
 // NW waves per workgroup, QTW 32-query tiles per wave (tile = wave + j*NW).  QTW > 1 requires the whole sequence in one key
@@ -670,11 +688,12 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const __bf16* __restrict_
 // C ABI ------------------------------------------------------------------------------------------
 // qkv [B*N, ldqkv] bf16 (q|k|v, un-rotated, bias already added); cos/sin [(N-1), 64] f32; out [B*N, ldo] bf16;
 // lse [B*H, N] f32 or null.  Head dim fixed at 64 (both EVA02 towers).
-extern "C" int cs_attn_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* out, float* lse, int B, int Ntok, int H,
-                           int ldqkv, int ldo, float scale, hipStream_t stream) {
+static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t, void* out, float* lse, float* stats_part, int B, int Ntok,
+                         int H, int ldqkv, int ldo, float scale, hipStream_t stream) {
     if (check_common("cs_attn_fwd", B, Ntok, H, ldqkv, ldo)) return -1;
     AttnArgs a{};
     a.qkv = (const __bf16*)qkv; a.cos_t = cos_t; a.sin_t = sin_t; a.out = (__bf16*)out; a.lse_out = lse;
+    a.stats_part = stats_part; a.Mtot = (long)B * Ntok;
     a.Ntok = Ntok; a.H = H; a.ldqkv = ldqkv; a.ldo = ldo; a.scale = scale;
     constexpr int CH = 7;
     const size_t lds = (size_t)CH * 32 * 128 + (size_t)HD * VT_LD * 2;
@@ -690,6 +709,19 @@ extern "C" int cs_attn_fwd(const void* qkv, const float* cos_t, const float* sin
     }
     CS_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int cs_attn_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* out, float* lse, int B, int Ntok, int H,
+                           int ldqkv, int ldo, float scale, hipStream_t stream) {
+    return attn_fwd_impl(qkv, cos_t, sin_t, out, lse, nullptr, B, Ntok, H, ldqkv, ldo, scale, stream);
+}
+
+// cs_attn_fwd that also emits stats_part [H][B*Ntok][2] f32: per head, (sum, sum of squares) of each output row's 64 values
+// (after rounding to bf16) -- the LayerNorm statistics of inner_attn_ln without another pass (see cs_ln_stats_finalize).
+extern "C" int cs_attn_fwd_stats(const void* qkv, const float* cos_t, const float* sin_t, void* out, float* lse, float* stats_part, int B,
+                                 int Ntok, int H, int ldqkv, int ldo, float scale, hipStream_t stream) {
+    CS_CHECK_ARG(stats_part != nullptr && ((uintptr_t)stats_part % 8) == 0, "cs_attn_fwd_stats: stats_part must be an 8-byte aligned buffer");
+    return attn_fwd_impl(qkv, cos_t, sin_t, out, lse, stats_part, B, Ntok, H, ldqkv, ldo, scale, stream);
 }
 
 extern "C" size_t cs_attn_bwd_workspace(int B, int Ntok, int H) { return (size_t)B * H * Ntok * sizeof(float); }

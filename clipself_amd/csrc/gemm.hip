@@ -38,7 +38,7 @@ namespace {
 
 constexpr int BK = 64;
 constexpr bool PP_DEFAULT = false;     // make the ping-pong schedule the default for 256x256 tiles (A/B knob, see tools/gemm_bench.py)
-enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID_F32 = 2, EPI_SWIGLU_BF16 = 3, EPI_ATOMIC_F32 = 4, EPI_PATCH_F32 = 5 };
+enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID_F32 = 2, EPI_SWIGLU_BF16 = 3, EPI_ATOMIC_F32 = 4, EPI_PATCH_F32 = 5, EPI_RESID_LN_F32 = 6 };
 
 struct GemmArgs {
     const __bf16* A;
@@ -52,6 +52,12 @@ struct GemmArgs {
     int ktiles_per_split;
     int group;            // EPI_PATCH: tokens-1 per image ; EPI_SWIGLU: hidden width Hd
     int gm;               // M panels per raster group
+    // LayerNorm folded into the GEMM (frozen towers): A holds the *un-normalised* rows, B = gamma (.) W, and the epilogue applies
+    // out = extra + rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]   with ln_colsum[n] = sum_k B[n,k], bias[n] = beta.W[n] + b[n].
+    const float* ln_mean;
+    const float* ln_rstd;
+    const float* ln_colsum;
+    float* stats_part;    // EPI_SWIGLU: optional per-(32-column slice, row) partial (sum, sum of squares) of the bf16 outputs
     int dbg;              // ablation switches for tools/gemm_bench.py: bit0 skip the in-loop operand DMA, bit1 skip ds_read+MFMA
 };
 
@@ -137,11 +143,20 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
         // rows instead of predicates): a load->add->store chain per row would serialise 8 memory round trips per block
         // (vmcnt also counts the previous store), and here their latency hides behind the LDS transposition.
         float4 xin[8];
-        if ((EPI == EPI_RESID_F32 || EPI == EPI_PATCH_F32) && col < p.N) {
+        float lmean[8], lrstd[8];
+        if (EPI == EPI_RESID_LN_F32 && col < p.N) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int row = min(row_base + rrow + it * 4, p.M - 1);
-                if (EPI == EPI_RESID_F32) {
+                lmean[it] = p.ln_mean[row];
+                lrstd[it] = p.ln_rstd[row];
+            }
+        }
+        if ((EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32 || EPI == EPI_PATCH_F32) && col < p.N) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = min(row_base + rrow + it * 4, p.M - 1);
+                if (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
                     xin[it] = *(const float4*)(p.extra + (size_t)row * p.ldc + col);
                 } else {
                     const int img = row / p.group, t = row - img * p.group;
@@ -158,24 +173,39 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
             // slab columns [0,32) = x1, [32,64) = x2 of hidden units hcol .. ; 8 lanes per row, 4 hidden units per lane
             const int hr = lane >> 3, hc = (lane & 7) * 4;
             const int hcol = tn * (BN / 2) + wn * 32 + hc;
-            if (hcol < p.group) {
-                float b1[4] = {0, 0, 0, 0}, b2[4] = {0, 0, 0, 0};
-                if (p.bias) {
-                    const float4 t1 = *(const float4*)(p.bias + hcol), t2 = *(const float4*)(p.bias + p.group + hcol);
-                    b1[0] = t1.x; b1[1] = t1.y; b1[2] = t1.z; b1[3] = t1.w; b2[0] = t2.x; b2[1] = t2.y; b2[2] = t2.z; b2[3] = t2.w;
+            const bool colok = hcol < p.group;
+            float b1[4] = {0, 0, 0, 0}, b2[4] = {0, 0, 0, 0};
+            if (colok && p.bias) {
+                const float4 t1 = *(const float4*)(p.bias + hcol), t2 = *(const float4*)(p.bias + p.group + hcol);
+                b1[0] = t1.x; b1[1] = t1.y; b1[2] = t1.z; b1[3] = t1.w; b2[0] = t2.x; b2[1] = t2.y; b2[2] = t2.z; b2[3] = t2.w;
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rl = hr + it * 8, row = row_base + rl;
+                float ps = 0.f, pq = 0.f;
+                if (colok && row < p.M) {
+                    const float4 x1 = *(const float4*)(slab + rl * EP_LD + hc), x2 = *(const float4*)(slab + rl * EP_LD + 32 + hc);
+                    const float u[4] = {x1.x + b1[0], x1.y + b1[1], x1.z + b1[2], x1.w + b1[3]};
+                    const float v[4] = {x2.x + b2[0], x2.y + b2[1], x2.z + b2[2], x2.w + b2[3]};
+                    U64 o;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {    // silu(u)*v with the hardware exp2/rcp (1 ulp each; the result is rounded to bf16)
+                        o.e[t] = f2bf(u[t] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u[t])) * v[t]);
+                        const float r = bf2f(o.e[t]);
+                        ps += r;
+                        pq += r * r;
+                    }
+                    *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + hcol) = o.u;
                 }
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int rl = hr + it * 8, row = row_base + rl;
-                    if (row < p.M) {
-                        const float4 x1 = *(const float4*)(slab + rl * EP_LD + hc), x2 = *(const float4*)(slab + rl * EP_LD + 32 + hc);
-                        const float u[4] = {x1.x + b1[0], x1.y + b1[1], x1.z + b1[2], x1.w + b1[3]};
-                        const float v[4] = {x2.x + b2[0], x2.y + b2[1], x2.z + b2[2], x2.w + b2[3]};
-                        U64 o;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)      // silu(u)*v with the hardware exp2/rcp (1 ulp each; the result is rounded to bf16)
-                            o.e[t] = f2bf(u[t] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u[t])) * v[t]);
-                        *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + hcol) = o.u;
+                if (p.stats_part) {
+                    // LayerNorm statistics of the rounded outputs, reduced over the 8 lanes (32 hidden units) of this row slice;
+                    // cs_ln_stats_finalize() combines the slices, so the sub-LN pass over the hidden matrix disappears.
+                    ps += __shfl_xor(ps, 1); pq += __shfl_xor(pq, 1);
+                    ps += __shfl_xor(ps, 2); pq += __shfl_xor(pq, 2);
+                    ps += __shfl_xor(ps, 4); pq += __shfl_xor(pq, 4);
+                    if ((lane & 7) == 0 && row < p.M) {
+                        const size_t slice = (size_t)tn * (BN / 64) + wn;
+                        *(float2*)(p.stats_part + (slice * p.M + row) * 2) = make_float2(ps, pq);
                     }
                 }
             }
@@ -183,6 +213,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
             if (col < p.N) {
                 float bv[4] = {0, 0, 0, 0};
                 if (p.bias) { const float4 t = *(const float4*)(p.bias + col); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
+                float cs[4] = {0, 0, 0, 0};
+                if (EPI == EPI_RESID_LN_F32) { const float4 t = *(const float4*)(p.ln_colsum + col); cs[0] = t.x; cs[1] = t.y; cs[2] = t.z; cs[3] = t.w; }
                 const bool full = row_base + 32 <= p.M;              // wave-uniform
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
@@ -190,6 +222,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                     if (!full && row >= p.M) continue;
                     const float4 s = *(const float4*)(slab + rl * EP_LD + rcol);
                     float v[4] = {s.x + bv[0], s.y + bv[1], s.z + bv[2], s.w + bv[3]};
+                    if (EPI == EPI_RESID_LN_F32) {
+                        const float mu = lmean[it], rs = lrstd[it];
+                        v[0] = rs * (s.x - mu * cs[0]) + bv[0]; v[1] = rs * (s.y - mu * cs[1]) + bv[1];
+                        v[2] = rs * (s.z - mu * cs[2]) + bv[2]; v[3] = rs * (s.w - mu * cs[3]) + bv[3];
+                    }
                     if (EPI == EPI_BF16) {
                         U64 o;
 #pragma unroll
@@ -197,7 +234,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                         *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + col) = o.u;
                     } else if (EPI == EPI_F32) {
                         *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else if (EPI == EPI_RESID_F32) {
+                    } else if (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
                         const float4 x = xin[it];
                         *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
                     } else if (EPI == EPI_ATOMIC_F32) {
@@ -663,8 +700,9 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 //                 8 = 256x128 K-32 ring, two workgroups per CU; 0 = heuristic)
 //       bits 8-11: raster group height override (0 = 8)
 //       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue
-extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
-                          int lda, int ldb, int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
+static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias, const float* extra, const float* ln_mean,
+                        const float* ln_rstd, const float* ln_colsum, float* stats_part, int M, int N, int K, int lda, int ldb, int ldc,
+                        int epi, int splits, int group, int flags, hipStream_t stream) {
     CS_CHECK_ARG(M > 0 && N > 0 && K > 0, "cs_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
     CS_CHECK_ARG(K % BK == 0, "cs_gemm_nt: K=%d must be a multiple of %d", K, BK);
     CS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0, "cs_gemm_nt: lda/ldb must be multiples of 8 (16-byte rows)");
@@ -676,10 +714,13 @@ extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bi
     GemmArgs a;
     a.A = (const __bf16*)A; a.B = (const __bf16*)B; a.C = C; a.bias = bias; a.extra = extra;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.group = group;
+    a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_colsum = ln_colsum; a.stats_part = stats_part;
     a.tiles_m = a.tiles_n = 0;
     a.gm = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 8;
     if (epi == EPI_SWIGLU_BF16) CS_CHECK_ARG(group > 0 && N == 2 * group, "cs_gemm_nt: swiglu epilogue needs N == 2*group");
-    if (epi == EPI_PATCH_F32 || epi == EPI_RESID_F32) CS_CHECK_ARG(extra != nullptr && ((uintptr_t)extra % 16) == 0, "cs_gemm_nt: epilogue %d needs 16-byte aligned extra", epi);
+    if (epi == EPI_RESID_LN_F32) CS_CHECK_ARG(ln_mean && ln_rstd && ln_colsum && ((uintptr_t)ln_colsum % 16) == 0, "cs_gemm_nt_ln: epilogue 6 needs mean, rstd and a 16-byte aligned column-sum vector");
+    CS_CHECK_ARG(stats_part == nullptr || epi == EPI_SWIGLU_BF16, "cs_gemm_nt_ln: statistics output only exists for the SwiGLU epilogue");
+    if (epi == EPI_PATCH_F32 || epi == EPI_RESID_F32 || epi == EPI_RESID_LN_F32) CS_CHECK_ARG(extra != nullptr && ((uintptr_t)extra % 16) == 0, "cs_gemm_nt: epilogue %d needs 16-byte aligned extra", epi);
     if (epi == EPI_PATCH_F32) CS_CHECK_ARG(group > 0, "cs_gemm_nt: patch epilogue needs group");
     a.ktiles_per_split = K / BK;
     const int glds = (flags & 1) ? 0 : 1;
@@ -693,7 +734,24 @@ extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bi
         case EPI_SWIGLU_BF16: return launch<EPI_SWIGLU_BF16>(a, splits, glds, force, stream);
         case EPI_ATOMIC_F32: return launch<EPI_ATOMIC_F32>(a, splits, glds, force, stream);
         case EPI_PATCH_F32: return launch<EPI_PATCH_F32>(a, splits, glds, force, stream);
+        case EPI_RESID_LN_F32: return launch<EPI_RESID_LN_F32>(a, splits, glds, force, stream);
     }
     cs_set_error("cs_gemm_nt: unknown epilogue %d", epi);
     return -1;
+}
+
+extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
+                          int lda, int ldb, int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
+    CS_CHECK_ARG(epi != EPI_RESID_LN_F32, "cs_gemm_nt: epilogue 6 (folded LayerNorm) is reached through cs_gemm_nt_ln");
+    return gemm_nt_impl(A, B, C, bias, extra, nullptr, nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldc, epi, splits, group, flags, stream);
+}
+
+// cs_gemm_nt plus the folded-LayerNorm operands (frozen towers; see GemmArgs):
+//   epi 6: C = extra + ln_rstd[m] * (A.B^T - ln_mean[m] * ln_colsum[n]) + bias[n]     (A un-normalised, B = gamma (.) W)
+//   epi 3 with stats_part != null: also writes, per 32-hidden-unit slice s and row m, (sum, sum of squares) of the rounded
+//          outputs to stats_part[(s*M + m)*2 ..]; slices = 4*ceil(group/128); combine with cs_ln_stats_finalize.
+extern "C" int cs_gemm_nt_ln(const void* A, const void* B, void* C, const float* bias, const float* extra, const float* ln_mean,
+                             const float* ln_rstd, const float* ln_colsum, float* stats_part, int M, int N, int K, int lda, int ldb,
+                             int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
+    return gemm_nt_impl(A, B, C, bias, extra, ln_mean, ln_rstd, ln_colsum, stats_part, M, N, K, lda, ldb, ldc, epi, splits, group, flags, stream);
 }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, l
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) {
         const int c = (g * 64 + lane) * 4;
-        if (g < ng && c < C) {
+        if (y != nullptr && g < ng && c < C) {       // y == null: statistics only
             const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
             float o[4] = {(v[g][0] - mean) * rstd * ga.x + be.x, (v[g][1] - mean) * rstd * ga.y + be.y,
                           (v[g][2] - mean) * rstd * ga.z + be.z, (v[g][3] - mean) * rstd * ga.w + be.w};
@@ -78,6 +78,29 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, l
         }
     }
     if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// Combine per-slice (sum, sum of squares) partials -- written by the SwiGLU GEMM epilogue (32 columns per slice) or the attention
+// forward (64 per head) -- into LayerNorm mean / rstd per row.  Slice p covers columns [p*npp, min((p+1)*npp, C)); the pooled
+// variance uses each slice's own centred second moment (Chan et al.), so nothing cancels against a large row mean.
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, int P, int npp, int C, int M, float eps,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    float tot = 0.f;
+    for (int p = 0; p < P; ++p)
+        if (C - p * npp > 0) tot += part[((size_t)p * M + row) * 2];
+    const float mean = tot / (float)C;
+    float m2 = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const int n = min(npp, C - p * npp);
+        if (n <= 0) continue;
+        const float2 sq = *(const float2*)(part + ((size_t)p * M + row) * 2);
+        const float mp = sq.x / (float)n, d = mp - mean;
+        m2 += fmaxf(sq.y - sq.x * mp, 0.f) + (float)n * d * d;
+    }
+    mean_out[row] = mean;
+    rstd_out[row] = rsqrtf(m2 / (float)C + eps);
 }
 
 // dx modes
@@ -259,6 +282,15 @@ extern "C" int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const floa
     if (x_dtype == 0) { if (C <= 1024) LNF(float, 4); else if (C <= 2048) LNF(float, 8); else LNF(float, 12); }
     else { if (C <= 1024) LNF(__bf16, 4); else if (C <= 2048) LNF(__bf16, 8); else LNF(__bf16, 12); }
 #undef LNF
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+
+// part [P][M][2] f32 (sum, sum of squares per slice of npp columns; slices past C are ignored) -> mean, rstd [M] of a C-wide LayerNorm.
+extern "C" int cs_ln_stats_finalize(const float* part, int P, int npp, int C, int M, float eps, float* mean, float* rstd, hipStream_t stream) {
+    CS_CHECK_ARG(part && mean && rstd && P > 0 && npp > 0 && C > 0 && M > 0 && (long)P * npp >= C,
+                 "cs_ln_stats_finalize: bad arguments P=%d npp=%d C=%d M=%d", P, npp, C, M);
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, part, P, npp, C, M, eps, mean, rstd);
     CS_LAUNCH_CHECK();
     return 0;
 }

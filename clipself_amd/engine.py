@@ -37,7 +37,7 @@ import torch.nn.functional as F
 from .config import TowerCfg
 
 BF16, F32 = torch.bfloat16, torch.float32
-EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32 = range(6)
+EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32, EPI_RESID_LN_F32 = range(7)
 DX_BF16, DX_F32_ASSIGN, DX_F32_ACCUM = range(3)
 ALIGN = 64
 
@@ -124,6 +124,11 @@ class EvaEngine:
         # encode_image() consumes only the CLS row, so the last block runs its query/proj/MLP for that row alone (keys and
         # values still span all tokens); False runs the last block over every token -- same outputs, ~1/L more work.
         self.cls_only_last_block = True
+        # Frozen towers fold the two sub-LayerNorms (inner_attn_ln ahead of proj, ffn_ln ahead of w3) into the following GEMM:
+        # gamma goes into a bf16 copy of the weight, beta and the row statistics into the GEMM epilogue, and the statistics
+        # come out of the producing kernels' epilogues -- the LN passes over [M,C] and [M,hidden] disappear (_block_post_folded).
+        self.fold_sub_ln = not trainable
+        self.fold = {}
         if trainable:
             self.grad = ops.zeros((self.numel,), F32)
             self.exp_avg = ops.zeros((self.numel,), F32)
@@ -176,6 +181,25 @@ class EvaEngine:
         self._pos_cache.clear()
         if self.trainable:
             self.sync_transposed()
+        if self.fold_sub_ln:
+            self._build_folds()
+
+    def _build_folds(self):
+        """gamma (.) W in bf16, its row sums, and W.beta + b for proj and w3 of every block (one-time, after a weight load)."""
+        cfg, C, Hl = self.cfg, self.cfg.width, self.cfg.hidden
+        self.fold = {}
+        with torch.no_grad():
+            for i in range(cfg.layers):
+                b = f"{self.prefix}blocks.{i}."
+                out = {}
+                for key, wname, ln, bname, K in (("proj", "attn.proj.weight", "attn.inner_attn_ln", "attn.proj.bias", C),
+                                                 ("w3", "mlp.w3.weight", "mlp.ffn_ln", "mlp.w3.bias", Hl)):
+                    W = self.storage_of(self.master, b + wname)                    # [C, K padded]
+                    g, beta = self.p[b + ln + ".weight"][:K], self.p[b + ln + ".bias"][:K]
+                    Wf = torch.zeros_like(W, dtype=BF16)
+                    Wf[:, :K] = (W[:, :K] * g[None, :]).to(BF16)
+                    out[key] = (Wf, Wf.float().sum(dim=1).contiguous(), (W[:, :K] @ beta + self.p[b + bname]).contiguous())
+                self.fold[i] = out
 
     def _wt_alloc(self, key, rows, cols):
         t = self.wt.get(key)
@@ -296,6 +320,13 @@ class EvaEngine:
         ops.layernorm_fwd(x, self.p[b + "norm1.weight"], self.p[b + "norm1.bias"], ln1, m1, r1, eps)
         wqkv, bqkv = self._qkv_w(b)
         qkv = lse = None
+        if with_attn and not keep and inplace and self.fold_sub_ln:
+            qkv = ops.empty((M, 3 * C), BF16)
+            ops.gemm_nt(ln1, wqkv, qkv, bias=bqkv, epi=EPI_BF16)
+            att = ops.empty((M, C), BF16)
+            part = ops.empty((H, M, 2), F32)
+            ops.attn_fwd_stats(qkv, cos, sin, att, None, part, B, N, H, cfg.head_width ** -0.5)
+            return self._block_post_folded(i, b, x, att, part, M)
         if with_attn:
             qkv = ops.empty((M, 3 * C), BF16)
             ops.gemm_nt(ln1, wqkv, qkv, bias=bqkv, epi=EPI_BF16)
@@ -343,6 +374,27 @@ class EvaEngine:
         if keep:
             save.update(iln=iln, st2=(m2, r2), x1=x1, ln2=ln2, st3=(m3, r3), x12=x12, hid=hid, fln=fln, st4=(m4, r4))
         return x2
+
+    def _block_post_folded(self, i, b, x, att, att_part, M):
+        """_block_post for a frozen tower with both sub-LayerNorms folded into proj / w3 (in place on x)."""
+        ops, cfg = self.ops, self.cfg
+        C, Hd, Hl, eps = cfg.width, self.Hp, cfg.hidden, cfg.ln_eps
+        f = self.fold[i]
+        mean, rstd = ops.empty((M,), F32), ops.empty((M,), F32)
+        ops.ln_stats_finalize(att_part, 64, C, mean, rstd, eps)
+        Wp, cp, dp = f["proj"]
+        ops.gemm_nt_ln(att, Wp, x, bias=dp, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=cp, epi=EPI_RESID_LN_F32)
+
+        ln2 = ops.empty((M, C), BF16)
+        ops.layernorm_fwd(x, self.p[b + "norm2.weight"], self.p[b + "norm2.bias"], ln2, None, None, eps)
+        w12, b12 = self._w12(b)
+        hid = ops.empty((M, Hd), BF16)
+        part = ops.empty((4 * ((Hd + 127) // 128), M, 2), F32)
+        ops.gemm_nt_ln(ln2, w12, hid, bias=b12, stats_part=part, epi=EPI_SWIGLU_BF16, group=Hd)
+        ops.ln_stats_finalize(part, 32, Hl, mean, rstd, eps)
+        W3, c3, d3 = f["w3"]
+        ops.gemm_nt_ln(hid, W3, x, bias=d3, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=c3, epi=EPI_RESID_LN_F32)
+        return x
 
     def _block_fwd_cls(self, i, x, B, N, cos, sin):
         """Last teacher block restricted to what encode_image() consumes: the CLS row.  x fp32 [B*N, C] -> fp32 [B, C].

@@ -17,7 +17,7 @@ import torch
 _CSRC = Path(__file__).resolve().parent / "csrc"
 _LIB_PATH = _CSRC / "libclipself_hip.so"
 
-EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32 = range(6)
+EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32, EPI_RESID_LN_F32 = range(7)
 DX_BF16, DX_F32_ASSIGN, DX_F32_ACCUM = range(3)
 
 _vp, _i, _l, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
@@ -26,6 +26,9 @@ _vp, _i, _l, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_fl
 SIGNATURES = {
     "cs_last_error": (ctypes.c_char_p, []),
     "cs_gemm_nt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cs_gemm_nt_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cs_ln_stats_finalize": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "cs_attn_fwd_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_layernorm_fwd": (_i, [_vp, _i, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _vp]),
     "cs_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "cs_layernorm_bwd": (_i, [_vp, _l, _vp, _i, _l, _vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _i, _i, _vp]),
@@ -137,10 +140,35 @@ class HipOps:
         self._ok(self.lib.cs_gemm_nt(_p(A), _p(B), _p(C), _p(bias), _p(extra), M, N, K, A.stride(0), B.stride(0),
                                      C.stride(0), epi, splits, group, flags, self._stream()), "cs_gemm_nt")
 
+    def gemm_nt_ln(self, A, B, C, bias=None, extra=None, ln_mean=None, ln_rstd=None, ln_colsum=None, stats_part=None,
+                   epi=EPI_RESID_LN_F32, group=0, flags=0):
+        self._chk(A, B, C, bias, extra, ln_mean, ln_rstd, ln_colsum, stats_part)
+        M, K = A.shape
+        N = B.shape[0]
+        assert B.shape[1] == K and A.stride(1) == 1 and B.stride(1) == 1 and C.stride(-1) == 1
+        if extra is not None and epi in (EPI_RESID_F32, EPI_RESID_LN_F32):
+            assert extra.stride(0) == C.stride(0), "extra must share C's row stride"
+        if stats_part is not None:
+            assert stats_part.is_contiguous() and stats_part.shape[0] >= 4 * ((group + 127) // 128) and stats_part.shape[1] == M
+        self._ok(self.lib.cs_gemm_nt_ln(_p(A), _p(B), _p(C), _p(bias), _p(extra), _p(ln_mean), _p(ln_rstd), _p(ln_colsum), _p(stats_part),
+                                        M, N, K, A.stride(0), B.stride(0), C.stride(0), epi, 1, group, flags, self._stream()), "cs_gemm_nt_ln")
+
+    def ln_stats_finalize(self, part, npp, C, mean, rstd, eps=1e-6):
+        self._chk(part, mean, rstd)
+        P, M = part.shape[0], part.shape[1]
+        assert part.is_contiguous() and part.shape[2] == 2
+        self._ok(self.lib.cs_ln_stats_finalize(_p(part), P, npp, C, M, eps, _p(mean), _p(rstd), self._stream()), "cs_ln_stats_finalize")
+
+    def attn_fwd_stats(self, qkv, cos, sin, out, lse, stats_part, B, Ntok, H, scale):
+        self._chk(qkv, cos, sin, out, lse, stats_part)
+        assert stats_part.is_contiguous() and tuple(stats_part.shape) == (H, B * Ntok, 2)
+        self._ok(self.lib.cs_attn_fwd_stats(_p(qkv), _p(cos), _p(sin), _p(out), _p(lse), _p(stats_part), B, Ntok, H, qkv.stride(0),
+                                            out.stride(0), scale, self._stream()), "cs_attn_fwd_stats")
+
     def layernorm_fwd(self, x, gamma, beta, y, mean=None, rstd=None, eps=1e-6):
         self._chk(x, gamma, beta, y, mean, rstd)
         M, C = x.shape
-        self._ok(self.lib.cs_layernorm_fwd(_p(x), _dt(x), x.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0),
+        self._ok(self.lib.cs_layernorm_fwd(_p(x), _dt(x), x.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0) if y is not None else 0,
                                            _p(mean), _p(rstd), M, C, eps, self._stream()), "cs_layernorm_fwd")
 
     def layernorm_bwd_workspace(self, M, C) -> int:

@@ -34,11 +34,24 @@ const char* cs_last_error(void);
 int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
                int lda, int ldb, int ldc, int epi, int splits, int group, int flags, cs_stream_t stream);
 
+/* cs_gemm_nt with a sub-LayerNorm folded in (frozen teacher; SwiGLU.ffn_ln eva_vit_model.py:102 ahead of w3, Attention.inner_attn_ln
+ * :218 ahead of proj): the GEMM reads the *un-normalised* bf16 rows, B = gamma (.) W, and
+ *   epi 6: C = extra + ln_rstd[m] * (A.B^T - ln_mean[m] * ln_colsum[n]) + bias[n],  ln_colsum[n] = sum_k B[n,k],  bias = W.beta + b.
+ *   epi 3 with stats_part != NULL additionally writes, per 32-hidden-unit slice s and row m, (sum, sum of squares) of the rounded
+ *          outputs to stats_part[(s*M + m)*2 ..]  (4*ceil(group/128) slices); cs_ln_stats_finalize turns them into mean/rstd.
+ * All other epilogues behave as in cs_gemm_nt (the LN pointers are ignored). */
+int cs_gemm_nt_ln(const void* A, const void* B, void* C, const float* bias, const float* extra, const float* ln_mean,
+                  const float* ln_rstd, const float* ln_colsum, float* stats_part, int M, int N, int K, int lda, int ldb, int ldc,
+                  int epi, int splits, int group, int flags, cs_stream_t stream);
+
 /* --- LayerNorm(eps, biased var): src/open_clip/eva_clip/transformer.py:52-58 used at eva_vit_model.py:306-307 (norm1/2),
  *     :218 (inner_attn_ln), :102 (ffn_ln), :565/:616 (final norm); replaces apex FusedLayerNorm / F.layer_norm.
- * x_dtype 0=f32 1=bf16; y bf16; mean/rstd [M] f32 (nullable when no backward is needed). */
+ * x_dtype 0=f32 1=bf16; y bf16 (NULL = statistics only); mean/rstd [M] f32 (nullable when no backward is needed). */
 int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, void* y, long ldy,
                      float* mean, float* rstd, int M, int C, float eps, cs_stream_t stream);
+/* part [P][M][2] f32 = per-slice (sum, sum of squares) over npp columns each (slices past C ignored) -> LayerNorm mean/rstd [M]
+ * of a C-wide row; producers: cs_gemm_nt_ln epi 3 (npp 32) and cs_attn_fwd_stats (npp 64, P = heads). */
+int cs_ln_stats_finalize(const float* part, int P, int npp, int C, int M, float eps, float* mean, float* rstd, cs_stream_t stream);
 size_t cs_layernorm_bwd_workspace(int M, int C);
 /* dx_mode 0: bf16 write, 1: f32 write, 2: f32 accumulate (residual gradient stream).  dgamma/dbeta nullable (frozen). */
 int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
@@ -60,6 +73,9 @@ int cs_attn_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* o
  * kv [B*Ntok, ldkv] bf16 = k|v; out [B, ldo] bf16. */
 int cs_attn_cls_fwd(const void* q, const void* kv, const float* cos_t, const float* sin_t, void* out, int B, int Ntok, int H,
                     int ldq, int ldkv, int ldo, float scale, cs_stream_t stream);
+/* cs_attn_fwd that also emits stats_part [H][B*Ntok][2] f32 = per head (sum, sum of squares) of each output row's 64 values. */
+int cs_attn_fwd_stats(const void* qkv, const float* cos_t, const float* sin_t, void* out, float* lse, float* stats_part, int B, int Ntok,
+                      int H, int ldqkv, int ldo, float scale, cs_stream_t stream);
 size_t cs_attn_bwd_workspace(int B, int Ntok, int H);
 int cs_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* cos_t, const float* sin_t,
                 void* dqkv, void* workspace, int B, int Ntok, int H, int ldqkv, int ldo, float scale, cs_stream_t stream);

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from .roi_align_ref import roi_align_1x1
 
-EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32 = range(6)
+EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32, EPI_RESID_LN_F32 = range(7)
 DX_BF16, DX_F32_ASSIGN, DX_F32_ACCUM = range(3)
 
 
@@ -74,12 +74,43 @@ class RefOps:
         else:
             raise ValueError(epi)
 
+    def gemm_nt_ln(self, A, B, C, bias=None, extra=None, ln_mean=None, ln_rstd=None, ln_colsum=None, stats_part=None,
+                   epi=EPI_RESID_LN_F32, group=0, flags=0):
+        if epi == EPI_RESID_LN_F32:
+            acc = A.float() @ B.float().T
+            C.copy_(extra + ln_rstd[:, None] * (acc - ln_mean[:, None] * ln_colsum[None, :]) + bias)
+            return
+        self.gemm_nt(A, B, C, bias=bias, extra=extra, epi=epi, group=group)
+        if stats_part is not None:                                 # per 32-column slice (sum, sum of squares) of the rounded outputs
+            assert epi == EPI_SWIGLU_BF16
+            h = C.float()
+            for s in range(stats_part.shape[0]):
+                blk = h[:, 32 * s:32 * s + 32]
+                stats_part[s, :, 0] = blk.sum(-1)
+                stats_part[s, :, 1] = (blk * blk).sum(-1)
+
+    def ln_stats_finalize(self, part, npp, C, mean, rstd, eps=1e-6):
+        P = part.shape[0]
+        keep = [p for p in range(P) if C - p * npp > 0]
+        s = part[keep, :, 0].double().sum(0)
+        q = part[keep, :, 1].double().sum(0)
+        mu = s / C
+        mean.copy_(mu.float())
+        rstd.copy_(torch.rsqrt((q / C - mu * mu).clamp_min(0) + eps).float())
+
+    def attn_fwd_stats(self, qkv, cos, sin, out, lse, stats_part, B, Ntok, H, scale):
+        self.attn_fwd(qkv, cos, sin, out, lse, B, Ntok, H, scale)
+        o = out[:, :H * 64].float().reshape(B * Ntok, H, 64)
+        stats_part[:, :, 0] = o.sum(-1).T
+        stats_part[:, :, 1] = (o * o).sum(-1).T
+
     def layernorm_fwd(self, x, gamma, beta, y, mean=None, rstd=None, eps=1e-6):
         xf = x.float()
         mu = xf.mean(-1, keepdim=True)
         var = ((xf - mu) ** 2).mean(-1, keepdim=True)
         r = torch.rsqrt(var + eps)
-        y.copy_(((xf - mu) * r * gamma + beta).to(torch.bfloat16))
+        if y is not None:
+            y.copy_(((xf - mu) * r * gamma + beta).to(torch.bfloat16))
         if mean is not None:
             mean.copy_(mu[:, 0])
             rstd.copy_(r[:, 0])

@@ -70,12 +70,33 @@ def test_cls_only_last_teacher_block_is_the_same_function(gold):
     cfg = tiny_cfg()
     _, _, crops = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"])
     eng = _engine(cfg, rec["seed_w"], False)
-    assert eng.cls_only_last_block
+    assert eng.cls_only_last_block and eng.fold_sub_ln
+    eng.fold_sub_ln = False                       # isolate the schedule change: identical arithmetic per row
     fast = eng.encode_image(crops.flatten(0, 1), chunk=3)
     eng.cls_only_last_block = False
     full = eng.encode_image(crops.flatten(0, 1), chunk=3)
     assert rel(fast, full) < 1e-6
     assert rel(fast, g["teacher"]) < 2e-2
+
+
+def test_folded_sub_layernorms_match_the_unfolded_teacher(gold):
+    """Frozen towers fold inner_attn_ln / ffn_ln into proj / w3 (gamma into the bf16 weight, statistics from the producers'
+    epilogues).  Same function up to bf16 operand rounding: compared with the unfolded schedule and with the reference golden."""
+    g, rec = gold
+    cfg = tiny_cfg()
+    _, _, crops = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"])
+    eng = _engine(cfg, rec["seed_w"], False)
+    eng.cls_only_last_block = False               # every block through the folded path
+    folded = eng.encode_image(crops.flatten(0, 1), chunk=5)
+    eng.fold_sub_ln = False
+    plain = eng.encode_image(crops.flatten(0, 1), chunk=5)
+    cos = torch.nn.functional.cosine_similarity(folded.double(), plain.double(), dim=-1)
+    assert rel(folded, plain) < 1e-2 and float((1 - cos).max()) < 1e-4
+    assert rel(folded, g["teacher"]) < 2e-2
+    cosg = torch.nn.functional.cosine_similarity(folded.double(), torch.as_tensor(g["teacher"]).double(), dim=-1)
+    assert float((1 - cosg).max()) < 2e-4
+    # the trainable tower never folds (its backward needs the normalised activations)
+    assert not _engine(cfg, rec["seed_w"], True).fold_sub_ln
 
 
 def test_backward_chain_is_the_gradient(gold):

@@ -257,6 +257,80 @@ def test_attention_cls_query(hip, ref, B, Ntok, H, qscale):
     check(tag + ".vs_full_kernel", o_d, full_d.view(B, Ntok, C)[:, 0], 4e-3)
 
 
+# ------------------------------------------------------------------------------------------------ folded sub-LayerNorm pieces
+@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x70, 0x80])
+@pytest.mark.parametrize("Hd,Hl,M", [(2048, 2048, 394), (384, 341, 130), (2752, 2730, 300)])
+def test_gemm_swiglu_stats_finalize_and_folded_w3(hip, ref, Hd, Hl, M, flags):
+    """SwiGLU GEMM that also emits per-slice LayerNorm partials -> cs_ln_stats_finalize -> w3 GEMM with the LayerNorm folded in,
+    against (a) the reference ops of the same three calls and (b) the unfolded chain LN(h) . W3^T on the same inputs."""
+    K, C = 128, 192
+    A, W, bias = rnd((M, K), BF, seed=40), rnd((2 * Hd, K), BF, 0.1, seed=41), rnd((2 * Hd,), F32, 0.5, seed=42)
+    W[Hl:Hd] = 0; W[Hd + Hl:] = 0; bias[Hl:Hd] = 0; bias[Hd + Hl:] = 0           # padded hidden units are exact zeros
+    P = 4 * ((Hd + 127) // 128)
+    h_r, part_r = torch.empty(M, Hd, dtype=BF), torch.zeros(P, M, 2)
+    ref.gemm_nt_ln(A, W, h_r, bias=bias, stats_part=part_r, epi=3, group=Hd)
+    h_d = torch.full((M, Hd), float("nan"), dtype=BF, device="cuda")
+    part_d = torch.full((P, M, 2), float("nan"), device="cuda")
+    hip.gemm_nt_ln(A.cuda(), W.cuda(), h_d, bias=bias.cuda(), stats_part=part_d, epi=3, group=Hd, flags=flags)
+    tag = f"lnfold[{Hd},{Hl},{M}] flags={flags}"
+    check(tag + ".h", h_d, h_r, TOL_BF)
+    mean_r, rstd_r, mean_d, rstd_d = torch.empty(M), torch.empty(M), torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ref.ln_stats_finalize(part_r, 32, Hl, mean_r, rstd_r, 1e-6)
+    hip.ln_stats_finalize(part_d, 32, Hl, mean_d, rstd_d, 1e-6)
+    check(tag + ".mean", mean_d, mean_r, 2e-3)
+    check(tag + ".rstd", rstd_d, rstd_r, 2e-3)
+    # statistics really are those of the rows of h
+    hf = h_d.float().cpu()[:, :Hl]
+    check(tag + ".mean_vs_rows", mean_d, hf.mean(-1), 1e-4)
+    check(tag + ".rstd_vs_rows", rstd_d, torch.rsqrt(hf.var(-1, unbiased=False) + 1e-6), 1e-4)
+    # folded w3
+    g, beta = rnd((Hl,), F32, 0.2, seed=43) + 1.0, rnd((Hl,), F32, 0.1, seed=44)
+    W3, b3, res = rnd((C, Hd), F32, 0.05, seed=45), rnd((C,), F32, seed=46), rnd((M, C), F32, seed=47)
+    W3[:, Hl:] = 0
+    Wf = torch.zeros(C, Hd, dtype=BF)
+    Wf[:, :Hl] = (W3[:, :Hl] * g).to(BF)
+    cs, d = Wf.float().sum(1), W3[:, :Hl] @ beta + b3
+    out_r = torch.empty(M, C)
+    ref.gemm_nt_ln(h_d.cpu(), Wf, out_r, bias=d, extra=res, ln_mean=mean_d.cpu(), ln_rstd=rstd_d.cpu(), ln_colsum=cs)   # same operands as the kernel
+    out_d = res.cuda().clone()
+    hip.gemm_nt_ln(h_d, Wf.cuda(), out_d, bias=d.cuda(), extra=out_d, ln_mean=mean_d, ln_rstd=rstd_d, ln_colsum=cs.cuda(), flags=flags)
+    check(tag + ".out", out_d, out_r, 2e-4)
+    # unfolded chain on the same h: LayerNorm -> bf16 -> GEMM
+    fln = torch.zeros(M, Hd, dtype=BF)
+    gp, bp = torch.zeros(Hd), torch.zeros(Hd)
+    gp[:Hl], bp[:Hl] = g, beta
+    ref.layernorm_fwd(h_r[:, :Hl], gp[:Hl], bp[:Hl], fln[:, :Hl], None, None, 1e-6)
+    plain = torch.empty(M, C)
+    ref.gemm_nt(fln, W3.to(BF), plain, b3, res, epi=2)
+    check(tag + ".vs_unfolded", out_d - res.cuda(), plain - res, 1e-2)
+
+
+@pytest.mark.parametrize("B,Ntok,H", [(3, 197, 12), (2, 577, 16), (4, 17, 2)])
+def test_attention_fwd_stats_and_layernorm_stats_only(hip, ref, B, Ntok, H):
+    C = H * 64
+    qkv = rnd((B * Ntok, 3 * C), BF, 1.0, seed=50)
+    cos, sin = _rope(Ntok, 0)
+    scale = 64 ** -0.5
+    qd, cd, sd = both([qkv, cos, sin])
+    o_plain = torch.empty(B * Ntok, C, dtype=BF, device="cuda")
+    hip.attn_fwd(qd, cd, sd, o_plain, None, B, Ntok, H, scale)
+    o_d = torch.empty_like(o_plain)
+    part = torch.full((H, B * Ntok, 2), float("nan"), device="cuda")
+    hip.attn_fwd_stats(qd, cd, sd, o_d, None, part, B, Ntok, H, scale)
+    assert torch.equal(o_d, o_plain)
+    mean_d, rstd_d = torch.empty(B * Ntok, device="cuda"), torch.empty(B * Ntok, device="cuda")
+    hip.ln_stats_finalize(part, 64, C, mean_d, rstd_d, 1e-6)
+    of = o_d.float().cpu()
+    tag = f"attn_stats[{B},{Ntok},{H}]"
+    check(tag + ".mean", mean_d, of.mean(-1), 2e-4)
+    check(tag + ".rstd", rstd_d, torch.rsqrt(of.var(-1, unbiased=False) + 1e-6), 2e-4)
+    # statistics-only LayerNorm launch (y = NULL) gives the same numbers
+    m2, r2 = torch.empty_like(mean_d), torch.empty_like(rstd_d)
+    hip.layernorm_fwd(o_d, None, None, None, m2, r2, 1e-6)
+    check(tag + ".ln_stats_only.mean", m2, mean_d, 2e-4)
+    check(tag + ".ln_stats_only.rstd", r2, rstd_d, 2e-4)
+
+
 # ------------------------------------------------------------------------------------------------ elementwise
 def test_swiglu_cast_transpose_colsum_im2row(hip, ref):
     M, Hd = 333, 2048
