@@ -52,20 +52,24 @@ class KernelTimer:
 
     def __init__(self, ops, epi, min_rows=0, max_events=4096):
         self.ops, self.epi, self.min_rows, self.on, self.pairs, self.flops = ops, epi, min_rows, False, [], 0.0
-        self._inner = ops.gemm_nt
         self._pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max_events)]
-        ops.gemm_nt = self._wrapped
+        # both entry points of the GEMM (cs_gemm_nt and, with the folded sub-LayerNorm operands, cs_gemm_nt_ln)
+        ops.gemm_nt = self._wrap(ops.gemm_nt)
+        ops.gemm_nt_ln = self._wrap(ops.gemm_nt_ln)
 
-    def _wrapped(self, A, B, C, bias=None, extra=None, epi=0, splits=1, group=0, flags=0):
-        if self.on and epi == self.epi and A.shape[0] >= self.min_rows and len(self.pairs) < len(self._pool):
-            e0, e1 = self._pool[len(self.pairs)]
-            e0.record()
-            self._inner(A, B, C, bias, extra, epi, splits, group, flags)
-            e1.record()
-            self.pairs.append((e0, e1))
-            self.flops += 2.0 * A.shape[0] * B.shape[0] * A.shape[1]
-        else:
-            self._inner(A, B, C, bias, extra, epi, splits, group, flags)
+    def _wrap(self, inner):
+        def wrapped(A, B, C, *args, **kw):
+            epi = kw.get("epi", args[2] if len(args) > 2 and inner.__name__ == "gemm_nt" else None)
+            if self.on and epi == self.epi and A.shape[0] >= self.min_rows and len(self.pairs) < len(self._pool):
+                e0, e1 = self._pool[len(self.pairs)]
+                e0.record()
+                inner(A, B, C, *args, **kw)
+                e1.record()
+                self.pairs.append((e0, e1))
+                self.flops += 2.0 * A.shape[0] * B.shape[0] * A.shape[1]
+            else:
+                inner(A, B, C, *args, **kw)
+        return wrapped
 
     def result(self):
         if not self.pairs:

@@ -248,28 +248,25 @@ __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, c
 __device__ __forceinline__ void store_o(const AttnArgs& p, size_t rowbase, int q, int h, int bh, int hf, float m, float l, const f32x16 (&o)[2]) {
     const float inv = 1.f / l;
     __bf16* orow = p.out + (rowbase + q) * p.ldo + h * HD;
+    float ps = 0.f, pq = 0.f;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             U64 t;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) t.e[i] = f2bf(o[dt][g4 * 4 + i] * inv);
+            for (int i = 0; i < 4; ++i) {
+                t.e[i] = f2bf(o[dt][g4 * 4 + i] * inv);
+                const float r = bf2f(t.e[i]);
+                ps += r;
+                pq += r * r;
+            }
             *(uint2*)(orow + dt * 32 + g4 * 8 + hf * 4) = t.u;
         }
     if (p.lse_out && hf == 0) p.lse_out[(size_t)bh * p.Ntok + q] = m * p.scale + logf(l);
     if (p.stats_part) {
         // (sum, sum of squares) of this row's 64 rounded outputs of head h: the two half-wave lanes of a query hold 32 each.
         // cs_ln_stats_finalize() pools the H heads, so inner_attn_ln needs no pass of its own over the attention output.
-        float ps = 0.f, pq = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float r = bf2f(f2bf(o[dt][e] * inv));
-                ps += r;
-                pq += r * r;
-            }
         ps += __shfl_xor(ps, 32);
         pq += __shfl_xor(pq, 32);
         if (hf == 0) *(float2*)(p.stats_part + ((size_t)h * p.Mtot + rowbase + q) * 2) = make_float2(ps, pq);

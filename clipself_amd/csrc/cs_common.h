@@ -59,6 +59,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// sum over aligned groups of 8 lanes with DPP moves only (no LDS traffic): quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum_lanes8(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    return v;
+}
+
 // MFMA 32x32 accumulator register r of lane l holds C[row][col] with
 //   col = l & 31,  row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)        (cdna_hip_programming.md §3)
 __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

@@ -179,10 +179,10 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                 const float4 t1 = *(const float4*)(p.bias + hcol), t2 = *(const float4*)(p.bias + p.group + hcol);
                 b1[0] = t1.x; b1[1] = t1.y; b1[2] = t1.z; b1[3] = t1.w; b2[0] = t2.x; b2[1] = t2.y; b2[2] = t2.z; b2[3] = t2.w;
             }
+            float ps[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int rl = hr + it * 8, row = row_base + rl;
-                float ps = 0.f, pq = 0.f;
                 if (colok && row < p.M) {
                     const float4 x1 = *(const float4*)(slab + rl * EP_LD + hc), x2 = *(const float4*)(slab + rl * EP_LD + 32 + hc);
                     const float u[4] = {x1.x + b1[0], x1.y + b1[1], x1.z + b1[2], x1.w + b1[3]};
@@ -192,21 +192,27 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                     for (int t = 0; t < 4; ++t) {    // silu(u)*v with the hardware exp2/rcp (1 ulp each; the result is rounded to bf16)
                         o.e[t] = f2bf(u[t] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u[t])) * v[t]);
                         const float r = bf2f(o.e[t]);
-                        ps += r;
-                        pq += r * r;
+                        ps[it] += r;
+                        pq[it] += r * r;
                     }
                     *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + hcol) = o.u;
                 }
-                if (p.stats_part) {
-                    // LayerNorm statistics of the rounded outputs, reduced over the 8 lanes (32 hidden units) of this row slice;
-                    // cs_ln_stats_finalize() combines the slices, so the sub-LN pass over the hidden matrix disappears.
-                    ps += __shfl_xor(ps, 1); pq += __shfl_xor(pq, 1);
-                    ps += __shfl_xor(ps, 2); pq += __shfl_xor(pq, 2);
-                    ps += __shfl_xor(ps, 4); pq += __shfl_xor(pq, 4);
-                    if ((lane & 7) == 0 && row < p.M) {
-                        const size_t slice = (size_t)tn * (BN / 64) + wn;
-                        *(float2*)(p.stats_part + (slice * p.M + row) * 2) = make_float2(ps, pq);
-                    }
+            }
+            if (p.stats_part) {
+                // LayerNorm statistics of the rounded outputs: each row's 32 hidden units of this slice sit in 8 adjacent lanes
+                // (DPP butterfly, every lane ends with the sum); lane (lane & 7) == it keeps iteration it's row, so the 32 rows of
+                // the block leave in ONE 256-byte store.  cs_ln_stats_finalize() pools the slices: no sub-LN pass over the hidden matrix.
+                const int sel = lane & 7;
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const float a = sum_lanes8(ps[it]), b = sum_lanes8(pq[it]);
+                    if (sel == it) { s = a; q = b; }
+                }
+                const int row = row_base + hr + sel * 8;
+                if (sel < 4 && row < p.M) {
+                    const size_t slice = (size_t)tn * (BN / 64) + wn;
+                    *(float2*)(p.stats_part + (slice * p.M + row) * 2) = make_float2(s, q);
                 }
             }
         } else {

@@ -82,25 +82,35 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, l
 
 // Combine per-slice (sum, sum of squares) partials -- written by the SwiGLU GEMM epilogue (32 columns per slice) or the attention
 // forward (64 per head) -- into LayerNorm mean / rstd per row.  Slice p covers columns [p*npp, min((p+1)*npp, C)); the pooled
-// variance uses each slice's own centred second moment (Chan et al.), so nothing cancels against a large row mean.
+// variance = sum of the slices' own centred second moments + the spread of the slice means about the row mean (Chan et al.).
 __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, int P, int npp, int C, int M, float eps,
                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= M) return;
-    float tot = 0.f;
-    for (int p = 0; p < P; ++p)
-        if (C - p * npp > 0) tot += part[((size_t)p * M + row) * 2];
-    const float mean = tot / (float)C;
-    float m2 = 0.f;
-    for (int p = 0; p < P; ++p) {
+    // 64 rows per workgroup; the four waves split the slices, one coalesced 512-byte read per (slice, wave)
+    __shared__ float red[3][64][3];
+    const int r = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = min(blockIdx.x * 64 + r, M - 1);
+    float s = 0.f, q = 0.f, b = 0.f;                  // sum, within-slice centred squares, sum of s_p^2 / n_p
+    for (int p = w; p < P; p += 4) {
         const int n = min(npp, C - p * npp);
-        if (n <= 0) continue;
+        if (n <= 0) break;
         const float2 sq = *(const float2*)(part + ((size_t)p * M + row) * 2);
-        const float mp = sq.x / (float)n, d = mp - mean;
-        m2 += fmaxf(sq.y - sq.x * mp, 0.f) + (float)n * d * d;
+        const float t = sq.x * sq.x / (float)n;
+        s += sq.x;
+        q += fmaxf(sq.y - t, 0.f);
+        b += t;
     }
-    mean_out[row] = mean;
-    rstd_out[row] = rsqrtf(m2 / (float)C + eps);
+    if (w > 0) { red[w - 1][r][0] = s; red[w - 1][r][1] = q; red[w - 1][r][2] = b; }
+    __syncthreads();
+    if (w == 0 && blockIdx.x * 64 + r < M) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { s += red[i][r][0]; q += red[i][r][1]; b += red[i][r][2]; }
+        const float mean = s / (float)C;
+        // pooled variance = within-slice part + between-slice part; only the latter (slice means against the row mean) can
+        // cancel, and it is a small share of the total unless the row mean dwarfs the row's spread
+        const float m2 = q + fmaxf(b - s * mean, 0.f);
+        mean_out[row] = mean;
+        rstd_out[row] = rsqrtf(m2 / (float)C + eps);
+    }
 }
 
 // dx modes
@@ -290,7 +300,7 @@ extern "C" int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const floa
 extern "C" int cs_ln_stats_finalize(const float* part, int P, int npp, int C, int M, float eps, float* mean, float* rstd, hipStream_t stream) {
     CS_CHECK_ARG(part && mean && rstd && P > 0 && npp > 0 && C > 0 && M > 0 && (long)P * npp >= C,
                  "cs_ln_stats_finalize: bad arguments P=%d npp=%d C=%d M=%d", P, npp, C, M);
-    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, part, P, npp, C, M, eps, mean, rstd);
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 63) / 64), dim3(256), 0, stream, part, P, npp, C, M, eps, mean, rstd);
     CS_LAUNCH_CHECK();
     return 0;
 }

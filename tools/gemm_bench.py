@@ -55,5 +55,50 @@ def main():
             print(f"   ping-pong vs lockstep bitwise mismatches in 20 runs: {bad}", flush=True)
 
 
+
+def fold_ab():
+    """A/B of the folded-LayerNorm operands: SwiGLU GEMM with / without the statistics output, residual GEMM with / without the
+    folded epilogue, and the finalize kernel (usage: python tools/gemm_bench.py 512 fold)."""
+    ops = HipOps()
+    crops = int(sys.argv[1])
+    M = crops * 197
+
+    def timeit(fn, n=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+
+    A = torch.randn(M, 768, device="cuda").to(BF)
+    W = (torch.randn(4096, 768, device="cuda") * 0.05).to(BF)
+    bias = torch.randn(4096, device="cuda")
+    hid = torch.empty(M, 2048, dtype=BF, device="cuda")
+    part = torch.empty(64, M, 2, device="cuda")
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    for rep in range(2):
+        t0 = timeit(lambda: ops.gemm_nt(A, W, hid, bias, epi=3, group=2048))
+        t1 = timeit(lambda: ops.gemm_nt_ln(A, W, hid, bias=bias, stats_part=part, epi=3, group=2048))
+        t2 = timeit(lambda: ops.ln_stats_finalize(part, 32, 2048, mean, rstd))
+        print(f"w12 swiglu: plain {t0:7.1f} us | +stats {t1:7.1f} us | finalize(64 slices) {t2:6.1f} us", flush=True)
+    W3 = (torch.randn(768, 2048, device="cuda") * 0.05).to(BF)
+    x = torch.randn(M, 768, device="cuda")
+    b3, cs = torch.randn(768, device="cuda"), torch.randn(768, device="cuda")
+    ln_out = torch.empty(M, 2048, dtype=BF, device="cuda")
+    g, be = torch.ones(2048, device="cuda"), torch.zeros(2048, device="cuda")
+    for rep in range(2):
+        t0 = timeit(lambda: ops.gemm_nt(hid, W3, x, b3, x, epi=2))
+        t1 = timeit(lambda: ops.gemm_nt_ln(hid, W3, x, bias=b3, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=cs))
+        t2 = timeit(lambda: ops.layernorm_fwd(hid, g, be, ln_out))
+        print(f"w3 resid: plain {t0:7.1f} us | folded-LN epilogue {t1:7.1f} us | the LayerNorm pass it replaces {t2:6.1f} us", flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[2] == "fold":
+        fold_ab()
+    else:
+        main()
