@@ -126,12 +126,137 @@ __device__ __forceinline__ void source_rows(const GemmArgs& p, int wave, int lan
 constexpr int EP_LD = 68;                       // fp32 row stride of the epilogue slab (64 + 4 pad)
 constexpr int EP_BYTES = 32 * EP_LD * 4;        // 32 rows per wave slab
 
+// Fused SwiGLU epilogue.  x1 and x2 of a hidden unit sit in the same lane and register of accumulator column-tiles j = 0 / 1, so
+// silu(x1 + b1) * (x2 + b2) is formed in registers; two vertically adjacent results (accumulator registers e, e+1 = rows r, r+1)
+// are packed into one bf16x2 word and only that -- 8 ds_write_b32 and 2 ds_read_b128 per 32x32 block instead of 32 and 8 --
+// goes through the wave-private slab [16 row pairs][32 columns] to become 8-byte row-contiguous global stores.
+template <int FM, int BN>
+__device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, const f32x16 (&acc)[FM][2], char* smem, int wave, int lane, int row0,
+                                                int tn, int wn) {
+    const int l31 = lane & 31, hf = lane >> 5;
+    uint32_t* slab = (uint32_t*)(smem + wave * EP_BYTES);
+    const int hbase = tn * (BN / 2) + wn * 32;
+    const int hl = hbase + l31;
+    float b1 = 0.f, b2 = 0.f;
+    if (p.bias && hl < p.group) { b1 = p.bias[hl]; b2 = p.bias[p.group + hl]; }
+    const int c4 = lane & 7, hcol = hbase + c4 * 4;
+    const bool colok = hcol < p.group;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            float h[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {        // hardware exp2/rcp (1 ulp each; the result is rounded to bf16)
+                const float u = acc[i][0][e + t] + b1, v = acc[i][1][e + t] + b2;
+                h[t] = u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u)) * v;
+            }
+            union { bf16x2 v; uint32_t u; } pk;
+            pk.v[0] = f2bf(h[0]);
+            pk.v[1] = f2bf(h[1]);
+            const int rp = ((e & 3) >> 1) + 4 * (e >> 2) + 2 * hf;        // rows 2rp, 2rp+1 of the block
+            slab[rp * 32 + l31] = pk.u;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int row_base = row0 + i * 32;
+        float ps[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int rp = (lane >> 3) + 8 * k;
+            const uint4 w = *(const uint4*)(slab + rp * 32 + c4 * 4);
+            const uint2 lo = make_uint2((w.x & 0xffffu) | (w.y << 16), (w.z & 0xffffu) | (w.w << 16));
+            const uint2 hi = make_uint2((w.x >> 16) | (w.y & 0xffff0000u), (w.z >> 16) | (w.w & 0xffff0000u));
+            const int ra = row_base + 2 * rp;
+            if (colok && ra < p.M) *(uint2*)((__bf16*)p.C + (size_t)ra * p.ldc + hcol) = lo;
+            if (colok && ra + 1 < p.M) *(uint2*)((__bf16*)p.C + (size_t)(ra + 1) * p.ldc + hcol) = hi;
+            if (p.stats_part && colok) {
+                const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float a = __uint_as_float(ws[t] << 16), b = __uint_as_float(ws[t] & 0xffff0000u);
+                    ps[2 * k] += a; pq[2 * k] += a * a;
+                    ps[2 * k + 1] += b; pq[2 * k + 1] += b * b;
+                }
+            }
+        }
+        if (p.stats_part) {
+            // LayerNorm statistics of the rounded outputs: a row's 32 hidden units of this slice sit in 8 adjacent lanes (DPP
+            // butterfly, every lane ends with the sum); lane (lane & 7) == j keeps row-partial j, so the 32 rows of the block
+            // leave in ONE 256-byte store.  cs_ln_stats_finalize() pools the slices: no sub-LN pass over the hidden matrix.
+            const int sel = lane & 7;
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = sum_lanes8(ps[j]), b = sum_lanes8(pq[j]);
+                if (sel == j) { sv = a; qv = b; }
+            }
+            const int row = row_base + 2 * ((lane >> 3) + 8 * (sel >> 1)) + (sel & 1);
+            if (sel < 4 && row < p.M) {
+                const size_t slice = (size_t)tn * (BN / 64) + wn;
+                *(float2*)(p.stats_part + (slice * p.M + row) * 2) = make_float2(sv, qv);
+            }
+        }
+        if (i + 1 < FM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next block rewrites it
+    }
+}
+
+// bf16 output epilogue (acc + bias): like epilogue_swiglu, vertically adjacent results are packed into bf16x2 words in registers, so
+// the wave-private slab [16 row pairs][64 columns] sees 16 ds_write_b32 + 4 ds_read_b128 per 32x64 block instead of 32 + 8.
+template <int FM, int BN>
+__device__ __forceinline__ void epilogue_bf16(const GemmArgs& p, const f32x16 (&acc)[FM][2], char* smem, int wave, int lane, int row0,
+                                              int n0, int wn) {
+    const int l31 = lane & 31, hf = lane >> 5;
+    uint32_t* slab = (uint32_t*)(smem + wave * EP_BYTES);
+    float bj[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = n0 + wn * 64 + j * 32 + l31;
+        if (p.bias && c < p.N) bj[j] = p.bias[c];
+    }
+    const int c4 = lane & 15, col = n0 + wn * 64 + c4 * 4;
+    const bool colok = col < p.N;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                union { bf16x2 v; uint32_t u; } pk;
+                pk.v[0] = f2bf(acc[i][j][e] + bj[j]);
+                pk.v[1] = f2bf(acc[i][j][e + 1] + bj[j]);
+                const int rp = ((e & 3) >> 1) + 4 * (e >> 2) + 2 * hf;
+                slab[rp * 64 + j * 32 + l31] = pk.u;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int row_base = row0 + i * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int rp = (lane >> 4) + 4 * k;
+            const uint4 w = *(const uint4*)(slab + rp * 64 + c4 * 4);
+            const uint2 lo = make_uint2((w.x & 0xffffu) | (w.y << 16), (w.z & 0xffffu) | (w.w << 16));
+            const uint2 hi = make_uint2((w.x >> 16) | (w.y & 0xffff0000u), (w.z >> 16) | (w.w & 0xffff0000u));
+            const int ra = row_base + 2 * rp;
+            if (colok && ra < p.M) *(uint2*)((__bf16*)p.C + (size_t)ra * p.ldc + col) = lo;
+            if (colok && ra + 1 < p.M) *(uint2*)((__bf16*)p.C + (size_t)(ra + 1) * p.ldc + col) = hi;
+        }
+        if (i + 1 < FM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 // Epilogue through a wave-private LDS slab [32][EP_LD] fp32.  The slab is wave-private and a wave's DS operations execute in
 // order, so no workgroup barrier is needed inside (a __syncthreads() would also wait for every outstanding global store).
 template <int EPI, int FM, int FN, int BN>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[FM][FN], char* smem, int wave, int lane, int row0,
                                          int n0, int tn, int wn) {
     static_assert(FN == 2, "epilogue assumes 64-column wave tiles");
+    if (EPI == EPI_SWIGLU_BF16) {
+        epilogue_swiglu<FM, BN>(p, acc, smem, wave, lane, row0, tn, wn);
+        return;
+    }
+    if (EPI == EPI_BF16) {
+        epilogue_bf16<FM, BN>(p, acc, smem, wave, lane, row0, n0, wn);
+        return;
+    }
     const int l31 = lane & 31;
     float* slab = (float*)(smem + wave * EP_BYTES);
     const int rrow = lane >> 4, rcol = (lane & 15) * 4;  // read-out: 16 lanes per row, 4 consecutive columns per lane
@@ -169,53 +294,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
 #pragma unroll
             for (int e = 0; e < 16; ++e) slab[mfma32_row(e, lane) * EP_LD + j * 32 + l31] = acc[i][j][e];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (EPI == EPI_SWIGLU_BF16) {
-            // slab columns [0,32) = x1, [32,64) = x2 of hidden units hcol .. ; 8 lanes per row, 4 hidden units per lane
-            const int hr = lane >> 3, hc = (lane & 7) * 4;
-            const int hcol = tn * (BN / 2) + wn * 32 + hc;
-            const bool colok = hcol < p.group;
-            float b1[4] = {0, 0, 0, 0}, b2[4] = {0, 0, 0, 0};
-            if (colok && p.bias) {
-                const float4 t1 = *(const float4*)(p.bias + hcol), t2 = *(const float4*)(p.bias + p.group + hcol);
-                b1[0] = t1.x; b1[1] = t1.y; b1[2] = t1.z; b1[3] = t1.w; b2[0] = t2.x; b2[1] = t2.y; b2[2] = t2.z; b2[3] = t2.w;
-            }
-            float ps[4] = {0, 0, 0, 0}, pq[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int rl = hr + it * 8, row = row_base + rl;
-                if (colok && row < p.M) {
-                    const float4 x1 = *(const float4*)(slab + rl * EP_LD + hc), x2 = *(const float4*)(slab + rl * EP_LD + 32 + hc);
-                    const float u[4] = {x1.x + b1[0], x1.y + b1[1], x1.z + b1[2], x1.w + b1[3]};
-                    const float v[4] = {x2.x + b2[0], x2.y + b2[1], x2.z + b2[2], x2.w + b2[3]};
-                    U64 o;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {    // silu(u)*v with the hardware exp2/rcp (1 ulp each; the result is rounded to bf16)
-                        o.e[t] = f2bf(u[t] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u[t])) * v[t]);
-                        const float r = bf2f(o.e[t]);
-                        ps[it] += r;
-                        pq[it] += r * r;
-                    }
-                    *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + hcol) = o.u;
-                }
-            }
-            if (p.stats_part) {
-                // LayerNorm statistics of the rounded outputs: each row's 32 hidden units of this slice sit in 8 adjacent lanes
-                // (DPP butterfly, every lane ends with the sum); lane (lane & 7) == it keeps iteration it's row, so the 32 rows of
-                // the block leave in ONE 256-byte store.  cs_ln_stats_finalize() pools the slices: no sub-LN pass over the hidden matrix.
-                const int sel = lane & 7;
-                float s = 0.f, q = 0.f;
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const float a = sum_lanes8(ps[it]), b = sum_lanes8(pq[it]);
-                    if (sel == it) { s = a; q = b; }
-                }
-                const int row = row_base + hr + sel * 8;
-                if (sel < 4 && row < p.M) {
-                    const size_t slice = (size_t)tn * (BN / 64) + wn;
-                    *(float2*)(p.stats_part + (slice * p.M + row) * 2) = make_float2(s, q);
-                }
-            }
-        } else {
+        {
             if (col < p.N) {
                 float bv[4] = {0, 0, 0, 0};
                 if (p.bias) { const float4 t = *(const float4*)(p.bias + col); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
@@ -233,12 +312,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                         v[0] = rs * (s.x - mu * cs[0]) + bv[0]; v[1] = rs * (s.y - mu * cs[1]) + bv[1];
                         v[2] = rs * (s.z - mu * cs[2]) + bv[2]; v[3] = rs * (s.w - mu * cs[3]) + bv[3];
                     }
-                    if (EPI == EPI_BF16) {
-                        U64 o;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) o.e[t] = f2bf(v[t]);
-                        *(uint2*)((__bf16*)p.C + (size_t)row * p.ldc + col) = o.u;
-                    } else if (EPI == EPI_F32) {
+                    if (EPI == EPI_F32) {
                         *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                     } else if (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
                         const float4 x = xin[it];
@@ -333,10 +407,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();     // tile kt landed everywhere; tile kt-1's buffers (A slot (kt+2)%3, B slot (kt+1)&1) are free
             const int i = kt - kt_begin;
-            if (kt + 1 < kt_end)
-                stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 1) * BK, b_ring + ((i + 1) & 1) * B_BYTES, wave * B_INSTR, lane, brow, bchk);
-            if (kt + 2 < kt_end)
-                stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 2) * BK, smem + ((i + 2) % 3) * A_BYTES, wave * A_INSTR, lane, arow, achk);
+            if (!(A_INSTR == 4 && B_INSTR == 4) || (p.dbg & 8)) {     // burst issue (dbg bit 3 = A/B switch); default: interleaved below
+                if (kt + 1 < kt_end)
+                    stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 1) * BK, b_ring + ((i + 1) & 1) * B_BYTES, wave * B_INSTR, lane, brow, bchk);
+                if (kt + 2 < kt_end)
+                    stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 2) * BK, smem + ((i + 2) % 3) * A_BYTES, wave * A_INSTR, lane, arow, achk);
+            }
         } else if (NS == 3) {
             // Counted wait: tile kt (older) must have landed, tile kt+1 (A_INSTR+B_INSTR newer DMA ops of this wave) may stay
             // in flight across the barrier.  Raw s_barrier: __syncthreads() would drain the DMA queue (vmcnt(0)).
@@ -388,6 +464,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
             for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(la + i * (16 * 256) + off);
 #pragma unroll
             for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(lb + j * (16 * 256) + off);
+            if (AB && A_INSTR == 4 && B_INSTR == 4 && !(p.dbg & 8)) {
+                // the 8 DMA pieces of this iteration are issued two per k-step, in the shadow of the MFMAs, instead of in one burst
+                // behind the barrier (+1..3 %; same issue order: B(kt+1) first, then A(kt+2))
+                const int i0 = kt - kt_begin;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int x = (ks & 1) * 2 + h2;
+                    if (ks < 2) {
+                        if (kt + 1 < kt_end) {
+                            const int r1[1] = {brow[x]}, c1[1] = {bchk[x]};
+                            stage_tile<1, GLDS>(p.B, p.ldb, (kt + 1) * BK, b_ring + ((i0 + 1) & 1) * B_BYTES, wave * B_INSTR + x, lane, r1, c1);
+                        }
+                    } else if (kt + 2 < kt_end) {
+                        const int r1[1] = {arow[x]}, c1[1] = {achk[x]};
+                        stage_tile<1, GLDS>(p.A, p.lda, (kt + 2) * BK, smem + ((i0 + 2) % 3) * A_BYTES, wave * A_INSTR + x, lane, r1, c1);
+                    }
+                }
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -705,7 +799,8 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 //                 5 = 256x256 ping-pong, 6 = 256x256 lockstep + L2 warm-up, 7 = 256x256 split rings A3/B2,
 //                 8 = 256x128 K-32 ring, two workgroups per CU; 0 = heuristic)
 //       bits 8-11: raster group height override (0 = 8)
-//       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue
+//       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue;
+//       bit 15: split-ring schedule issues its DMA in one burst behind the barrier instead of interleaved with the MFMAs
 static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias, const float* extra, const float* ln_mean,
                         const float* ln_rstd, const float* ln_colsum, float* stats_part, int M, int N, int K, int lda, int ldb, int ldc,
                         int epi, int splits, int group, int flags, hipStream_t stream) {
@@ -731,7 +826,7 @@ static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias
     a.ktiles_per_split = K / BK;
     const int glds = (flags & 1) ? 0 : 1;
     const int force = (flags >> 4) & 15;
-    a.dbg = (flags >> 12) & 7;
+    a.dbg = (flags >> 12) & 15;
     CS_CHECK_ARG(!(force == 5 && !glds), "cs_gemm_nt: the ping-pong schedule only exists with LDS-DMA staging");
     switch (epi) {
         case EPI_BF16: return launch<EPI_BF16>(a, splits, glds, force, stream);
