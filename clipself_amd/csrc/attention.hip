@@ -43,6 +43,28 @@ __device__ __forceinline__ void rope8(U128& v, const float* __restrict__ cs, con
     }
 }
 
+// The reference builds its tables separably (rope.py:118-142: row-angle part for dims [0,32), column-angle part for [32,64), the
+// same for every token of a grid row / column), so a workgroup needs only 4 x [g][32] floats of the [g*g][64] tables.  rt holds
+// cos_row | sin_row | cos_col | sin_col; dims chunk c8 (8 dims) of token tok >= 1 is rotated from LDS instead of re-reading
+// 64 bytes of table per 16 bytes of q/k from L2 (that re-read was two thirds of the forward kernel's vector-memory traffic).
+__device__ __forceinline__ void rope8_lds(U128& v, const float* rt, int g, float inv_g, int tok, int c8) {
+    const int t = tok - 1;
+    const int r = (int)(((float)t + 0.5f) * inv_g), c = t - r * g;
+    const float* cs = rt + ((c8 < 4 ? r : 2 * g + c) << 5) + (c8 & 3) * 8;
+    rope8(v, cs, cs + (g << 5));
+}
+
+template <int NT>
+__device__ __forceinline__ void load_rope_tables(float* rt, const float* __restrict__ cos_t, const float* __restrict__ sin_t, int g, int tid) {
+    for (int i = tid; i < g * 32; i += NT) {
+        const int r = i >> 5, d = i & 31;
+        rt[i] = cos_t[(size_t)(r * g) * HD + d];
+        rt[(g << 5) + i] = sin_t[(size_t)(r * g) * HD + d];
+        rt[(2 * g << 5) + i] = cos_t[(size_t)r * HD + 32 + d];
+        rt[(3 * g << 5) + i] = sin_t[(size_t)r * HD + 32 + d];
+    }
+}
+
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int c2) {
     bf16x8 r;
 #pragma unroll
@@ -68,6 +90,8 @@ struct AttnArgs {
     const float* sin_t;
     const float* lse_in;   // bwd: [B*H, N]
     const float* dsum;     // bwd: rowsum(dO*O) [B*H, N]
+    int grid;              // fwd: token grid side g (Ntok = g*g + 1)
+    float inv_grid;
     float* stats_part;     // fwd, optional: [H][B*N][2] per-head (sum, sum of squares) of the output rows
     long Mtot;             // B*N
     __bf16* out;           // fwd: O [B*N, ldo] ; bwd: dqkv [B*N, ldqkv]
@@ -113,7 +137,7 @@ __device__ __forceinline__ int k_off(int r, int c) { return ((r >> 1) << 8) + ((
 
 template <int CHK, int NT>
 __device__ __forceinline__ void stage_k(const __bf16* __restrict__ src, size_t rowbase, int ld, int coloff, int tok0, int Ntok,
-                                        const float* cos_t, const float* sin_t, char* tile, int tid) {
+                                        const float* rt, int g, float inv_g, char* tile, int tid) {
     constexpr int ITEMS = (CHK * 8 + NT - 1) / NT;
     U128 v[ITEMS];
 #pragma unroll
@@ -126,7 +150,7 @@ __device__ __forceinline__ void stage_k(const __bf16* __restrict__ src, size_t r
     for (int it = 0; it < ITEMS; ++it) {
         const int idx = tid + it * NT, r = idx >> 3, c = idx & 7, tok = tok0 + r;
         if (idx < CHK * 8) {
-            if (tok > 0 && tok < Ntok) rope8(v[it], cos_t + (size_t)(tok - 1) * HD + c * 8, sin_t + (size_t)(tok - 1) * HD + c * 8);
+            if (tok > 0 && tok < Ntok) rope8_lds(v[it], rt, g, inv_g, tok, c);
             *(uint4*)(tile + k_off(r, c)) = v[it].u;
         }
     }
@@ -171,14 +195,14 @@ __device__ __forceinline__ bf16x8 pack8_swapped(const f32x16& a, int c2) {
     return out.v;
 }
 
-__device__ __forceinline__ void load_q_frags(const AttnArgs& p, size_t rowbase, int qc, int h, int hf, bf16x8 (&qf)[4]) {
+__device__ __forceinline__ void load_q_frags(const AttnArgs& p, const float* rt, size_t rowbase, int qc, int h, int hf, bf16x8 (&qf)[4]) {
+    U128 t[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) t[ks].u = *(const uint4*)(p.qkv + (rowbase + qc) * p.ldqkv + h * HD + ks * 16 + hf * 8);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const int d0 = ks * 16 + hf * 8;
-        U128 t;
-        t.u = *(const uint4*)(p.qkv + (rowbase + qc) * p.ldqkv + h * HD + d0);
-        if (qc > 0) rope8(t, p.cos_t + (size_t)(qc - 1) * HD + d0, p.sin_t + (size_t)(qc - 1) * HD + d0);
-        qf[ks] = t.h;
+        if (qc > 0) rope8_lds(t[ks], rt, p.grid, p.inv_grid, qc, ks * 2 + hf);
+        qf[ks] = t[ks].h;
     }
 }
 
@@ -282,6 +306,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kl = smem;
     __bf16* Vt = (__bf16*)(smem + CHK * 128);
+    float* rt = (float*)(smem + CHK * 128 + HD * VT_LD * 2);      // compact RoPE tables [4][g][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
@@ -293,13 +318,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
     if (QTW == 1) {
         const int q0 = q_wg + wave * 32, q = q0 + l31, qc = min(q, p.Ntok - 1);
         const bool active = q0 < p.Ntok;
+        load_rope_tables<NT>(rt, p.cos_t, p.sin_t, p.grid, tid);
+        __syncthreads();
         bf16x8 qf[4];
-        load_q_frags(p, rowbase, qc, h, hf, qf);
+        load_q_frags(p, rt, rowbase, qc, h, hf, qf);
         float m = -INFINITY, l = 0.f;
         f32x16 o[2] = {zero16(), zero16()};
         for (int key0 = 0; key0 < p.Ntok; key0 += CHK) {
             __syncthreads();
-            stage_k<CHK, NT>(p.qkv, rowbase, p.ldqkv, C + h * HD, key0, p.Ntok, p.cos_t, p.sin_t, Kl, tid);
+            stage_k<CHK, NT>(p.qkv, rowbase, p.ldqkv, C + h * HD, key0, p.Ntok, rt, p.grid, p.inv_grid, Kl, tid);
             stage_vt<CHK, NT>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0, p.Ntok, Vt, tid);
             __syncthreads();
             if (active) attend_chunk<CH>(Kl, Vt, qf, key0, p.Ntok, sl2, lane, key0 == 0, m, l, o);
@@ -334,12 +361,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
             for (int ks = 0; ks < 4; ++ks)
                 qraw[j][ks].u = *(const uint4*)(p.qkv + (rowbase + qcs[j]) * p.ldqkv + h * HD + ks * 16 + hf * 8);
         }
+        load_rope_tables<NT>(rt, p.cos_t, p.sin_t, p.grid, tid);
+        __syncthreads();
         // K: rotate + swizzled LDS image
 #pragma unroll
         for (int it = 0; it < KI; ++it) {
             const int idx = tid + it * NT, r = idx >> 3, c = idx & 7;
             if (idx < CHK * 8) {
-                if (r > 0 && r < p.Ntok) rope8(kr[it], p.cos_t + (size_t)(r - 1) * HD + c * 8, p.sin_t + (size_t)(r - 1) * HD + c * 8);
+                if (r > 0 && r < p.Ntok) rope8_lds(kr[it], rt, p.grid, p.inv_grid, r, c);
                 *(uint4*)(Kl + k_off(r, c)) = kr[it].u;
             }
         }
@@ -363,8 +392,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
                 bf16x8 qf[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const int d0 = ks * 16 + hf * 8;
-                    if (qc > 0) rope8(qraw[j][ks], p.cos_t + (size_t)(qc - 1) * HD + d0, p.sin_t + (size_t)(qc - 1) * HD + d0);
+                    if (qc > 0) rope8_lds(qraw[j][ks], rt, p.grid, p.inv_grid, qc, ks * 2 + hf);
                     qf[ks] = qraw[j][ks].h;
                 }
                 float m = -INFINITY, l = 0.f;
@@ -691,16 +719,20 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
     AttnArgs a{};
     a.qkv = (const __bf16*)qkv; a.cos_t = cos_t; a.sin_t = sin_t; a.out = (__bf16*)out; a.lse_out = lse;
     a.stats_part = stats_part; a.Mtot = (long)B * Ntok;
+    int g = (int)(sqrtf((float)(Ntok - 1)) + 0.5f);
+    CS_CHECK_ARG(g * g == Ntok - 1, "cs_attn_fwd: Ntok - 1 = %d is not a square token grid (the RoPE tables are read separably)", Ntok - 1);
+    a.grid = g; a.inv_grid = 1.f / (float)g;
     a.Ntok = Ntok; a.H = H; a.ldqkv = ldqkv; a.ldo = ldo; a.scale = scale;
     constexpr int CH = 7;
-    const size_t lds = (size_t)CH * 32 * 128 + (size_t)HD * VT_LD * 2;
+    const size_t lds = (size_t)CH * 32 * 128 + (size_t)HD * VT_LD * 2 + (size_t)4 * g * 32 * sizeof(float);
+    CS_CHECK_ARG(lds <= 160 * 1024, "cs_attn_fwd: token grid %d too large for the LDS RoPE tables", g);
     if (Ntok <= CH * 32) {
         // whole sequence in one key chunk: 4-wave workgroups, 2 query tiles per wave, 2 workgroups per CU
-        static bool once = (set_lds(attn_fwd_kernel<CH, 4, 2>, lds), true);
+        static bool once = (set_lds(attn_fwd_kernel<CH, 4, 2>, 160 * 1024), true);
         (void)once;
         hipLaunchKernelGGL((attn_fwd_kernel<CH, 4, 2>), dim3((Ntok + 255) / 256, B * H), dim3(256), lds, stream, a);
     } else {
-        static bool once = (set_lds(attn_fwd_kernel<CH, 8, 1>, lds), true);
+        static bool once = (set_lds(attn_fwd_kernel<CH, 8, 1>, 160 * 1024), true);
         (void)once;
         hipLaunchKernelGGL((attn_fwd_kernel<CH, 8, 1>), dim3((Ntok + 255) / 256, B * H), dim3(512), lds, stream, a);
     }

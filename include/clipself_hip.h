@@ -65,7 +65,9 @@ int cs_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, void* 
 /* --- attention core: xops.memory_efficient_attention / softmax math branch at eva_vit_model.py:198-243 together with
  *     VisionRotaryEmbeddingFast.forward (src/open_clip/eva_clip/rope.py:148-164) on q,k tokens 1.. ; head dim 64.
  * qkv [B*Ntok, ldqkv] bf16 = q|k|v (bias added, not rotated); cos/sin [(Ntok-1),64] f32; out [B*Ntok, ldo] bf16;
- * lse [B*H, Ntok] f32 (nullable in inference). */
+ * lse [B*H, Ntok] f32 (nullable in inference).  The forward kernels read the tables separably, exactly as rope.py:118-142 builds
+ * them (Ntok-1 = g*g; dims [0,32) depend on the grid row only, dims [32,64) on the grid column only): row r*g supplies the
+ * row part, row c the column part. */
 int cs_attn_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* out, float* lse, int B, int Ntok, int H,
                 int ldqkv, int ldo, float scale, cs_stream_t stream);
 /* CLS-query attention for the frozen teacher's last block: VisionTransformer.forward_features returns x[:, 0]
