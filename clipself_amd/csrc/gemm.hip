@@ -50,6 +50,7 @@ struct GemmArgs {
     int lda, ldb, ldc;
     int tiles_m, tiles_n;
     int ktiles_per_split;
+    long split_stride;    // EPI_F32 with split-K: slice y writes its partial product to C + y*split_stride (cs_gemm_wgrad)
     int group;            // EPI_PATCH: tokens-1 per image ; EPI_SWIGLU: hidden width Hd
     int gm;               // M panels per raster group
     // LayerNorm folded into the GEMM (frozen towers): A holds the *un-normalised* rows, B = gamma (.) W, and the epilogue applies
@@ -313,7 +314,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                         v[2] = rs * (s.z - mu * cs[2]) + bv[2]; v[3] = rs * (s.w - mu * cs[3]) + bv[3];
                     }
                     if (EPI == EPI_F32) {
-                        *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                        *(float4*)((float*)p.C + (size_t)blockIdx.y * p.split_stride + (size_t)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                     } else if (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
                         const float4 x = xin[it];
                         *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
@@ -758,7 +759,7 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
         for (int s = lo; s <= hi; ++s) {
             const long rounds = (t * s + slots - 1) / slots;
             const int kper = (ktiles + s - 1) / s;
-            const double c = rounds * (kper * us_per_ktile + 5.0) + (EPI == EPI_ATOMIC_F32 ? s * out_bytes / 1.5e6 : 0.0);
+            const double c = rounds * (kper * us_per_ktile + 5.0) + (EPI == EPI_ATOMIC_F32 ? s * out_bytes / 0.33e6 : 0.0);   // measured: fp32 atomics sustain ~0.33 TB/s
             if (c < cost) { cost = c; best = s; }
         }
         return best;
@@ -815,6 +816,7 @@ static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias
     GemmArgs a;
     a.A = (const __bf16*)A; a.B = (const __bf16*)B; a.C = C; a.bias = bias; a.extra = extra;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.group = group;
+    a.split_stride = 0;
     a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_colsum = ln_colsum; a.stats_part = stats_part;
     a.tiles_m = a.tiles_n = 0;
     a.gm = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 8;
@@ -841,6 +843,20 @@ static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias
     return -1;
 }
 
+// EPI_F32 with the K range cut into `splits` slices, slice y writing its [M,N] partial to C + y*M*N (cs_gemm_wgrad)
+static int gemm_nt_split_f32(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int cfg, int splits, hipStream_t stream) {
+    CS_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 4 == 0, "cs_gemm_wgrad: bad problem M=%d N=%d K=%d", M, N, K);
+    CS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "cs_gemm_wgrad: operands must be 16-byte aligned rows");
+    GemmArgs a;
+    a.A = (const __bf16*)A; a.B = (const __bf16*)B; a.C = C; a.bias = nullptr; a.extra = nullptr;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = N; a.group = 0;
+    a.split_stride = (long)M * N;
+    a.ln_mean = a.ln_rstd = a.ln_colsum = nullptr; a.stats_part = nullptr;
+    a.tiles_m = a.tiles_n = 0; a.gm = 8; a.dbg = 0;
+    a.ktiles_per_split = K / BK;
+    return launch<EPI_F32>(a, splits, 1, cfg, stream);
+}
+
 extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
                           int lda, int ldb, int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
     CS_CHECK_ARG(epi != EPI_RESID_LN_F32, "cs_gemm_nt: epilogue 6 (folded LayerNorm) is reached through cs_gemm_nt_ln");
@@ -855,4 +871,70 @@ extern "C" int cs_gemm_nt_ln(const void* A, const void* B, void* C, const float*
                              const float* ln_rstd, const float* ln_colsum, float* stats_part, int M, int N, int K, int lda, int ldb,
                              int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
     return gemm_nt_impl(A, B, C, bias, extra, ln_mean, ln_rstd, ln_colsum, stats_part, M, N, K, lda, ldb, ldc, epi, splits, group, flags, stream);
+}
+
+
+// ------------------------------------------------------------------------------------------------ wgrad: split-K through partials
+// dW[M,N] += A[M,K] . B[N,K]^T with a long contraction (K = tokens) and a small output: the K range is cut into `splits` slices
+// whose partial products go to a workspace with plain stores, and one streaming pass adds them into dW.  (fp32 atomics into dW
+// cost ~3 us per MB and slice on this part -- 0.33 TB/s -- which made the atomic split-K form 2-4x slower; profiles/r01_j.)
+namespace {
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long stride, float* __restrict__ dst,
+                                                            int M, int N, int ldc) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;          // one float4 of the [M, N] partials
+    const int n4 = N >> 2;
+    if (i >= (long)M * n4) return;
+    const int row = (int)(i / n4), c = (int)(i - (long)row * n4) * 4;
+    float4 acc = *(const float4*)(ws + (size_t)row * N + c);
+    for (int s = 1; s < splits; ++s) {
+        const float4 t = *(const float4*)(ws + (size_t)s * stride + (size_t)row * N + c);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    float4* d = (float4*)(dst + (size_t)row * ldc + c);
+    const float4 o = *d;
+    *d = make_float4(o.x + acc.x, o.y + acc.y, o.z + acc.z, o.w + acc.w);
+}
+
+// tile schedule (1 = 128x128 two per CU, 2 = 256x128, 7 = 256x256) and slice count minimising MFMA rounds + partial traffic
+void choose_wgrad(int M, int N, int K, int& cfg, int& splits) {
+    const int ktiles = K / BK;
+    const double out_mb = 4.0 * M * N / 1e6;
+    const struct { int cfg, bm, bn, per_cu; double us; } cand[3] = {{1, 128, 128, 2, 1.9}, {2, 256, 128, 1, 1.4}, {7, 256, 256, 1, 2.2}};
+    double best = 1e30;
+    cfg = 7; splits = 1;
+    for (const auto& c : cand) {
+        if (M < c.bm || N < c.bn) continue;
+        const long tiles = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+        for (int s = 1; s <= 64 && s <= ktiles; ++s) {
+            const long rounds = (tiles * s + 256L * c.per_cu - 1) / (256L * c.per_cu);
+            const int kper = (ktiles + s - 1) / s;
+            const double t = rounds * (kper * c.us + 6.0) + (s + 2) * out_mb / 5.0 + 6.0;
+            if (t < best) { best = t; cfg = c.cfg; splits = s; }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t cs_gemm_wgrad_workspace(int M, int N, int K) {
+    int cfg, splits;
+    choose_wgrad(M, N, K, cfg, splits);
+    return (size_t)splits * M * N * sizeof(float);
+}
+
+// dW[M,N] (f32, row stride ldc) += A[M,K] . B[N,K]^T, bf16 operands; workspace >= cs_gemm_wgrad_workspace(M,N,K) bytes, 16-byte aligned.
+extern "C" int cs_gemm_wgrad(const void* A, const void* B, float* dW, void* workspace, int M, int N, int K, int lda, int ldb, int ldc,
+                             hipStream_t stream) {
+    CS_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace % 16) == 0 && dW != nullptr && ((uintptr_t)dW % 16) == 0 && ldc % 4 == 0,
+                 "cs_gemm_wgrad: workspace / dW must be 16-byte aligned buffers");
+    int cfg, splits;
+    choose_wgrad(M, N, K, cfg, splits);
+    const int rc = gemm_nt_split_f32(A, B, (float*)workspace, M, N, K, lda, ldb, cfg, splits, stream);
+    if (rc) return rc;
+    const long n = (long)M * (N >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, splits,
+                       (long)M * N, dW, M, N, ldc);
+    CS_LAUNCH_CHECK();
+    return 0;
 }

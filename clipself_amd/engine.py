@@ -121,6 +121,7 @@ class EvaEngine:
         self.first_trainable = cfg.layers      # no block trainable until lock()/unlock is applied
         self.grad_ready_hook = None            # callable(block_index) fired when a block's grads are complete
         self._ctx = None
+        self._wgrad_ws = None
         # encode_image() consumes only the CLS row, so the last block runs its query/proj/MLP for that row alone (keys and
         # values still span all tokens); False runs the last block over every token -- same outputs, ~1/L more work.
         self.cls_only_last_block = True
@@ -488,7 +489,10 @@ class EvaEngine:
         Mp = Xt.shape[1]
         dYt = ops.empty((N, Mp), BF16)
         ops.transpose_bf16(dY, dYt)
-        ops.gemm_nt(dYt, Xt, dW, epi=EPI_ATOMIC_F32, splits=0)          # 0 = library picks the split-K factor
+        need = ops.gemm_wgrad_workspace(N, Xt.shape[0], Mp)
+        if self._wgrad_ws is None or self._wgrad_ws.numel() < need:
+            self._wgrad_ws = ops.empty((need,), torch.uint8)
+        ops.gemm_wgrad(dYt, Xt, dW, self._wgrad_ws)                      # split-K through partial buffers, then dW += sum
 
     def _transposed(self, X):
         M, K = X.shape

@@ -26,6 +26,8 @@ _vp, _i, _l, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_fl
 SIGNATURES = {
     "cs_last_error": (ctypes.c_char_p, []),
     "cs_gemm_nt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cs_gemm_wgrad_workspace": (_sz, [_i, _i, _i]),
+    "cs_gemm_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_gemm_nt_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_ln_stats_finalize": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "cs_attn_fwd_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
@@ -152,6 +154,19 @@ class HipOps:
             assert stats_part.is_contiguous() and stats_part.shape[0] >= 4 * ((group + 127) // 128) and stats_part.shape[1] == M
         self._ok(self.lib.cs_gemm_nt_ln(_p(A), _p(B), _p(C), _p(bias), _p(extra), _p(ln_mean), _p(ln_rstd), _p(ln_colsum), _p(stats_part),
                                         M, N, K, A.stride(0), B.stride(0), C.stride(0), epi, 1, group, flags, self._stream()), "cs_gemm_nt_ln")
+
+    def gemm_wgrad_workspace(self, M, N, K) -> int:
+        return int(self.lib.cs_gemm_wgrad_workspace(M, N, K))
+
+    def gemm_wgrad(self, A, B, dW, workspace):
+        """dW[M,N] += A[M,K] . B[N,K]^T (split-K through `workspace`, a uint8/any buffer of >= gemm_wgrad_workspace bytes)."""
+        self._chk(A, B, dW, workspace)
+        M, K = A.shape
+        N = B.shape[0]
+        assert B.shape[1] == K and A.stride(1) == 1 and B.stride(1) == 1 and dW.stride(1) == 1 and dW.dtype == torch.float32
+        assert workspace.numel() * workspace.element_size() >= self.gemm_wgrad_workspace(M, N, K)
+        self._ok(self.lib.cs_gemm_wgrad(_p(A), _p(B), _p(dW), _p(workspace), M, N, K, A.stride(0), B.stride(0), dW.stride(0),
+                                        self._stream()), "cs_gemm_wgrad")
 
     def ln_stats_finalize(self, part, npp, C, mean, rstd, eps=1e-6):
         self._chk(part, mean, rstd)

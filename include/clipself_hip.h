@@ -34,6 +34,13 @@ const char* cs_last_error(void);
 int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
                int lda, int ldb, int ldc, int epi, int splits, int group, int flags, cs_stream_t stream);
 
+/* Weight gradient of a Linear (autograd of F.linear at the call sites above): dW[M,N] (f32, row stride ldc) += A[M,K] . B[N,K]^T with
+ * A = dY^T, B = X^T (bf16, contraction = tokens, zero padded to K % 64 == 0).  The K range is split into slices whose partial
+ * products go through `workspace` (>= cs_gemm_wgrad_workspace bytes, 16-byte aligned) and one pass adds them into dW. */
+size_t cs_gemm_wgrad_workspace(int M, int N, int K);
+int cs_gemm_wgrad(const void* A, const void* B, float* dW, void* workspace, int M, int N, int K, int lda, int ldb, int ldc,
+                  cs_stream_t stream);
+
 /* cs_gemm_nt with a sub-LayerNorm folded in (frozen teacher; SwiGLU.ffn_ln eva_vit_model.py:102 ahead of w3, Attention.inner_attn_ln
  * :218 ahead of proj): the GEMM reads the *un-normalised* bf16 rows, B = gamma (.) W, and
  *   epi 6: C = extra + ln_rstd[m] * (A.B^T - ln_mean[m] * ln_colsum[n]) + bias[n],  ln_colsum[n] = sum_k B[n,k],  bias = W.beta + b.

@@ -89,6 +89,12 @@ class RefOps:
                 stats_part[s, :, 0] = blk.sum(-1)
                 stats_part[s, :, 1] = (blk * blk).sum(-1)
 
+    def gemm_wgrad_workspace(self, M, N, K):
+        return 16
+
+    def gemm_wgrad(self, A, B, dW, workspace):
+        dW.add_(A.float() @ B.float().T)
+
     def ln_stats_finalize(self, part, npp, C, mean, rstd, eps=1e-6):
         P = part.shape[0]
         keep = [p for p in range(P) if C - p * npp > 0]

@@ -108,6 +108,27 @@ def test_gemm_splitk_atomic_wgrad_shape(hip, ref):
         check(f"gemm_splitk_atomic flags={flags}", Cd, Cr, TOL_F32)
 
 
+@pytest.mark.parametrize("N,Kd,Mp", [(768, 256, 3200), (2304, 768, 12672), (128, 64, 64), (4096, 768, 1280), (300, 192, 640)])
+def test_gemm_wgrad_split_through_partials(hip, ref, N, Kd, Mp):
+    """cs_gemm_wgrad: dW += dY^T . X through split-K partial buffers + one reduction pass (no atomics: bit-reproducible)."""
+    A, B = rnd((N, Mp), BF, seed=60), rnd((Kd, Mp), BF, seed=61)
+    base = rnd((N, Kd), F32, seed=62)
+    Cr = base.clone()
+    ref.gemm_wgrad(A, B, Cr, None)
+    ws = torch.empty(hip.gemm_wgrad_workspace(N, Kd, Mp), dtype=torch.uint8, device="cuda")
+    Cd = base.cuda()
+    hip.gemm_wgrad(A.cuda(), B.cuda(), Cd, ws)
+    check(f"gemm_wgrad[{N},{Kd},{Mp}]", Cd, Cr, TOL_F32)
+    Cd2 = base.cuda()
+    hip.gemm_wgrad(A.cuda(), B.cuda(), Cd2, ws)
+    assert torch.equal(Cd, Cd2)
+    # strided destination (a slice of the flat grad buffer viewed with a wider row)
+    wide = torch.zeros(N, Kd + 64, device="cuda")
+    hip.gemm_wgrad(A.cuda(), B.cuda(), wide[:, :Kd], ws)
+    check(f"gemm_wgrad_strided[{N},{Kd},{Mp}]", wide[:, :Kd] + base.cuda(), Cr, TOL_F32)
+    assert float(wide[:, Kd:].abs().sum()) == 0.0
+
+
 def test_gemm_patch_epilogue(hip, ref):
     nimg, G, N, K = 5, 16, 128, 192
     A, W, bias = rnd((nimg * G, K), BF, seed=14), rnd((N, K), BF, 0.1, seed=15), rnd((N,), F32, seed=16)

@@ -97,8 +97,45 @@ def fold_ab():
         print(f"w3 resid: plain {t0:7.1f} us | folded-LN epilogue {t1:7.1f} us | the LayerNorm pass it replaces {t2:6.1f} us", flush=True)
 
 
+
+
+def wgrad_ab():
+    """Student wgrad shapes (contraction = 64*197 tokens padded to 12672): automatic split-K vs forced splits / tile configs
+    (usage: python tools/gemm_bench.py 64 wgrad)."""
+    ops = HipOps()
+    Mp = ((int(sys.argv[1]) * 197 + 63) // 64) * 64
+    for name, N, K in (("w12 4096x768", 4096, 768), ("w3 768x2048", 768, 2048), ("qkv 2304x768", 2304, 768), ("proj 768x768", 768, 768)):
+        A = torch.randn(N, Mp, device="cuda").to(BF)
+        B = torch.randn(K, Mp, device="cuda").to(BF)
+        C = torch.zeros(N, K, device="cuda")
+        line = f"{name} Mp={Mp}: "
+        for cfg, splits in ((0, 0), (3, 2), (2, 4), (1, 8)):
+            def run():
+                ops.gemm_nt(A, B, C, epi=4, splits=splits, flags=cfg << 4)
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 20
+            line += f"c{cfg}/s{splits}: {us:6.1f} ({2.0 * N * K * Mp / us / 1e6:4.0f}) | "
+        ws = torch.empty(ops.gemm_wgrad_workspace(N, K, Mp), dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            ops.gemm_wgrad(A, B, C, ws)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.gemm_wgrad(A, B, C, ws)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        line += f"cs_gemm_wgrad (partials, ws {ws.numel() >> 20} MiB): {us:6.1f} ({2.0 * N * K * Mp / us / 1e6:4.0f})"
+        print(line, flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "fold":
-        fold_ab()
-    else:
-        main()
+    mode = sys.argv[2] if len(sys.argv) > 2 else ""
+    {"fold": fold_ab, "wgrad": wgrad_ab}.get(mode, main)()
