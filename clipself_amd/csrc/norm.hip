@@ -218,21 +218,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
 }
 
 // part [nparts][2][C] -> dgamma[C] (+=), dbeta[C] (+=)
-// 64 columns per workgroup, the 4 waves split the partial rows 4 ways, LDS combine in fixed order (deterministic)
+// 16 columns per workgroup, 16 thread groups split the partial rows (4 loads in flight each), LDS combine in fixed order
+// (deterministic).  96 workgroups for C = 768 instead of 24 with one dependent load chain of 128 per thread.
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ float red[16][16];
+    const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int Cp = (C + 3) & ~3;
-    const int c = blockIdx.x * 64 + lane;            // index into a [2][Cp] partial row
+    const int c = blockIdx.x * 16 + cl;              // index into a [2][Cp] partial row
     const bool live = c < 2 * Cp && (c < Cp ? c : c - Cp) < C;
-    float s = 0.f;
-    if (live)
-        for (int p = w; p < nparts; p += 4) s += part[(size_t)p * 2 * Cp + c];
-    red[w][lane] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (live) {
+        int p = grp;
+        for (; p + 48 < nparts; p += 64) {
+            s0 += part[(size_t)p * 2 * Cp + c];
+            s1 += part[(size_t)(p + 16) * 2 * Cp + c];
+            s2 += part[(size_t)(p + 32) * 2 * Cp + c];
+            s3 += part[(size_t)(p + 48) * 2 * Cp + c];
+        }
+        for (; p < nparts; p += 16) s0 += part[(size_t)p * 2 * Cp + c];
+    }
+    red[grp][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (w == 0 && live) {
-        s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (grp == 0 && live) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += red[g][cl];
         float* dst = c < Cp ? dgamma + c : dbeta + (c - Cp);
         *dst = accumulate ? *dst + s : s;
     }
@@ -339,7 +350,7 @@ extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_
 #undef LNB3
     CS_LAUNCH_CHECK();
     if (dgamma) {
-        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * ((C + 3) & ~3) + 63) / 64), dim3(256), 0, stream, part, nwg, C, dgamma, dbeta, accumulate_params);
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * ((C + 3) & ~3) + 15) / 16), dim3(256), 0, stream, part, nwg, C, dgamma, dbeta, accumulate_params);
         CS_LAUNCH_CHECK();
     }
     return 0;
