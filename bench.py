@@ -125,7 +125,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--teacher-chunk", type=int, default=512)
+    ap.add_argument("--teacher-chunk", type=int, default=2048,
+                    help="crops per teacher launch; 2048 = the whole batch of configs[1] in one pass (~7 GB of live activations)")
     ap.add_argument("--full-last-block", action="store_true",
                     help="run the teacher's last block over every token instead of the CLS query only (same outputs, more work)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)

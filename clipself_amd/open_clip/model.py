@@ -76,7 +76,7 @@ class _Node(nn.Module):
 class EVAVisionTower(_Node):
     """`model.visual`: EVA02 ViT (RoPE + SwiGLU + sub-LN) executing on the HIP engine."""
 
-    def __init__(self, cfg: TowerCfg, ops=None, trainable: bool = True, teacher_chunk: int = 512):
+    def __init__(self, cfg: TowerCfg, ops=None, trainable: bool = True, teacher_chunk: int = 2048):
         super().__init__()
         self.cfg = cfg
         self.image_size = cfg.image_size

@@ -38,7 +38,7 @@ _TABLE = [
     ("delete-previous-checkpoint", "flag", False),
 ]
 # additions of this build (absent from the reference): synthetic input pipeline for `--train-data synthetic`
-_EXTRA = [("synthetic-steps", _I, 100), ("synthetic-image-size", _I, None), ("teacher-chunk", _I, 512)]
+_EXTRA = [("synthetic-steps", _I, 100), ("synthetic-image-size", _I, None), ("teacher-chunk", _I, 2048)]
 
 
 class _KeyValue(argparse.Action):
