@@ -16,6 +16,8 @@
 //   * keys are consumed in chunks of CH*32 with an online softmax, so any sequence length works; for the
 //     14x14(+CLS) grid a single chunk of 224 covers all 197 keys and no rescale is ever taken.
 #include "cs_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -90,6 +92,7 @@ struct AttnArgs {
     const float* sin_t;
     const float* lse_in;   // bwd: [B*H, N]
     const float* dsum;     // bwd: rowsum(dO*O) [B*H, N]
+    int dbg;               // timing ablations (env CS_ATTN_DBG, results wrong): 1 = no MFMA/softmax phase, 2 = no RoPE, 4 = no output stores
     int grid;              // fwd: token grid side g (Ntok = g*g + 1)
     float inv_grid;
     float* stats_part;     // fwd, optional: [H][B*N][2] per-head (sum, sum of squares) of the output rows
@@ -285,7 +288,7 @@ __device__ __forceinline__ void store_o(const AttnArgs& p, size_t rowbase, int q
                 ps += r;
                 pq += r * r;
             }
-            *(uint2*)(orow + dt * 32 + g4 * 8 + hf * 4) = t.u;
+            if (!(p.dbg & 4)) *(uint2*)(orow + dt * 32 + g4 * 8 + hf * 4) = t.u;
         }
     if (p.lse_out && hf == 0) p.lse_out[(size_t)bh * p.Ntok + q] = m * p.scale + logf(l);
     if (p.stats_part) {
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
         for (int it = 0; it < KI; ++it) {
             const int idx = tid + it * NT, r = idx >> 3, c = idx & 7;
             if (idx < CHK * 8) {
-                if (r > 0 && r < p.Ntok) rope8_lds(kr[it], rt, p.grid, p.inv_grid, r, c);
+                if (r > 0 && r < p.Ntok && !(p.dbg & 2)) rope8_lds(kr[it], rt, p.grid, p.inv_grid, r, c);
                 *(uint4*)(Kl + k_off(r, c)) = kr[it].u;
             }
         }
@@ -392,12 +395,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
                 bf16x8 qf[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    if (qc > 0) rope8_lds(qraw[j][ks], rt, p.grid, p.inv_grid, qc, ks * 2 + hf);
+                    if (qc > 0 && !(p.dbg & 2)) rope8_lds(qraw[j][ks], rt, p.grid, p.inv_grid, qc, ks * 2 + hf);
                     qf[ks] = qraw[j][ks].h;
                 }
                 float m = -INFINITY, l = 0.f;
                 f32x16 o[2] = {zero16(), zero16()};
-                attend_chunk<CH>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o);
+                if (!(p.dbg & 1)) attend_chunk<CH>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o);
+                else { l = 1.f; m = 0.f; o[0][0] = bf2f(qf[0][0]); }
                 if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
             }
         }
@@ -722,14 +726,22 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
     int g = (int)(sqrtf((float)(Ntok - 1)) + 0.5f);
     CS_CHECK_ARG(g * g == Ntok - 1, "cs_attn_fwd: Ntok - 1 = %d is not a square token grid (the RoPE tables are read separably)", Ntok - 1);
     a.grid = g; a.inv_grid = 1.f / (float)g;
+    static const int dbg_env = getenv("CS_ATTN_DBG") ? atoi(getenv("CS_ATTN_DBG")) : 0;
+    a.dbg = dbg_env;
     a.Ntok = Ntok; a.H = H; a.ldqkv = ldqkv; a.ldo = ldo; a.scale = scale;
     constexpr int CH = 7;
-    const size_t lds = (size_t)CH * 32 * 128 + (size_t)HD * VT_LD * 2 + (size_t)4 * g * 32 * sizeof(float);
+    static const size_t lds_pad = getenv("CS_ATTN_LDSPAD") ? (size_t)atoi(getenv("CS_ATTN_LDSPAD")) : 0;     // occupancy experiments
+    const size_t lds = (size_t)CH * 32 * 128 + (size_t)HD * VT_LD * 2 + (size_t)4 * g * 32 * sizeof(float) + lds_pad;
     CS_CHECK_ARG(lds <= 160 * 1024, "cs_attn_fwd: token grid %d too large for the LDS RoPE tables", g);
     if (Ntok <= CH * 32) {
         // whole sequence in one key chunk: 4-wave workgroups, 2 query tiles per wave, 2 workgroups per CU
         static bool once = (set_lds(attn_fwd_kernel<CH, 4, 2>, 160 * 1024), true);
         (void)once;
+        if (getenv("CS_ATTN_DEBUG")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_fwd_kernel<CH, 4, 2>, 256, lds);
+            fprintf(stderr, "[cs_attn] fwd<7,4,2>: %d resident workgroups per CU (lds %zu)\n", nb, lds);
+        }
         hipLaunchKernelGGL((attn_fwd_kernel<CH, 4, 2>), dim3((Ntok + 255) / 256, B * H), dim3(256), lds, stream, a);
     } else {
         static bool once = (set_lds(attn_fwd_kernel<CH, 8, 1>, 160 * 1024), true);
