@@ -1,12 +1,20 @@
+#!/usr/bin/env python
+"""GPU micro-benchmark of cs_attn_fwd on the teacher's shape (512 crops x 12 heads x 197 tokens); see profiles/r01_n_*.
+env: CS_ATTN_DBG (ablation bits), CS_ATTN_LDSPAD, CS_ATTN_DEBUG."""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from clipself_amd.hip import HipOps
-from oracle.eva_ref import rope_tables
 ops = HipOps()
 B, N, H = 512, 197, 12
 C = H * 64
 qkv = torch.randn(B * N, 3 * C, device="cuda").to(torch.bfloat16)
-cos, sin = [t.cuda() for t in rope_tables(14, 64)]
+g = 14                                                   # separable tables as rope.py:118-142 builds them
+freqs = 10000.0 ** (-torch.arange(0, 32, 2).float() / 32)
+ang = (torch.arange(g).float() / g * 16)[:, None] * freqs[None, :]
+ang = ang.repeat_interleave(2, dim=-1)
+full = torch.cat([ang[:, None, :].expand(g, g, 32), ang[None, :, :].expand(g, g, 32)], dim=-1).reshape(g * g, 64)
+cos, sin = full.cos().contiguous().cuda(), full.sin().contiguous().cuda()
 out = torch.empty(B * N, C, dtype=torch.bfloat16, device="cuda")
 for _ in range(3):
     ops.attn_fwd(qkv, cos, sin, out, None, B, N, H, 0.125)
