@@ -79,6 +79,25 @@ class KernelTimer:
                     flops_per_launch=self.flops / len(self.pairs))
 
 
+def isolated_swiglu_gemm(ops, M, cfg, launches=5):
+    """Mean duration (us) of the dominant kernel's launch shape with nothing else on the GPU (HIP events)."""
+    C, Hd = cfg.width, ((cfg.hidden + 63) // 64) * 64
+    A = torch.randn(M, C, device="cuda").to(torch.bfloat16)
+    W = (torch.randn(2 * Hd, C, device="cuda") * 0.05).to(torch.bfloat16)
+    bias = torch.randn(2 * Hd, device="cuda")
+    hid = torch.empty(M, Hd, dtype=torch.bfloat16, device="cuda")
+    part = torch.empty(4 * ((Hd + 127) // 128), M, 2, device="cuda")
+    torch.cuda.synchronize()
+    ops.gemm_nt_ln(A, W, hid, bias=bias, stats_part=part, epi=3, group=Hd)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        ops.gemm_nt_ln(A, W, hid, bias=bias, stats_part=part, epi=3, group=Hd)
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / launches
+
+
 def cpu_baseline_worker():
     """fp32 CPU oracle (oracle/eva_ref.py) on the host cores, bounded sample: one full step on 1 image x 8 crops
     (teacher + student fwd/bwd + AdamW) plus the teacher's per-crop cost on 16 more crops; the 32-crop step time is
@@ -129,6 +148,8 @@ def main():
                     help="crops per teacher launch; 2048 = the whole batch of configs[1] in one pass (~7 GB of live activations)")
     ap.add_argument("--full-last-block", action="store_true",
                     help="run the teacher's last block over every token instead of the CLS query only (same outputs, more work)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the teacher inline on the main stream instead of one batch ahead on a side stream (A/B switch)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
@@ -170,7 +191,11 @@ def main():
     sched = cosine_lr(opt, 1e-5, 1000, 100000)
     args = SimpleNamespace(device=device, precision="amp_bf16", distributed=distributed, skip_scheduler=False, grad_clip_norm=None,
                            multiscale=False, extract_type="v2", cosine_weight=1.0)
-    batch = tuple(t.to(device) for t in synthetic_batch(BATCH, CROPS, SIZE, SIZE, seed=1234, rank=rank))
+    # two distinct synthetic batches, alternated: step i trains on batches[i % 2] while the frozen teacher's pass over
+    # batches[(i + 1) % 2] runs one step ahead on a side stream (train_step(next_batch=...)); every step -- warm-up and timed --
+    # launches exactly one teacher pass and one student pass, and the final synchronize waits for both streams.
+    batches = [tuple(t.to(device) for t in synthetic_batch(BATCH, CROPS, SIZE, SIZE, seed=1234 + 977 * j, rank=rank)) for j in range(2)]
+    args.teacher_prefetch = not a.no_overlap
     method = CLIPSelf()
     # the fused SwiGLU GEMM is launched by the teacher's engine; the full-token launches (M = chunk*197) are the dominant kernel
     timer = KernelTimer(teacher.visual.engine.ops, epi=3, min_rows=min(a.teacher_chunk, BATCH * CROPS) * cfg.tokens)
@@ -182,14 +207,14 @@ def main():
 
     step = 0
     for _ in range(a.warmup):
-        train_step(model, method, batch, opt, sched, step, dist_model, args)
+        train_step(model, method, batches[step % 2], opt, sched, step, dist_model, args, next_batch=batches[(step + 1) % 2])
         step += 1
     sync()
     timer.on = True
     t0 = time.perf_counter()
     last = None
     for _ in range(a.steps):
-        last, _, _ = train_step(model, method, batch, opt, sched, step, dist_model, args)
+        last, _, _ = train_step(model, method, batches[step % 2], opt, sched, step, dist_model, args, next_batch=batches[(step + 1) % 2])
         step += 1
     sync()
     elapsed = time.perf_counter() - t0
@@ -212,7 +237,8 @@ def main():
             "config": {"workload": f"{MODEL} CLIPSelf image-patches step, {BATCH} images x {CROPS} crops per GPU, {SIZE}^2 (BASELINE configs[1])",
                        "global_batch": BATCH * world, "crops_per_image": CROPS, "image_size": SIZE,
                        "parallelism": f"dp{world}", "teacher_chunk": a.teacher_chunk,
-                       "teacher_last_block": "full" if a.full_last_block else "cls_query_only", "loss_last_step": loss},
+                       "teacher_last_block": "full" if a.full_last_block else "cls_query_only",
+                       "teacher_schedule": "inline" if a.no_overlap else "one_batch_ahead_on_side_stream", "loss_last_step": loss},
             "step_tflops": F * ips / 1e12, "step_mfma_frac": F * ips / 1e12 / (PEAK_BF16_TFLOPS * world),
         }
         if kt:
@@ -224,6 +250,12 @@ def main():
                                "traffic": (5.95e9 * min(a.teacher_chunk, BATCH * CROPS) / 2048.0),
                                "kernel": "gemm_nt_kernel<EPI_SWIGLU_BF16> (teacher W1|W2 GEMM + SiLU*mul, M=chunk*197,N=4096,K=768)",
                                "launches": kt["launches"], "mean_us": kt["mean_us"], "flops_per_launch": kt["flops_per_launch"]}
+            if not a.no_overlap:
+                # In the overlapped schedule this kernel shares the CUs with the student's kernels for part of the step, which
+                # stretches its launches; the same launch alone on the GPU (after the timed region) is reported beside it.
+                iso = isolated_swiglu_gemm(teacher.visual.engine.ops, min(a.teacher_chunk, BATCH * CROPS) * cfg.tokens, cfg)
+                out["roofline"]["isolated"] = {"mean_us": iso, "achieved": kt["flops_per_launch"] / iso / 1e6,
+                                               "frac": kt["flops_per_launch"] / iso / 1e6 / PEAK_BF16_TFLOPS}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

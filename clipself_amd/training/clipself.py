@@ -39,15 +39,63 @@ def cosine_distill_loss(student, teacher, ops, weight=1.0):
 
 
 class CLIPSelf:
+    """Besides the reference's call contract, the method can run the frozen teacher one batch ahead: `prefetch_teacher(next_batch,
+    ...)` launches the teacher forward of the NEXT batch on a high-priority side stream, where it overlaps the student's backward,
+    gradient all-reduce and AdamW of the current batch and the student forward of the next one (the teacher never changes, so its
+    features do not depend on the student's update).  `__call__` picks the prefetched features up when it is handed that batch and
+    otherwise computes them inline, exactly like the reference."""
+
+    def __init__(self):
+        self._pending = None           # (image_crops tensor of the prefetched batch, features, side stream)
+        self._side = None
+
+    @staticmethod
+    def _valid_crops(normed_boxes, image_crops):
+        valid = normed_boxes[..., -1] > 0.5                                   # [B, max_boxes]
+        if bool(valid.all()):                                                 # dense batch: no gather needed
+            return valid, True, image_crops.reshape(-1, *image_crops.shape[2:])
+        return valid, False, image_crops[valid]
+
+    def prefetch_teacher(self, batch, dist_model, device, cast_dtype, distributed):
+        device = torch.device(device)
+        if device.type != "cuda":
+            return
+        if distributed:
+            dist_model = dist_model.module
+        _, normed_boxes, image_crops = batch
+        boxes_d = normed_boxes.to(device=device, dtype=torch.float32, non_blocking=True)
+        crops_d = image_crops.to(device=device, dtype=cast_dtype, non_blocking=True)
+        _, _, crops = self._valid_crops(boxes_d, crops_d)
+        main = torch.cuda.current_stream(device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=device, priority=-1)        # the teacher is the long pole: let it win CUs
+        side = self._side
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            feats = dist_model.encode_image(crops, normalize=False)
+        crops.record_stream(side)
+        self._pending = (image_crops, feats, side)
+
+    def _teacher_features(self, image_crops, crops, dist_model):
+        pend, self._pending = self._pending, None
+        if pend is not None and pend[0] is image_crops:
+            _, feats, side = pend
+            main = torch.cuda.current_stream(feats.device)
+            main.wait_stream(side)
+            feats.record_stream(main)
+            return feats
+        with torch.no_grad():
+            return dist_model.encode_image(crops, normalize=False)
+
     def __call__(self, batch, model, dist_model, loss, device, cast_dtype, distributed, args):
         if distributed:
             model = model.module
             dist_model = dist_model.module
-        images, normed_boxes, image_crops = batch       # note texts are not paired with images
+        images, normed_boxes, image_crops_in = batch    # note texts are not paired with images
 
         images = images.to(device=device, dtype=cast_dtype, non_blocking=True)
         normed_boxes = normed_boxes.to(device=device, dtype=torch.float32, non_blocking=True)
-        image_crops = image_crops.to(device=device, dtype=cast_dtype, non_blocking=True)
+        image_crops = image_crops_in.to(device=device, dtype=cast_dtype, non_blocking=True)
 
         if getattr(args, "multiscale", False):
             side = images.shape[2]
@@ -58,21 +106,19 @@ class CLIPSelf:
             tar = random.choice(choices)
             images = F.interpolate(images, size=(tar, tar), mode="bilinear")
 
-        valid = normed_boxes[..., -1] > 0.5                                   # [B, max_boxes]
-        if bool(valid.all()):                                                 # dense batch: no gather needed
+        valid, dense, crops = self._valid_crops(normed_boxes, image_crops)
+        if dense:
             B, k = valid.shape
             idx = torch.arange(B, device=normed_boxes.device, dtype=torch.float32).repeat_interleave(k)[:, None]
             rois = torch.cat([idx, normed_boxes[..., :4].reshape(B * k, 4)], dim=1)
-            crops = image_crops.reshape(B * k, *image_crops.shape[2:])
         else:
             bidx = torch.nonzero(valid)[:, 0].to(torch.float32)[:, None]
             rois = torch.cat([bidx, normed_boxes[valid][:, :4]], dim=1)
-            crops = image_crops[valid]
 
-        with torch.no_grad():
-            teacher_crop_features = dist_model.encode_image(crops, normalize=False)
+        # student first: when the teacher features were prefetched they are still being produced on the side stream
         student_roi_features = model.encode_pseudo_boxes(images, rois, normalize=False,
                                                          extract_type=getattr(args, "extract_type", "v2"))
+        teacher_crop_features = self._teacher_features(image_crops_in, crops, dist_model)
 
         loss_cosine = cosine_distill_loss(student_roi_features, teacher_crop_features, model.visual.engine.ops,
                                           getattr(args, "cosine_weight", 1.0))

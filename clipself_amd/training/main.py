@@ -75,6 +75,7 @@ def main(argv):
         args.model, args.pretrained, precision=args.precision, device=device, cache_dir=args.cache_dir,
         det_image_size=args.det_image_size, dataset_type=args.dataset_type)
     model.visual.teacher_chunk = args.teacher_chunk
+    args.teacher_prefetch = not args.no_teacher_prefetch
     args.input_size = model.visual.image_size
     if args.dataset_type in ("grid_distill", "proposals_distill"):
         method = CLIPSelf()

@@ -38,7 +38,8 @@ _TABLE = [
     ("delete-previous-checkpoint", "flag", False),
 ]
 # additions of this build (absent from the reference): synthetic input pipeline for `--train-data synthetic`
-_EXTRA = [("synthetic-steps", _I, 100), ("synthetic-image-size", _I, None), ("teacher-chunk", _I, 2048)]
+_EXTRA = [("synthetic-steps", _I, 100), ("synthetic-image-size", _I, None), ("teacher-chunk", _I, 2048),
+          ("no-teacher-prefetch", "flag", False)]      # run the frozen teacher inline instead of one batch ahead on a side stream
 
 
 class _KeyValue(argparse.Action):

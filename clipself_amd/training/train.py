@@ -41,8 +41,10 @@ def student_teacher_ensemble(student, teacher, alpha=0.5):
     return {k: v * alpha + teacher[k] * (1.0 - alpha) for k, v in student.items()}
 
 
-def train_step(model, method, batch, optimizer, scheduler, step, dist_model, args, loss=None):
-    """One iteration of the loop body (train.py:80-119).  Returns (losses, batch_size, logit_scale)."""
+def train_step(model, method, batch, optimizer, scheduler, step, dist_model, args, loss=None, next_batch=None):
+    """One iteration of the loop body (train.py:80-119).  Returns (losses, batch_size, logit_scale).
+    next_batch (optional): handed to method.prefetch_teacher() once this step's forward is queued, so the frozen teacher's pass
+    over the next batch overlaps this step's backward / all-reduce / AdamW on the GPU."""
     device = torch.device(args.device)
     cast_dtype = torch.bfloat16 if args.precision == "bf16" else None
     if scheduler is not None and not getattr(args, "skip_scheduler", False):
@@ -52,6 +54,8 @@ def train_step(model, method, batch, optimizer, scheduler, step, dist_model, arg
         losses, batch_size, logit_scale = method(batch, model, dist_model, loss, device, cast_dtype, args.distributed, args)
         total_loss = sum(losses.values())
         losses["loss"] = total_loss
+    if next_batch is not None and getattr(args, "teacher_prefetch", True) and hasattr(method, "prefetch_teacher"):
+        method.prefetch_teacher(next_batch, dist_model, device, cast_dtype, args.distributed)
     backward(total_loss)
     if hasattr(model, "finish_grad_sync"):
         model.finish_grad_sync()
@@ -74,10 +78,16 @@ def train_one_epoch(model, method, data, loss, epoch, optimizer, scaler, schedul
     sample_digits = math.ceil(math.log(dataloader.num_samples + 1, 10))
     losses_m, batch_time_m, data_time_m = {}, AverageMeter(), AverageMeter()
     end = time.time()
-    for i, batch in enumerate(dataloader):
+    batches = iter(dataloader)
+    upcoming = next(batches, None)
+    i = -1
+    while upcoming is not None:
+        batch, upcoming = upcoming, next(batches, None)           # one batch of look-ahead for the teacher prefetch
+        i += 1
         step = num_batches_per_epoch * epoch + i
         data_time_m.update(time.time() - end)
-        losses, batch_size, logit_scale = train_step(model, method, batch, optimizer, scheduler, step, dist_model, args, loss)
+        losses, batch_size, logit_scale = train_step(model, method, batch, optimizer, scheduler, step, dist_model, args, loss,
+                                                     next_batch=upcoming)
         batch_time_m.update(time.time() - end)
         end = time.time()
         batch_count = i + 1

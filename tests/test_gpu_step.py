@@ -305,3 +305,32 @@ def test_bench_two_rank_rehearsal():
     _log(f"bench 2-rank rehearsal on one GPU: {out['value']:.1f} img/s loss={out['config']['loss_last_step']:.4f}")
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and 0.0 < out["config"]["loss_last_step"] < 2.0
+
+
+def test_teacher_prefetch_on_side_stream_equals_inline():
+    """train_step(next_batch=...) runs the frozen teacher one batch ahead on a side stream (overlapping the student's backward and
+    AdamW); the training trajectory must be the one of the inline schedule."""
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.train import train_step
+    cfg = tiny_cfg()
+    batches = [tuple(t.cuda() for t in synthetic_batch(3, 4, cfg.image_size, cfg.image_size, seed=70 + j)) for j in range(3)]
+
+    def run(prefetch):
+        student, teacher = _pair(cfg, 5)
+        opt = FlatAdamW(student, lr=1e-3, weight_decay=0.1)
+        method, losses = CLIPSelf(), []
+        for step in range(5):
+            nxt = batches[(step + 1) % 3] if prefetch and step < 4 else None
+            out, _, _ = train_step(student, method, batches[step % 3], opt, None, step, teacher, _args(skip_scheduler=True), next_batch=nxt)
+            losses.append(out["loss"].detach())
+            if prefetch and step < 4:
+                assert method._pending is not None and method._pending[0] is batches[(step + 1) % 3][2]
+        torch.cuda.synchronize()
+        return [float(v) for v in losses], student.visual.engine.master.clone()
+
+    l_inline, p_inline = run(False)
+    l_pref, p_pref = run(True)
+    _log(f"teacher prefetch vs inline: losses {l_pref} vs {l_inline}, param rel {rel(p_pref, p_inline):.2e}")
+    assert max(abs(a - b) for a, b in zip(l_pref, l_inline)) < 1e-5
+    assert rel(p_pref, p_inline) < 1e-5
