@@ -51,6 +51,40 @@ class DataInfo:
         self.dataloader.epoch = epoch
 
 
+class SyntheticPanopticVal:
+    """Batches shaped like the panoptic validation set (src/training/data.py:331-387) plus `.embeddings`: boxes from the synthetic
+    recipe, a rectangular mask per box at feature-map resolution, a class per box and a things/stuff flag per class."""
+
+    def __init__(self, steps, batch_size, boxes, image_size, crop_size, grid, embed_dim, num_classes=32, seed=4321):
+        g = torch.Generator().manual_seed(seed)
+        self.embeddings = torch.randn(num_classes, embed_dim, generator=g).numpy()
+        self.batches = []
+        for i in range(steps):
+            images, nb, crops = synthetic_batch(batch_size, boxes, image_size, crop_size, seed=seed + 1 + i, valid_prob=0.8)
+            labels = torch.randint(0, num_classes, nb.shape[:2], generator=g).float()
+            area = (nb[..., 2] - nb[..., 0]) * (nb[..., 3] - nb[..., 1]) * image_size * image_size
+            info = torch.stack([labels, nb[..., 4], area, (labels % 3 != 0).float()], dim=-1)
+            bboxes = torch.cat([nb[..., :4], info], dim=-1)                                        # [B,K,8]
+            ys = (torch.arange(grid).float() + 0.5) / grid
+            inside_y = (ys[None, None, :] >= nb[..., 1:2]) & (ys[None, None, :] <= nb[..., 3:4])    # [B,K,g]
+            inside_x = (ys[None, None, :] >= nb[..., 0:1]) & (ys[None, None, :] <= nb[..., 2:3])
+            masks = (inside_y[..., :, None] & inside_x[..., None, :]).float()                     # [B,K,g,g]
+            masks[..., grid // 2, grid // 2] = 1.0                                                  # never empty
+            self.batches.append((images, bboxes, crops, masks, crops.clone()))
+
+    def __len__(self):
+        return len(self.batches)
+
+
+class _ValLoader:
+    def __init__(self, dataset):
+        self.dataset = dataset
+        self.num_batches, self.num_samples = len(dataset), sum(len(b[0]) for b in dataset.batches)
+
+    def __iter__(self):
+        return iter(self.dataset.batches)
+
+
 def get_data(args, preprocess_fns=None, epoch=0, tokenizer=None):
     if args.train_data != "synthetic":
         raise NotImplementedError(
@@ -61,4 +95,10 @@ def get_data(args, preprocess_fns=None, epoch=0, tokenizer=None):
                               args.device, args.rank, args.world_size, seed=1234 + args.seed,
                               valid_prob=0.7 if args.dataset_type == "proposals_distill" else 1.0, resident=False)
     loader.region_clip = args.dataset_type == "region_clip"
-    return {"train": DataInfo(loader)}
+    data = {"train": DataInfo(loader)}
+    if getattr(args, "val_data", None) == "synthetic":
+        cfg = args.tower_cfg
+        val = SyntheticPanopticVal(2, min(args.batch_size, 4), min(args.max_boxes, 6), size, args.input_size, size // cfg.patch_size,
+                                   cfg.embed_dim, seed=4321 + args.seed)
+        data["val"] = DataInfo(_ValLoader(val))
+    return data

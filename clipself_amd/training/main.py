@@ -77,6 +77,7 @@ def main(argv):
     model.visual.teacher_chunk = args.teacher_chunk
     args.teacher_prefetch = not args.no_teacher_prefetch
     args.input_size = model.visual.image_size
+    args.tower_cfg = model.visual.cfg
     if args.dataset_type in ("grid_distill", "proposals_distill"):
         method = CLIPSelf()
         dist_model = create_model(args.model, args.pretrained, device=device, precision=args.precision,
@@ -148,6 +149,12 @@ def main(argv):
             target_sd = student_teacher_ensemble(student_sd, teacher_sd, args.alpha)
         else:
             target_sd = student_sd
+        if "val" in data:                                       # main.py:300-342: the saved (ensembled) weights are what gets evaluated
+            test_model = create_model(args.model, args.pretrained, device=device, precision=args.precision, cache_dir=None,
+                                      trainable=False)
+            test_model.load_state_dict(target_sd)
+            evaluate(test_model, data, completed_epoch, args)
+            del test_model
         if is_master(args):
             ckpt = {"epoch": completed_epoch, "name": args.name, "state_dict": target_sd, "optimizer": optimizer.state_dict()}
             if completed_epoch == args.epochs or (args.save_frequency > 0 and completed_epoch % args.save_frequency == 0):

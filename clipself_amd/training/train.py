@@ -107,9 +107,16 @@ def train_one_epoch(model, method, data, loss, epoch, optimizer, scaler, schedul
 
 
 def evaluate(model, data, epoch, args):
-    """The reference evaluates zero-shot region mAcc on COCO-panoptic (src/training/zero_shot.py); that harness needs
-    the dataset + panopticapi and is outside the hot path."""
-    if "val" not in data:
-        logging.info("evaluate: no validation data wired in this build (zero-shot region eval is out of scope); skipping")
-        return {}
-    raise NotImplementedError
+    """Zero-shot region classification on the validation split + the reference's bookkeeping (train.py:168-195)."""
+    import json
+    import os
+    from .zero_shot import zero_shot_eval
+    model.eval()
+    metrics = dict(zero_shot_eval(model, data, epoch, args))
+    if not is_master(args) or not metrics:
+        return {} if not is_master(args) else metrics
+    logging.info(f"Eval Epoch: {epoch}. " + ", ".join(f"{k}: {v:.4f}" for k, v in metrics.items()))
+    if getattr(args, "save_logs", False) and getattr(args, "checkpoint_path", None):
+        with open(os.path.join(args.checkpoint_path, "results.json"), "a+") as f:
+            f.write(json.dumps(metrics) + "\n")
+    return metrics

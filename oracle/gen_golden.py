@@ -210,6 +210,44 @@ def gen_regionclip(oc):
     print("regionclip loss", float(total))
 
 
+ZEROSHOT = dict(seed_w=6, steps=2, batch=3, boxes=5, num_classes=12, seed=4321)
+
+
+def gen_zeroshot(oc):
+    """zero_shot.run + macc_with_is_thing (src/training/zero_shot.py:11-173) of the reference on the tiny tower, fed with the
+    synthetic panoptic-style validation batches of clipself_amd/training/data.py (inputs are seeded, so tests rebuild them)."""
+    from training import zero_shot as ref_zs
+    from clipself_amd.training.data import SyntheticPanopticVal
+    cfg = _register_tiny(oc)
+    rec = ZEROSHOT
+    model = _build(oc, cfg, rec["seed_w"])
+    model.eval()
+    val = SyntheticPanopticVal(rec["steps"], rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, cfg.image_size // cfg.patch_size,
+                               cfg.embed_dim, num_classes=rec["num_classes"], seed=rec["seed"])
+    class _Loader:
+        dataset = val
+
+        def __iter__(self):
+            return iter(val.batches)
+
+        def __len__(self):
+            return len(val.batches)
+
+    args = SimpleNamespace(device="cpu", precision="fp32", distributed=False, horovod=False, extract_type="v2", image_ave_pool=False,
+                           rank=0, local_rank=0)
+    (hit_rois, hit_crops, hit_mask, sim_rois, sim_crops, sim_mask, sizes, thing, labels) = ref_zs.run(model, _Loader(), args)
+    metrics = {}
+    for key, h in (("rois", hit_rois), ("crops", hit_crops), ("maskpool", hit_mask)):
+        metrics.update(ref_zs.macc_with_is_thing(h, thing, labels, key))
+    blob = {"hit_rois": hit_rois.numpy(), "hit_crops": hit_crops.numpy(), "hit_maskpool": hit_mask.numpy(),
+            "sim_rois": sim_rois.numpy(), "sim_crops": sim_crops.numpy(), "sim_maskpool": sim_mask.numpy(),
+            "size": sizes.numpy(), "thing": thing.numpy(), "label": labels.numpy(),
+            "metric_names": np.array(list(metrics)), "metric_values": np.array([metrics[k] for k in metrics], np.float64),
+            "recipe": np.array(json.dumps(rec))}
+    np.savez_compressed(GOLD / "tiny_zeroshot.npz", **blob)
+    print("zero-shot metrics", metrics)
+
+
 def gen_b16(oc):
     cfg = get_tower_cfg("EVA02-CLIP-B-16")
     rec = B16
@@ -253,9 +291,13 @@ def main():
     if "--regionclip-only" in sys.argv:
         gen_regionclip(oc)
         return
+    if "--zeroshot-only" in sys.argv:
+        gen_zeroshot(oc)
+        return
     gen_tiny(oc)
     gen_tiny14(oc)
     gen_regionclip(oc)
+    gen_zeroshot(oc)
     if "--tiny-only" not in sys.argv:
         gen_b16(oc)
 

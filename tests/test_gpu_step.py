@@ -262,10 +262,13 @@ def test_training_main_entrypoint_end_to_end(tmp_path):
     base = [sys.executable, "-m", "clipself_amd.training.main", "--model", "EVA02-CLIP-B-16", "--pretrained", "eva", "--train-data", "synthetic",
             "--dataset-type", "grid_distill", "--batch-size", "4", "--max-boxes", "4", "--det-image-size", "224", "--synthetic-steps", "3",
             "--epochs", "1", "--lock-image", "--lock-image-unlocked-groups", "12", "--alpha", "0.7", "--lr", "1e-5", "--wd", "0.1",
-            "--warmup", "10", "--log-every-n-steps", "1", "--logs", str(tmp_path), "--cache-dir", "none.pt"]
+            "--warmup", "10", "--log-every-n-steps", "1", "--logs", str(tmp_path), "--cache-dir", "none.pt",
+            "--val-data", "synthetic", "--zeroshot-frequency", "1"]
     r = subprocess.run(base + ["--name", "run1"], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Train Epoch: 0" in r.stderr and "Loss_cosine" in r.stderr
+    assert r.stderr.count("Eval Epoch:") == 2 and "maskpool.stuff.macc5" in r.stderr          # before training and on the saved ensemble
+    assert len((tmp_path / "run1" / "checkpoints" / "results.json").read_text().strip().splitlines()) == 2
     ckpt = tmp_path / "run1" / "checkpoints" / "epoch_1.pt"
     blob = torch.load(ckpt, map_location="cpu", weights_only=False)
     assert set(blob) == {"epoch", "name", "state_dict", "optimizer"} and blob["epoch"] == 1
@@ -334,3 +337,12 @@ def test_teacher_prefetch_on_side_stream_equals_inline():
     _log(f"teacher prefetch vs inline: losses {l_pref} vs {l_inline}, param rel {rel(p_pref, p_inline):.2e}")
     assert max(abs(a - b) for a, b in zip(l_pref, l_inline)) < 1e-5
     assert rel(p_pref, p_inline) < 1e-5
+
+
+def test_zero_shot_region_eval_on_gpu(golden_dir):
+    """zero-shot region classification (RoIAlign / mask pooling / crop embeddings against class embeddings) through
+    the HIP engine, against the golden captured from the reference's zero_shot.run."""
+    from clipself_amd.hip import HipOps
+    from test_zeroshot_cpu import run_zeroshot
+    m = run_zeroshot(HipOps, "cuda", golden_dir, log=_log)
+    _log(f"zero-shot metrics on GPU: {m}")
