@@ -45,10 +45,82 @@ class _SyntheticLoader:
 
 @dataclass
 class DataInfo:
-    dataloader: _SyntheticLoader
+    dataloader: object
 
     def set_epoch(self, epoch):
         self.dataloader.epoch = epoch
+
+
+def grid_choices(max_split):
+    """(M, N) grids the reference samples from (GridDistillDataset._init_choices, data.py:200-206)."""
+    return [(m, n) for m in range(1, max_split + 1) for n in range((m + 1) // 2, min(m * 2 + 1, max_split + 1))]
+
+
+def grid_boxes(M, N):
+    """Cells of an M x N grid as (x0, y0, x1, y1) in [0,1], row-major (data.py:211-224)."""
+    xs, ys = torch.linspace(0, 1, N + 1), torch.linspace(0, 1, M + 1)
+    gx, gy = torch.meshgrid(xs, ys, indexing="xy")
+    return torch.cat([torch.stack([gx[:M, :N], gy[:M, :N]], -1), torch.stack([gx[1:, 1:], gy[1:, 1:]], -1)], -1).view(-1, 4)
+
+
+class GpuGridDistillLoader:
+    """GridDistillDataset (src/training/data.py:135-281) with the pixel work on the GPU: decoded RGB images
+    (uint8 HWC, resident in HBM) -> the batch contract.  Per image, as the reference: one (M, N) grid drawn from `grid_choices`, its
+    cells shuffled and cut to max_boxes, optional enlargement by crop_scale clipped to the image, every cell cropped and resized
+    (ResizeMaxSize, centred padding) to crop_size, the image itself resized (ResizeLongest, right/bottom padding) to det_size, boxes
+    rescaled to the padded square.  Crops and the det image come from cs_crop_resize_u8, bit-identical to the Pillow path; the
+    random draws use Python's `random` exactly where the reference does."""
+
+    def __init__(self, images_u8, ops, batch_size, max_boxes, det_size, crop_size, max_split=6, crop_scale=1.0, steps=None, seed=0):
+        import random
+        self.images, self.ops = images_u8, ops
+        self.batch_size, self.max_boxes, self.det_size, self.crop_size = batch_size, max_boxes, det_size, crop_size
+        self.crop_scale = crop_scale
+        self.choices = grid_choices(max_split)
+        self.templates = {c: grid_boxes(*c) for c in self.choices}
+        self.num_batches = steps if steps is not None else len(images_u8) // batch_size
+        self.num_samples = self.num_batches * batch_size
+        self.rng = random.Random(seed)
+        self.epoch = 0
+
+    def __len__(self):
+        return self.num_batches
+
+    def sample(self, img):
+        """-> (det image [3,S,S], boxes [max_boxes,5], crops [max_boxes,3,Sc,Sc]) for one decoded image; also returns the pixel
+        boxes actually cropped (for the tests)."""
+        H, W = img.shape[0], img.shape[1]
+        dev = img.device
+        tmpl = self.templates[self.rng.choice(self.choices)]
+        idx = list(range(len(tmpl)))
+        self.rng.shuffle(idx)
+        idx = idx[:self.max_boxes]
+        px = tmpl[idx] * torch.tensor([W, H, W, H], dtype=torch.float32)
+        crop_px = px.clone()
+        if self.crop_scale > 1.0:                                    # data.py:236-241
+            bw, bh = px[:, 2] - px[:, 0], px[:, 3] - px[:, 1]
+            cx, cy = (px[:, 2] + px[:, 0]) / 2, (px[:, 3] + px[:, 1]) / 2
+            d = 0.5 * self.crop_scale
+            crop_px = torch.stack([(cx - bw * d).clamp(min=0), (cy - bh * d).clamp(min=0), (cx + bw * d).clamp(max=W),
+                                   (cy + bh * d).clamp(max=H)], -1)
+        k = len(idx)
+        crops = torch.zeros(self.max_boxes, 3, self.crop_size, self.crop_size, device=dev)
+        self.ops.crop_resize(img, crop_px.to(dev), self.crop_size, pad_center=True, out=crops[:k])
+        whole = torch.tensor([[0.0, 0.0, float(W), float(H)]], device=dev)
+        det = self.ops.crop_resize(img, whole, self.det_size, pad_center=False)[0]
+        scale = min(self.det_size / H, self.det_size / W)            # get_scale (transform.py:194-207) of ResizeLongest's square output
+        boxes = torch.zeros(self.max_boxes, 5)
+        boxes[:k, :4] = px * scale / self.det_size
+        boxes[:k, 4] = 1.0
+        return det, boxes.to(dev), crops, crop_px
+
+    def __iter__(self):
+        order = list(range(len(self.images)))
+        random_order = __import__("random").Random(1000 + self.epoch)
+        random_order.shuffle(order)
+        for b in range(self.num_batches):
+            parts = [self.sample(self.images[order[(b * self.batch_size + j) % len(order)]])[:3] for j in range(self.batch_size)]
+            yield tuple(torch.stack([p[i] for p in parts]) for i in range(3))
 
 
 class SyntheticPanopticVal:
@@ -86,6 +158,17 @@ class _ValLoader:
 
 
 def get_data(args, preprocess_fns=None, epoch=0, tokenizer=None):
+    if args.train_data == "synthetic-raw":
+        # decoded images of assorted sizes (uint8, HWC, in HBM) through the GPU grid-distill pipeline
+        from ..hip import HipOps
+        g = torch.Generator().manual_seed(77 + args.seed)
+        sizes = [(427, 640), (640, 480), (500, 375), (333, 500), (480, 640), (612, 612)]
+        n = max(args.batch_size, 8)
+        images = [torch.randint(0, 256, (*sizes[i % len(sizes)], 3), generator=g, dtype=torch.uint8).to(args.device) for i in range(n)]
+        size = args.synthetic_image_size or args.det_image_size
+        loader = GpuGridDistillLoader(images, HipOps(), args.batch_size, args.max_boxes, size, args.input_size, max_split=args.max_split,
+                                      crop_scale=args.crop_scale, steps=args.synthetic_steps, seed=1234 + args.seed + 7919 * args.rank)
+        return {"train": DataInfo(loader)}
     if args.train_data != "synthetic":
         raise NotImplementedError(
             "only --train-data synthetic is wired in this build: the COCO/LVIS PIL pipeline is host-side and out of "

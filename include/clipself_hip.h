@@ -122,6 +122,17 @@ int cs_fed_bce_fwd(const float* logits, long ldz, const int* tgt, float* rowloss
 int cs_fed_bce_bwd(const float* logits, long ldz, const int* tgt, void* dz_bf16, long ldd, int K, int ns, float temp,
                    float weight, const float* upstream, cs_stream_t stream);
 
+/* --- input pipeline on the GPU: the region crops of GridDistillDataset._obtain_image_crops (src/training/data.py:226-245,
+ *     transforms[1] = ResizeMaxSize + ToTensor + Normalize, src/open_clip/transform.py:26-49,93-99) and the det image itself
+ *     (ResizeLongest, transform.py:169-191) from ONE decoded RGB image resident in HBM.  Pillow's bicubic resampling (PIL.Image.crop +
+ *     Image.resize as reached through torchvision.transforms.functional.resize) is restated bit-exactly: fixed-point coefficients,
+ *     horizontal pass then vertical pass, uint8 after each.
+ * src [H,W,3] u8; boxes [K,4] f32 pixel (x0,y0,x1,y1), device; mean3/std3: HOST arrays of 3 floats; out [K,3,S,S] f32;
+ * pad_center 1 = centred zero padding (crop transform), 0 = right/bottom (det transform); workspace >= cs_crop_resize_workspace bytes. */
+size_t cs_crop_resize_workspace(int H, int K, int S);
+int cs_crop_resize_u8(const void* src, int H, int W, const float* boxes, int K, int S, int pad_center, const float* mean3,
+                      const float* std3, float* out, void* workspace, cs_stream_t stream);
+
 /* --- optimizer: torch.optim.AdamW built at src/training/main.py:198-213, stepped at src/training/train.py:115.
  * Flat fp32 master/grad/moment buffers; flags[n/64]: bit0 = tensor has a gradient this step, bit1 = weight decay applies. */
 int cs_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, const uint8_t* flags, long n, float lr,

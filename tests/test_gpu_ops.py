@@ -352,6 +352,36 @@ def test_attention_fwd_stats_and_layernorm_stats_only(hip, ref, B, Ntok, H):
     check(tag + ".ln_stats_only.rstd", r2, rstd_d, 2e-4)
 
 
+# ------------------------------------------------------------------------------------------------ GPU input pipeline
+@pytest.mark.parametrize("H,W,size,pad_center", [(427, 640, 224, True), (500, 333, 224, True), (683, 1024, 336, True), (96, 130, 224, True),
+                                                   (480, 640, 224, False)])
+def test_crop_resize_is_pillow_exact(hip, H, W, size, pad_center):
+    """cs_crop_resize_u8 (crop -> bicubic resize of the longest side -> zero pad -> /255 -> normalise) against Pillow itself:
+    grid cells of the reference's (M, N) templates (data.py:200-224), free-form boxes, and the whole image (the det transform)."""
+    import numpy as np
+    from oracle.pil_crops_ref import pil_crops
+    rng = np.random.default_rng(H * 7 + W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    img[: H // 2, : W // 3] = (rng.integers(0, 256, (H // 2, W // 3, 1)) // 3 + 90).astype(np.uint8)      # some smooth structure too
+    boxes = []
+    for M, N in ((1, 1), (2, 3), (6, 6), (5, 3)):
+        xs, ys = np.linspace(0, 1, N + 1) * W, np.linspace(0, 1, M + 1) * H
+        boxes += [(xs[j], ys[i], xs[j + 1], ys[i + 1]) for i in range(M) for j in range(N)]
+    for _ in range(12):
+        x0, y0 = rng.uniform(0, W * 0.6), rng.uniform(0, H * 0.6)
+        boxes.append((x0, y0, min(x0 + rng.uniform(8, W * 0.4), W), min(y0 + rng.uniform(8, H * 0.4), H)))
+    boxes.append((10.5, 20.5, 41.5, 37.5))                                                                 # .5 edges: round-half-even
+    if not pad_center:
+        boxes = [(0.0, 0.0, float(W), float(H))]                                                            # det image transform
+    boxes = np.asarray(boxes, np.float32)
+    want = torch.from_numpy(pil_crops(img, boxes, size, pad_center))
+    got = hip.crop_resize(torch.from_numpy(img).cuda(), torch.from_numpy(boxes).cuda(), size, pad_center)
+    bad = int((got.cpu() != want).sum())
+    with open(_LOG, "a") as f:
+        f.write(f"crop_resize[{H}x{W}->{size}, {len(boxes)} boxes, centre={pad_center}]: {bad} of {want.numel()} values differ from Pillow\n")
+    assert bad == 0
+
+
 # ------------------------------------------------------------------------------------------------ elementwise
 def test_swiglu_cast_transpose_colsum_im2row(hip, ref):
     M, Hd = 333, 2048

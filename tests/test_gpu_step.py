@@ -346,3 +346,48 @@ def test_zero_shot_region_eval_on_gpu(golden_dir):
     from test_zeroshot_cpu import run_zeroshot
     m = run_zeroshot(HipOps, "cuda", golden_dir, log=_log)
     _log(f"zero-shot metrics on GPU: {m}")
+
+
+def test_gpu_grid_distill_loader_matches_pillow_pipeline():
+    """GridDistillDataset's batch contract produced on the GPU from decoded uint8 images (grid choice, shuffled cells,
+    crop_scale enlargement, ResizeMaxSize crops, ResizeLongest det image, rescaled boxes) against the same steps done with Pillow."""
+    import numpy as np
+    from clipself_amd.hip import HipOps
+    from clipself_amd.training.data import GpuGridDistillLoader, grid_choices
+    from oracle.pil_crops_ref import pil_crops
+    assert len(grid_choices(6)) == 24                       # SURVEY.md §8 A0: 24 (M, N) choices at the shipped max_split
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in ((427, 640), (500, 333), (612, 612))]
+    for crop_scale in (1.0, 1.5):
+        loader = GpuGridDistillLoader([torch.from_numpy(a).cuda() for a in imgs], HipOps(), batch_size=3, max_boxes=8, det_size=320,
+                                      crop_size=224, max_split=6, crop_scale=crop_scale, steps=2, seed=3)
+        for a, t in zip(imgs, loader.images):
+            det, boxes, crops, crop_px = loader.sample(t)
+            H, W = a.shape[:2]
+            k = int(boxes[:, 4].sum())
+            assert 1 <= k <= 8 and torch.all(boxes[k:] == 0) and torch.all(crops[k:] == 0)
+            want_crops = torch.from_numpy(pil_crops(a, crop_px.numpy(), 224, True))
+            assert torch.equal(crops[:k].cpu(), want_crops)
+            assert torch.equal(det.cpu(), torch.from_numpy(pil_crops(a, np.array([[0, 0, W, H]], np.float32), 320, False))[0])
+            b = boxes[:k, :4].cpu()
+            assert float(b.min()) >= 0 and float(b.max()) <= 1.0 + 1e-6
+            # a grid cell of the original image maps to the same fraction of the resized content inside the padded square
+            scale = min(320 / H, 320 / W)
+            assert float(b[:, 2].max()) <= W * scale / 320 + 1e-6 and float(b[:, 3].max()) <= H * scale / 320 + 1e-6
+        batch = next(iter(loader))
+        assert batch[0].shape == (3, 3, 320, 320) and batch[1].shape == (3, 8, 5) and batch[2].shape == (3, 8, 3, 224, 224)
+
+
+def test_training_main_on_gpu_input_pipeline(tmp_path):
+    """`--train-data synthetic-raw`: decoded uint8 images -> GPU crop/resize pipeline -> CLIPSelf steps, through training.main."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, "-m", "clipself_amd.training.main", "--model", "EVA02-CLIP-B-16", "--pretrained", "eva", "--train-data", "synthetic-raw",
+           "--dataset-type", "grid_distill", "--batch-size", "4", "--max-boxes", "6", "--det-image-size", "224", "--synthetic-steps", "3",
+           "--epochs", "1", "--lock-image", "--lock-image-unlocked-groups", "12", "--lr", "1e-5", "--wd", "0.1", "--warmup", "10",
+           "--log-every-n-steps", "1", "--logs", str(tmp_path), "--cache-dir", "none.pt", "--name", "raw", "--zeroshot-frequency", "0"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("Train Epoch: 0") == 3 and "Loss_cosine" in r.stderr
