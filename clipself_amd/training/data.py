@@ -123,6 +123,59 @@ class GpuGridDistillLoader:
             yield tuple(torch.stack([p[i] for p in parts]) for i in range(3))
 
 
+class GpuProposalDistillLoader:
+    """ProposalDistillDataset (src/training/data.py:30-132) with the pixel work on the GPU: per decoded image and its annotation boxes
+    (x, y, w, h in pixels): annotations shuffled, the first max_anns considered, those outside [min_size^2, max_size^2] in area left as
+    empty slots, student box = the annotation, teacher crop = the box enlarged 1.5x about its centre and clipped to the image
+    (data.py:111-118), fallback to the top-left quarter image when nothing is valid (:122-124), boxes rescaled to the padded square."""
+
+    def __init__(self, images_u8, annotations, ops, batch_size, det_size, crop_size, min_size=8, max_size=1024, max_anns=20, steps=None, seed=0):
+        import random
+        self.images, self.anns, self.ops = images_u8, annotations, ops
+        self.batch_size, self.det_size, self.crop_size = batch_size, det_size, crop_size
+        self.min_size, self.max_size, self.max_anns = min_size, max_size, max_anns
+        self.num_batches = steps if steps is not None else len(images_u8) // batch_size
+        self.num_samples = self.num_batches * batch_size
+        self.rng = random.Random(seed)
+        self.epoch = 0
+
+    def __len__(self):
+        return self.num_batches
+
+    def sample(self, img, anns):
+        H, W = img.shape[0], img.shape[1]
+        dev = img.device
+        order = list(range(len(anns)))
+        self.rng.shuffle(order)
+        boxes = torch.zeros(self.max_anns, 5)
+        slots, crop_px = [], []
+        for i, a in enumerate(order[:self.max_anns]):
+            x, y, w, h = anns[a]
+            if w * h < self.min_size ** 2 or w * h > self.max_size ** 2:
+                continue
+            cx, cy = x + w * 0.5, y + h * 0.5
+            crop_px.append([max(cx - w * 0.75, 0), max(cy - h * 0.75, 0), min(cx + w * 0.75, W), min(cy + h * 0.75, H)])
+            boxes[i] = torch.tensor([x, y, x + w, y + h, 1.0])
+            slots.append(i)
+        if not slots:                                                   # avoid an empty image
+            boxes[0] = torch.tensor([0, 0, W / 4, H / 4, 1.0])
+            crop_px, slots = [[0, 0, W // 4, H // 4]], [0]
+        crop_px = torch.tensor(crop_px, dtype=torch.float32)
+        crops = torch.zeros(self.max_anns, 3, self.crop_size, self.crop_size, device=dev)
+        crops[slots] = self.ops.crop_resize(img, crop_px.to(dev), self.crop_size, pad_center=True)
+        det = self.ops.crop_resize(img, torch.tensor([[0.0, 0.0, float(W), float(H)]], device=dev), self.det_size, pad_center=False)[0]
+        boxes[:, :4] *= min(self.det_size / H, self.det_size / W) / self.det_size
+        return det, boxes.to(dev), crops, crop_px, slots
+
+    def __iter__(self):
+        order = list(range(len(self.images)))
+        __import__("random").Random(1000 + self.epoch).shuffle(order)
+        for b in range(self.num_batches):
+            ids = [order[(b * self.batch_size + j) % len(order)] for j in range(self.batch_size)]
+            parts = [self.sample(self.images[i], self.anns[i])[:3] for i in ids]
+            yield tuple(torch.stack([p[i] for p in parts]) for i in range(3))
+
+
 class SyntheticPanopticVal:
     """Batches shaped like the panoptic validation set (src/training/data.py:331-387) plus `.embeddings`: boxes from the synthetic
     recipe, a rectangular mask per box at feature-map resolution, a class per box and a things/stuff flag per class."""
@@ -166,8 +219,20 @@ def get_data(args, preprocess_fns=None, epoch=0, tokenizer=None):
         n = max(args.batch_size, 8)
         images = [torch.randint(0, 256, (*sizes[i % len(sizes)], 3), generator=g, dtype=torch.uint8).to(args.device) for i in range(n)]
         size = args.synthetic_image_size or args.det_image_size
-        loader = GpuGridDistillLoader(images, HipOps(), args.batch_size, args.max_boxes, size, args.input_size, max_split=args.max_split,
-                                      crop_scale=args.crop_scale, steps=args.synthetic_steps, seed=1234 + args.seed + 7919 * args.rank)
+        seed = 1234 + args.seed + 7919 * args.rank
+        if args.dataset_type == "proposals_distill":
+            anns = []
+            for im in images:                                           # random annotation boxes (x, y, w, h), a few of them tiny
+                H, W = im.shape[:2]
+                k = int(torch.randint(0, 12, (1,), generator=g))
+                xy = torch.rand(k, 2, generator=g) * torch.tensor([W * 0.7, H * 0.7])
+                wh = torch.rand(k, 2, generator=g) * torch.tensor([W * 0.3, H * 0.3]) + 2.0
+                anns.append(torch.cat([xy, wh], 1).tolist())
+            loader = GpuProposalDistillLoader(images, anns, HipOps(), args.batch_size, size, args.input_size, min_size=args.min_size,
+                                              max_size=args.max_size, steps=args.synthetic_steps, seed=seed)
+        else:
+            loader = GpuGridDistillLoader(images, HipOps(), args.batch_size, args.max_boxes, size, args.input_size, max_split=args.max_split,
+                                          crop_scale=args.crop_scale, steps=args.synthetic_steps, seed=seed)
         return {"train": DataInfo(loader)}
     if args.train_data != "synthetic":
         raise NotImplementedError(

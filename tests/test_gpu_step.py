@@ -391,3 +391,34 @@ def test_training_main_on_gpu_input_pipeline(tmp_path):
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stderr.count("Train Epoch: 0") == 3 and "Loss_cosine" in r.stderr
+
+
+def test_gpu_proposal_distill_loader_matches_pillow_pipeline():
+    """ProposalDistillDataset's contract (annotation boxes for the student, 1.5x enlarged clipped crops for the teacher, area filter
+    leaving empty slots, quarter-image fallback) produced on the GPU, against the same steps done with Pillow."""
+    import numpy as np
+    from clipself_amd.hip import HipOps
+    from clipself_amd.training.data import GpuProposalDistillLoader
+    from oracle.pil_crops_ref import pil_crops
+    rng = np.random.default_rng(9)
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in ((427, 640), (500, 333), (300, 300))]
+    anns = [[[30.0, 40.0, 200.0, 150.0], [5.0, 5.0, 3.0, 2.0], [400.0, 200.0, 239.5, 226.0], [100.2, 80.7, 50.3, 60.1]],   # one too small
+            [[10.0, 10.0, 300.0, 450.0]] + [[float(3 * i), float(5 * i), 40.0 + i, 30.0 + i] for i in range(25)],              # > max_anns
+            [[1.0, 1.0, 2.0, 2.0]]]                                                                                           # nothing valid
+    loader = GpuProposalDistillLoader([torch.from_numpy(a).cuda() for a in imgs], anns, HipOps(), batch_size=3, det_size=256, crop_size=224,
+                                      min_size=8, max_size=1024, steps=1, seed=11)
+    for a, t, an in zip(imgs, loader.images, anns):
+        det, boxes, crops, crop_px, slots = loader.sample(t, an)
+        H, W = a.shape[:2]
+        valid = boxes[:, 4].cpu() > 0.5
+        assert valid.nonzero()[:, 0].tolist() == sorted(slots) and 1 <= len(slots) <= 20
+        assert torch.equal(crops[slots].cpu(), torch.from_numpy(pil_crops(a, crop_px.numpy(), 224, True)))
+        assert torch.all(crops[~valid.to(crops.device)] == 0)
+        assert torch.equal(det.cpu(), torch.from_numpy(pil_crops(a, np.array([[0, 0, W, H]], np.float32), 256, False))[0])
+        # every teacher crop contains its student box (both in original pixels)
+        scale = min(256 / H, 256 / W)
+        sb = boxes[slots, :4].cpu() * 256 / scale
+        assert torch.all(crop_px[:, :2] <= sb[:, :2] + 1e-3) and torch.all(crop_px[:, 2:] >= sb[:, 2:] - 1e-3)
+    assert len(anns[2]) == 1 and loader.sample(loader.images[2], anns[2])[4] == [0]        # fallback slot
+    b = next(iter(loader))
+    assert b[0].shape == (3, 3, 256, 256) and b[1].shape == (3, 20, 5) and b[2].shape == (3, 20, 3, 224, 224)
