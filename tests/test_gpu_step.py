@@ -422,3 +422,26 @@ def test_gpu_proposal_distill_loader_matches_pillow_pipeline():
     assert len(anns[2]) == 1 and loader.sample(loader.images[2], anns[2])[4] == [0]        # fallback slot
     b = next(iter(loader))
     assert b[0].shape == (3, 3, 256, 256) and b[1].shape == (3, 20, 5) and b[2].shape == (3, 20, 3, 224, 224)
+
+
+def test_ragged_batch_with_an_image_without_valid_boxes_matches_oracle():
+    """Variable boxes per image (BASELINE configs[2] semantics: invalid rows dropped, clipself.py:29-36), including an image whose
+    boxes are ALL invalid: loss and gradients against the fp32 CPU oracle on the same inputs."""
+    from clipself_amd.training.clipself import CLIPSelf
+    from oracle import eva_ref
+    cfg = tiny_cfg()
+    student, teacher = _pair(cfg, 8)
+    sd = seeded_visual_state(cfg, 8)
+    images, boxes, crops = synthetic_batch(4, 5, cfg.image_size, cfg.image_size, seed=21, valid_prob=0.5)
+    boxes[2, :, 4] = 0.0                                           # image 2 contributes nothing
+    assert 0 < int(boxes[..., 4].sum()) < 20
+    out, bs, _ = CLIPSelf()((images.cuda(), boxes.cuda(), crops.cuda()), student, teacher, None, "cuda", None, False, _args())
+    out["loss_cosine"].backward()
+    leaves = {k: torch.as_tensor(v).clone().requires_grad_(True) for k, v in sd.items()}
+    want, _, _ = eva_ref.clipself_loss(leaves, {k: torch.as_tensor(v) for k, v in sd.items()}, cfg, (images, boxes, crops))
+    want.backward()
+    got = float(out["loss_cosine"].detach())
+    _log(f"ragged batch: loss {got:.6f} vs oracle {float(want):.6f}")
+    assert bs == 4 and abs(got - float(want)) < 2e-3 * abs(float(want))
+    for n in ("visual.blocks.0.mlp.w3.weight", "visual.blocks.1.attn.v_bias", "visual.blocks.0.norm1.weight"):
+        assert rel(dict(student.named_parameters())[n].grad, leaves[n].grad) < 6e-2, n
