@@ -71,6 +71,12 @@ __device__ __forceinline__ float sum_lanes8(float v) {
     return v;
 }
 
+__device__ __forceinline__ float sum_lanes16(float v) {      // aligned groups of 16 lanes: + row_mirror (lane i <-> 15 - i)
+    v = sum_lanes8(v);
+    v += dpp_move<0x140>(v);
+    return v;
+}
+
 // MFMA 32x32 accumulator register r of lane l holds C[row][col] with
 //   col = l & 31,  row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)        (cdna_hip_programming.md §3)
 __device__ __forceinline__ int mfma32_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

@@ -58,7 +58,10 @@ struct GemmArgs {
     const float* ln_mean;
     const float* ln_rstd;
     const float* ln_colsum;
-    float* stats_part;    // EPI_SWIGLU: optional per-(32-column slice, row) partial (sum, sum of squares) of the bf16 outputs
+    float* stats_part;    // optional per-(column slice, row) partial (sum, sum of squares) of the outputs: EPI_SWIGLU 32-column slices of
+                          // the rounded bf16 values, residual epilogues 64-column slices of the fp32 values
+    __bf16* xb_out;       // residual epilogues: optional bf16 copy of the fp32 output (operand of the next LN-folded GEMM)
+    int ldxb;
     int dbg;              // ablation switches for tools/gemm_bench.py: bit0 skip the in-loop operand DMA, bit1 skip ds_read+MFMA
 };
 
@@ -140,6 +143,19 @@ __device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, const f32x16 
     const int hl = hbase + l31;
     float b1 = 0.f, b2 = 0.f;
     if (p.bias && hl < p.group) { b1 = p.bias[hl]; b2 = p.bias[p.group + hl]; }
+    // LayerNorm folded into this GEMM (norm2 of a frozen tower): x1 = rstd*(acc1 - mean*c1) + b1, likewise x2; the rows' (mean, rstd)
+    // of this wave are staged behind its slab
+    const bool ln = p.ln_mean != nullptr;
+    float c1 = 0.f, c2 = 0.f;
+    float2* rowst = (float2*)(smem + wave * EP_BYTES + 4096);
+    if (ln) {
+        if (hl < p.group) { c1 = p.ln_colsum[hl]; c2 = p.ln_colsum[p.group + hl]; }
+        for (int r = lane; r < FM * 32; r += 64) {
+            const int row = min(row0 + r, p.M - 1);
+            rowst[r] = make_float2(p.ln_mean[row], p.ln_rstd[row]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     const int c4 = lane & 7, hcol = hbase + c4 * 4;
     const bool colok = hcol < p.group;
 #pragma unroll
@@ -149,7 +165,14 @@ __device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, const f32x16 
             float h[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {        // hardware exp2/rcp (1 ulp each; the result is rounded to bf16)
-                const float u = acc[i][0][e + t] + b1, v = acc[i][1][e + t] + b2;
+                float u = acc[i][0][e + t], v = acc[i][1][e + t];
+                if (ln) {
+                    const float2 st = rowst[i * 32 + mfma32_row(e + t, lane)];
+                    u = st.y * (u - st.x * c1);
+                    v = st.y * (v - st.x * c2);
+                }
+                u += b1;
+                v += b2;
                 h[t] = u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u)) * v;
             }
             union { bf16x2 v; uint32_t u; } pk;
@@ -214,6 +237,21 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& p, const f32x16 (&
         const int c = n0 + wn * 64 + j * 32 + l31;
         if (p.bias && c < p.N) bj[j] = p.bias[c];
     }
+    const bool ln = p.ln_mean != nullptr;      // LayerNorm folded into this GEMM (norm1 of a frozen tower), see epilogue_swiglu
+    float cj[2] = {0.f, 0.f};
+    float2* rowst = (float2*)(smem + wave * EP_BYTES + 4096);
+    if (ln) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = n0 + wn * 64 + j * 32 + l31;
+            if (c < p.N) cj[j] = p.ln_colsum[c];
+        }
+        for (int r = lane; r < FM * 32; r += 64) {
+            const int row = min(row0 + r, p.M - 1);
+            rowst[r] = make_float2(p.ln_mean[row], p.ln_rstd[row]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     const int c4 = lane & 15, col = n0 + wn * 64 + c4 * 4;
     const bool colok = col < p.N;
 #pragma unroll
@@ -222,9 +260,15 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& p, const f32x16 (&
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
+                float v0 = acc[i][j][e], v1 = acc[i][j][e + 1];
+                if (ln) {
+                    const float2 s0 = rowst[i * 32 + mfma32_row(e, lane)], s1 = rowst[i * 32 + mfma32_row(e + 1, lane)];
+                    v0 = s0.y * (v0 - s0.x * cj[j]);
+                    v1 = s1.y * (v1 - s1.x * cj[j]);
+                }
                 union { bf16x2 v; uint32_t u; } pk;
-                pk.v[0] = f2bf(acc[i][j][e] + bj[j]);
-                pk.v[1] = f2bf(acc[i][j][e + 1] + bj[j]);
+                pk.v[0] = f2bf(v0 + bj[j]);
+                pk.v[1] = f2bf(v1 + bj[j]);
                 const int rp = ((e & 3) >> 1) + 4 * (e >> 2) + 2 * hf;
                 slab[rp * 64 + j * 32 + l31] = pk.u;
             }
@@ -296,6 +340,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
             for (int e = 0; e < 16; ++e) slab[mfma32_row(e, lane) * EP_LD + j * 32 + l31] = acc[i][j][e];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         {
+            float ps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pq[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // per-row partial statistics (residual epilogues)
             if (col < p.N) {
                 float bv[4] = {0, 0, 0, 0};
                 if (p.bias) { const float4 t = *(const float4*)(p.bias + col); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
@@ -317,7 +362,18 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                         *(float4*)((float*)p.C + (size_t)blockIdx.y * p.split_stride + (size_t)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                     } else if (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
                         const float4 x = xin[it];
-                        *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
+                        const float o[4] = {x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]};
+                        *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
+                        if (p.xb_out) {                       // bf16 copy of the new residual stream: A operand of the next LN-folded GEMM
+                            U64 ob;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) ob.e[t] = f2bf(o[t]);
+                            *(uint2*)(p.xb_out + (size_t)row * p.ldxb + col) = ob.u;
+                        }
+                        if (p.stats_part) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) { ps[it] += o[t]; pq[it] += o[t] * o[t]; }
+                        }
                     } else if (EPI == EPI_ATOMIC_F32) {
                         float* d = (float*)p.C + (size_t)row * p.ldc + col;
 #pragma unroll
@@ -327,6 +383,22 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                         const float4 x = xin[it];
                         *(float4*)((float*)p.C + (size_t)(row + img + 1) * p.ldc + col) = make_float4(x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]);
                     }
+                }
+            }
+            if ((EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) && p.stats_part) {
+                // LayerNorm statistics of the fp32 outputs for the NEXT norm: a row's 64 columns of this slice sit in 16 adjacent lanes
+                // (DPP butterfly); lane (lane & 15) == it keeps iteration it's row, so the 32 rows leave in one 256-byte store.
+                const int sel = lane & 15;
+                float sv = 0.f, qv = 0.f;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const float a = sum_lanes16(ps[it]), b = sum_lanes16(pq[it]);
+                    if (sel == it) { sv = a; qv = b; }
+                }
+                const int row = row_base + rrow + 4 * sel;
+                if (sel < 8 && row < p.M && n0 + wn * 64 < p.N) {
+                    const size_t slice = (size_t)tn * (BN / 64) + wn;
+                    *(float2*)(p.stats_part + (slice * p.M + row) * 2) = make_float2(sv, qv);
                 }
             }
         }
@@ -803,8 +875,8 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 //       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue;
 //       bit 15: split-ring schedule issues its DMA in one burst behind the barrier instead of interleaved with the MFMAs
 static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias, const float* extra, const float* ln_mean,
-                        const float* ln_rstd, const float* ln_colsum, float* stats_part, int M, int N, int K, int lda, int ldb, int ldc,
-                        int epi, int splits, int group, int flags, hipStream_t stream) {
+                        const float* ln_rstd, const float* ln_colsum, float* stats_part, void* xb_out, int ldxb, int M, int N, int K, int lda,
+                        int ldb, int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
     CS_CHECK_ARG(M > 0 && N > 0 && K > 0, "cs_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
     CS_CHECK_ARG(K % BK == 0, "cs_gemm_nt: K=%d must be a multiple of %d", K, BK);
     CS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0, "cs_gemm_nt: lda/ldb must be multiples of 8 (16-byte rows)");
@@ -818,11 +890,19 @@ static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.group = group;
     a.split_stride = 0;
     a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_colsum = ln_colsum; a.stats_part = stats_part;
+    a.xb_out = (__bf16*)xb_out; a.ldxb = ldxb;
     a.tiles_m = a.tiles_n = 0;
     a.gm = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 8;
     if (epi == EPI_SWIGLU_BF16) CS_CHECK_ARG(group > 0 && N == 2 * group, "cs_gemm_nt: swiglu epilogue needs N == 2*group");
     if (epi == EPI_RESID_LN_F32) CS_CHECK_ARG(ln_mean && ln_rstd && ln_colsum && ((uintptr_t)ln_colsum % 16) == 0, "cs_gemm_nt_ln: epilogue 6 needs mean, rstd and a 16-byte aligned column-sum vector");
-    CS_CHECK_ARG(stats_part == nullptr || epi == EPI_SWIGLU_BF16, "cs_gemm_nt_ln: statistics output only exists for the SwiGLU epilogue");
+    CS_CHECK_ARG(stats_part == nullptr || epi == EPI_SWIGLU_BF16 || epi == EPI_RESID_F32 || epi == EPI_RESID_LN_F32,
+                 "cs_gemm_nt_ln: statistics output exists for the SwiGLU and residual epilogues");
+    CS_CHECK_ARG(xb_out == nullptr || ((epi == EPI_RESID_F32 || epi == EPI_RESID_LN_F32) && ldxb % 4 == 0 && ((uintptr_t)xb_out % 8) == 0),
+                 "cs_gemm_nt_ln: the bf16 copy exists for the residual epilogues (8-byte aligned, ldxb %% 4 == 0)");
+    CS_CHECK_ARG((ln_mean == nullptr) == (ln_rstd == nullptr) && (ln_mean == nullptr || ln_colsum != nullptr),
+                 "cs_gemm_nt_ln: mean, rstd and the column-sum vector come together");
+    CS_CHECK_ARG(ln_mean == nullptr || epi == EPI_BF16 || epi == EPI_SWIGLU_BF16 || epi == EPI_RESID_LN_F32,
+                 "cs_gemm_nt_ln: a folded LayerNorm exists for epilogues 0, 3 and 6");
     if (epi == EPI_PATCH_F32 || epi == EPI_RESID_F32 || epi == EPI_RESID_LN_F32) CS_CHECK_ARG(extra != nullptr && ((uintptr_t)extra % 16) == 0, "cs_gemm_nt: epilogue %d needs 16-byte aligned extra", epi);
     if (epi == EPI_PATCH_F32) CS_CHECK_ARG(group > 0, "cs_gemm_nt: patch epilogue needs group");
     a.ktiles_per_split = K / BK;
@@ -851,7 +931,7 @@ static int gemm_nt_split_f32(const void* A, const void* B, float* C, int M, int 
     a.A = (const __bf16*)A; a.B = (const __bf16*)B; a.C = C; a.bias = nullptr; a.extra = nullptr;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = N; a.group = 0;
     a.split_stride = (long)M * N;
-    a.ln_mean = a.ln_rstd = a.ln_colsum = nullptr; a.stats_part = nullptr;
+    a.ln_mean = a.ln_rstd = a.ln_colsum = nullptr; a.stats_part = nullptr; a.xb_out = nullptr; a.ldxb = 0;
     a.tiles_m = a.tiles_n = 0; a.gm = 8; a.dbg = 0;
     a.ktiles_per_split = K / BK;
     return launch<EPI_F32>(a, splits, 1, cfg, stream);
@@ -860,17 +940,22 @@ static int gemm_nt_split_f32(const void* A, const void* B, float* C, int M, int 
 extern "C" int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
                           int lda, int ldb, int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
     CS_CHECK_ARG(epi != EPI_RESID_LN_F32, "cs_gemm_nt: epilogue 6 (folded LayerNorm) is reached through cs_gemm_nt_ln");
-    return gemm_nt_impl(A, B, C, bias, extra, nullptr, nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldc, epi, splits, group, flags, stream);
+    return gemm_nt_impl(A, B, C, bias, extra, nullptr, nullptr, nullptr, nullptr, nullptr, 0, M, N, K, lda, ldb, ldc, epi, splits, group, flags, stream);
 }
 
 // cs_gemm_nt plus the folded-LayerNorm operands (frozen towers; see GemmArgs):
 //   epi 6: C = extra + ln_rstd[m] * (A.B^T - ln_mean[m] * ln_colsum[n]) + bias[n]     (A un-normalised, B = gamma (.) W)
 //   epi 3 with stats_part != null: also writes, per 32-hidden-unit slice s and row m, (sum, sum of squares) of the rounded
 //          outputs to stats_part[(s*M + m)*2 ..]; slices = 4*ceil(group/128); combine with cs_ln_stats_finalize.
+//   epi 0 / 3 with ln_mean != null: the LayerNorm in front of the GEMM is folded the same way (norm1 -> q|k|v, norm2 -> W1|W2):
+//          A = bf16 copy of the un-normalised rows, value = ln_rstd[m] * (acc - ln_mean[m] * ln_colsum[n]) + bias[n] before bf16 / SiLU.
+//   epi 2 / 6 with xb_out != null: also stores that bf16 copy of the fp32 output (row stride ldxb); with stats_part != null also the
+//          per-64-column-slice (sum, sum of squares) of the fp32 outputs, stats_part[(s*M + m)*2 ..], slices = ceil(N/64).
 extern "C" int cs_gemm_nt_ln(const void* A, const void* B, void* C, const float* bias, const float* extra, const float* ln_mean,
-                             const float* ln_rstd, const float* ln_colsum, float* stats_part, int M, int N, int K, int lda, int ldb,
-                             int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
-    return gemm_nt_impl(A, B, C, bias, extra, ln_mean, ln_rstd, ln_colsum, stats_part, M, N, K, lda, ldb, ldc, epi, splits, group, flags, stream);
+                             const float* ln_rstd, const float* ln_colsum, float* stats_part, void* xb_out, int ldxb, int M, int N, int K,
+                             int lda, int ldb, int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
+    return gemm_nt_impl(A, B, C, bias, extra, ln_mean, ln_rstd, ln_colsum, stats_part, xb_out, ldxb, M, N, K, lda, ldb, ldc, epi, splits, group,
+                        flags, stream);
 }
 
 

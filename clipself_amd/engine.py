@@ -129,6 +129,9 @@ class EvaEngine:
         # gamma goes into a bf16 copy of the weight, beta and the row statistics into the GEMM epilogue, and the statistics
         # come out of the producing kernels' epilogues -- the LN passes over [M,C] and [M,hidden] disappear (_block_post_folded).
         self.fold_sub_ln = not trainable
+        # ... and, in encode_image(), the block LayerNorms norm1 / norm2 as well: the residual GEMMs also emit a bf16 copy of the new
+        # stream and its row statistics, the q|k|v and W1|W2 GEMMs apply the normalisation in their epilogues (_teacher_block_folded)
+        self.fold_block_ln = not trainable
         self.fold = {}
         if trainable:
             self.grad = ops.zeros((self.numel,), F32)
@@ -200,6 +203,16 @@ class EvaEngine:
                     Wf = torch.zeros_like(W, dtype=BF16)
                     Wf[:, :K] = (W[:, :K] * g[None, :]).to(BF16)
                     out[key] = (Wf, Wf.float().sum(dim=1).contiguous(), (W[:, :K] @ beta + self.p[b + bname]).contiguous())
+                if self.fold_block_ln:
+                    # norm1 -> [Wq;Wk;Wv] and norm2 -> [W1;W2]: the stacked matrices and biases are adjacent in the flat store
+                    Hd = self.Hp
+                    for key, wname, bias_name, ln, rows in (("qkv", "attn.q_proj.weight", "attn.q_bias", "norm1", 3 * C),
+                                                           ("w12", "mlp.w1.weight", "mlp.w1.bias", "norm2", 2 * Hd)):
+                        o, ob = self.offsets[b + wname][0], self.offsets[b + bias_name][0]
+                        W, bias = self.master[o:o + rows * C].view(rows, C), self.master[ob:ob + rows]
+                        g, beta = self.p[b + ln + ".weight"], self.p[b + ln + ".bias"]
+                        Wf = (W * g[None, :]).to(BF16).contiguous()
+                        out[key] = (Wf, Wf.float().sum(dim=1).contiguous(), (W @ beta + bias).contiguous())
                 self.fold[i] = out
 
     def _wt_alloc(self, key, rows, cols):
@@ -397,6 +410,51 @@ class EvaEngine:
         ops.gemm_nt_ln(hid, W3, x, bias=d3, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=c3, epi=EPI_RESID_LN_F32)
         return x
 
+    def _teacher_block_folded(self, i, x, xb, st, B, N, cos, sin, emit_next):
+        """One frozen-tower block with all four LayerNorms folded into the GEMMs (in place on x).  xb / st = bf16 copy and (mean, rstd)
+        of x for norm1 as left by the previous block's w3 GEMM, or None (first block: plain norm1 kernel).  Returns (xb, st) for the
+        next block when emit_next."""
+        ops, cfg = self.ops, self.cfg
+        C, Hd, Hl, H, eps = cfg.width, self.Hp, cfg.hidden, cfg.heads, cfg.ln_eps
+        b = f"{self.prefix}blocks.{i}."
+        M = B * N
+        f = self.fold[i]
+        qkv = ops.empty((M, 3 * C), BF16)
+        if xb is None:
+            ln1 = ops.empty((M, C), BF16)
+            ops.layernorm_fwd(x, self.p[b + "norm1.weight"], self.p[b + "norm1.bias"], ln1, None, None, eps)
+            wqkv, bqkv = self._qkv_w(b)
+            ops.gemm_nt(ln1, wqkv, qkv, bias=bqkv, epi=EPI_BF16)
+        else:
+            Wq, cq, dq = f["qkv"]
+            ops.gemm_nt_ln(xb, Wq, qkv, bias=dq, ln_mean=st[0], ln_rstd=st[1], ln_colsum=cq, epi=EPI_BF16)
+        att = ops.empty((M, C), BF16)
+        part_a = ops.empty((H, M, 2), F32)
+        ops.attn_fwd_stats(qkv, cos, sin, att, None, part_a, B, N, H, cfg.head_width ** -0.5)
+        mean, rstd = ops.empty((M,), F32), ops.empty((M,), F32)
+        ops.ln_stats_finalize(part_a, 64, C, mean, rstd, eps)
+        Wp, cp, dp = f["proj"]
+        part_x = ops.empty(((C + 63) // 64, M, 2), F32)
+        xb2 = ops.empty((M, C), BF16)
+        ops.gemm_nt_ln(att, Wp, x, bias=dp, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=cp, stats_part=part_x, xb_out=xb2,
+                       epi=EPI_RESID_LN_F32)
+        mean2, rstd2 = ops.empty((M,), F32), ops.empty((M,), F32)
+        ops.ln_stats_finalize(part_x, 64, C, mean2, rstd2, eps)
+        W12, c12, d12 = f["w12"]
+        hid = ops.empty((M, Hd), BF16)
+        part_h = ops.empty((4 * ((Hd + 127) // 128), M, 2), F32)
+        ops.gemm_nt_ln(xb2, W12, hid, bias=d12, ln_mean=mean2, ln_rstd=rstd2, ln_colsum=c12, stats_part=part_h, epi=EPI_SWIGLU_BF16,
+                       group=Hd)
+        ops.ln_stats_finalize(part_h, 32, Hl, mean, rstd, eps)
+        W3, c3, d3 = f["w3"]
+        if not emit_next:
+            ops.gemm_nt_ln(hid, W3, x, bias=d3, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=c3, epi=EPI_RESID_LN_F32)
+            return None, None
+        ops.gemm_nt_ln(hid, W3, x, bias=d3, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=c3, stats_part=part_x, xb_out=xb2,
+                       epi=EPI_RESID_LN_F32)
+        ops.ln_stats_finalize(part_x, 64, C, mean2, rstd2, eps)
+        return xb2, (mean2, rstd2)
+
     def _block_fwd_cls(self, i, x, B, N, cos, sin):
         """Last teacher block restricted to what encode_image() consumes: the CLS row.  x fp32 [B*N, C] -> fp32 [B, C].
         forward_features() returns x[:, 0] after the final norm (eva_vit_model.py:505-519), so only the CLS *query* of the
@@ -432,8 +490,12 @@ class EvaEngine:
             cos, sin = self.rope_tables(g)
             xf = x.view(B * N, cfg.width)
             last = cfg.layers - 1 if self.cls_only_last_block else cfg.layers
+            xb = st = None
             for i in range(last):
-                self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
+                if self.fold_sub_ln and self.fold_block_ln:
+                    xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last)
+                else:
+                    self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
             xc = self._block_fwd_cls(last, xf, B, N, cos, sin) if last < cfg.layers else x[:, 0, :]
             cls = ops.empty((B, cfg.width), BF16)
             ops.layernorm_fwd(xc, self.p[P + "norm.weight"], self.p[P + "norm.bias"], cls, None, None, cfg.ln_eps)

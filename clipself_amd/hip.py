@@ -30,7 +30,7 @@ SIGNATURES = {
     "cs_crop_resize_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cs_gemm_wgrad_workspace": (_sz, [_i, _i, _i]),
     "cs_gemm_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "cs_gemm_nt_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cs_gemm_nt_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_ln_stats_finalize": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "cs_attn_fwd_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_layernorm_fwd": (_i, [_vp, _i, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _vp]),
@@ -144,37 +144,22 @@ class HipOps:
         self._ok(self.lib.cs_gemm_nt(_p(A), _p(B), _p(C), _p(bias), _p(extra), M, N, K, A.stride(0), B.stride(0),
                                      C.stride(0), epi, splits, group, flags, self._stream()), "cs_gemm_nt")
 
-    def gemm_nt_ln(self, A, B, C, bias=None, extra=None, ln_mean=None, ln_rstd=None, ln_colsum=None, stats_part=None,
+    def gemm_nt_ln(self, A, B, C, bias=None, extra=None, ln_mean=None, ln_rstd=None, ln_colsum=None, stats_part=None, xb_out=None,
                    epi=EPI_RESID_LN_F32, group=0, flags=0):
-        self._chk(A, B, C, bias, extra, ln_mean, ln_rstd, ln_colsum, stats_part)
+        self._chk(A, B, C, bias, extra, ln_mean, ln_rstd, ln_colsum, stats_part, xb_out)
         M, K = A.shape
         N = B.shape[0]
         assert B.shape[1] == K and A.stride(1) == 1 and B.stride(1) == 1 and C.stride(-1) == 1
         if extra is not None and epi in (EPI_RESID_F32, EPI_RESID_LN_F32):
             assert extra.stride(0) == C.stride(0), "extra must share C's row stride"
         if stats_part is not None:
-            assert stats_part.is_contiguous() and stats_part.shape[0] >= 4 * ((group + 127) // 128) and stats_part.shape[1] == M
+            slices = 4 * ((group + 127) // 128) if epi == EPI_SWIGLU_BF16 else (N + 63) // 64
+            assert stats_part.is_contiguous() and stats_part.shape[0] >= slices and stats_part.shape[1] == M
+        if xb_out is not None:
+            assert xb_out.dtype == torch.bfloat16 and xb_out.stride(1) == 1 and xb_out.shape[0] == M
         self._ok(self.lib.cs_gemm_nt_ln(_p(A), _p(B), _p(C), _p(bias), _p(extra), _p(ln_mean), _p(ln_rstd), _p(ln_colsum), _p(stats_part),
-                                        M, N, K, A.stride(0), B.stride(0), C.stride(0), epi, 1, group, flags, self._stream()), "cs_gemm_nt_ln")
-
-    def crop_resize(self, image_u8, boxes, size, pad_center=True, mean=(0.48145466, 0.4578275, 0.40821073),
-                    std=(0.26862954, 0.26130258, 0.27577711), out=None):
-        """image_u8 [H,W,3] uint8 on the GPU, boxes [K,4] f32 pixel xyxy -> [K,3,size,size] f32: crop, Pillow-exact bicubic resize of
-        the longest side to `size`, zero pad (centred or right/bottom), /255, normalise (defaults: the OpenAI CLIP statistics)."""
-        self._chk(image_u8, boxes, out)
-        assert image_u8.dtype == torch.uint8 and image_u8.dim() == 3 and image_u8.shape[2] == 3 and image_u8.is_contiguous()
-        boxes = boxes.to(torch.float32).contiguous()
-        H, W, K = image_u8.shape[0], image_u8.shape[1], boxes.shape[0]
-        if out is None:
-            out = torch.empty((K, 3, size, size), dtype=torch.float32, device=image_u8.device)
-        need = int(self.lib.cs_crop_resize_workspace(H, K, size))
-        ws = getattr(self, "_crop_ws", None)
-        if ws is None or ws.numel() < need:
-            ws = self._crop_ws = torch.empty(need, dtype=torch.uint8, device=image_u8.device)
-        m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
-        self._ok(self.lib.cs_crop_resize_u8(_p(image_u8), H, W, _p(boxes), K, size, int(bool(pad_center)), m3, s3, _p(out), _p(ws),
-                                            self._stream()), "cs_crop_resize_u8")
-        return out
+                                        _p(xb_out), xb_out.stride(0) if xb_out is not None else 0, M, N, K, A.stride(0), B.stride(0),
+                                        C.stride(0), epi, 1, group, flags, self._stream()), "cs_gemm_nt_ln")
 
     def gemm_wgrad_workspace(self, M, N, K) -> int:
         return int(self.lib.cs_gemm_wgrad_workspace(M, N, K))

@@ -41,15 +41,19 @@ size_t cs_gemm_wgrad_workspace(int M, int N, int K);
 int cs_gemm_wgrad(const void* A, const void* B, float* dW, void* workspace, int M, int N, int K, int lda, int ldb, int ldc,
                   cs_stream_t stream);
 
-/* cs_gemm_nt with a sub-LayerNorm folded in (frozen teacher; SwiGLU.ffn_ln eva_vit_model.py:102 ahead of w3, Attention.inner_attn_ln
- * :218 ahead of proj): the GEMM reads the *un-normalised* bf16 rows, B = gamma (.) W, and
- *   epi 6: C = extra + ln_rstd[m] * (A.B^T - ln_mean[m] * ln_colsum[n]) + bias[n],  ln_colsum[n] = sum_k B[n,k],  bias = W.beta + b.
- *   epi 3 with stats_part != NULL additionally writes, per 32-hidden-unit slice s and row m, (sum, sum of squares) of the rounded
- *          outputs to stats_part[(s*M + m)*2 ..]  (4*ceil(group/128) slices); cs_ln_stats_finalize turns them into mean/rstd.
- * All other epilogues behave as in cs_gemm_nt (the LN pointers are ignored). */
+/* cs_gemm_nt with a LayerNorm folded in (frozen teacher): the GEMM reads the *un-normalised* bf16 rows, B = gamma (.) W,
+ * ln_colsum[n] = sum_k B[n,k], bias = W.beta + b, and the epilogue applies rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]:
+ *   epi 6: residual form, C = extra + that value                  (SwiGLU.ffn_ln -> w3 eva_vit_model.py:102-103, inner_attn_ln -> proj :218-219)
+ *   epi 0 / 3 with ln_mean != NULL: before the bf16 store / before SiLU*mul   (Block.norm1 -> q|k|v :306,176-179; norm2 -> w1|w2 :307,99-101)
+ * and the epilogues can emit what the NEXT folded GEMM needs, so that no LayerNorm pass over the activations is left:
+ *   epi 3 with stats_part != NULL: per 32-hidden-unit slice s and row m, (sum, sum of squares) of the rounded outputs at
+ *          stats_part[(s*M + m)*2 ..]  (4*ceil(group/128) slices);
+ *   epi 2 / 6 with stats_part != NULL: the same per 64-column slice of the fp32 outputs (ceil(N/64) slices); with xb_out != NULL a bf16
+ *          copy of the fp32 output (row stride ldxb).  cs_ln_stats_finalize turns the partials into mean/rstd.
+ * All other arguments as in cs_gemm_nt. */
 int cs_gemm_nt_ln(const void* A, const void* B, void* C, const float* bias, const float* extra, const float* ln_mean,
-                  const float* ln_rstd, const float* ln_colsum, float* stats_part, int M, int N, int K, int lda, int ldb, int ldc,
-                  int epi, int splits, int group, int flags, cs_stream_t stream);
+                  const float* ln_rstd, const float* ln_colsum, float* stats_part, void* xb_out, int ldxb, int M, int N, int K, int lda,
+                  int ldb, int ldc, int epi, int splits, int group, int flags, cs_stream_t stream);
 
 /* --- LayerNorm(eps, biased var): src/open_clip/eva_clip/transformer.py:52-58 used at eva_vit_model.py:306-307 (norm1/2),
  *     :218 (inner_attn_ln), :102 (ffn_ln), :565/:616 (final norm); replaces apex FusedLayerNorm / F.layer_norm.

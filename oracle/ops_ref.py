@@ -74,15 +74,31 @@ class RefOps:
         else:
             raise ValueError(epi)
 
-    def gemm_nt_ln(self, A, B, C, bias=None, extra=None, ln_mean=None, ln_rstd=None, ln_colsum=None, stats_part=None,
+    def gemm_nt_ln(self, A, B, C, bias=None, extra=None, ln_mean=None, ln_rstd=None, ln_colsum=None, stats_part=None, xb_out=None,
                    epi=EPI_RESID_LN_F32, group=0, flags=0):
-        if epi == EPI_RESID_LN_F32:
-            acc = A.float() @ B.float().T
-            C.copy_(extra + ln_rstd[:, None] * (acc - ln_mean[:, None] * ln_colsum[None, :]) + bias)
+        acc = A.float() @ B.float().T
+        if ln_mean is not None:                                    # folded LayerNorm: rstd * (acc - mean * colsum)
+            acc = ln_rstd[:, None] * (acc - ln_mean[:, None] * ln_colsum[None, :])
+        if bias is not None:
+            acc = acc + bias
+        if epi in (EPI_RESID_F32, EPI_RESID_LN_F32):
+            o = extra + acc
+            C.copy_(o)
+            if xb_out is not None:
+                xb_out[:, :o.shape[1]] = o.to(torch.bfloat16)
+            if stats_part is not None:                             # per 64-column slice (sum, sum of squares) of the fp32 outputs
+                for s in range((o.shape[1] + 63) // 64):
+                    blk = o[:, 64 * s:64 * s + 64]
+                    stats_part[s, :, 0] = blk.sum(-1)
+                    stats_part[s, :, 1] = (blk * blk).sum(-1)
             return
-        self.gemm_nt(A, B, C, bias=bias, extra=extra, epi=epi, group=group)
+        if epi == EPI_BF16:
+            C.copy_(acc.to(torch.bfloat16))
+            return
+        assert epi == EPI_SWIGLU_BF16
+        x1, x2 = acc[:, :group], acc[:, group:]
+        C.copy_((F.silu(x1) * x2).to(torch.bfloat16))
         if stats_part is not None:                                 # per 32-column slice (sum, sum of squares) of the rounded outputs
-            assert epi == EPI_SWIGLU_BF16
             h = C.float()
             for s in range(stats_part.shape[0]):
                 blk = h[:, 32 * s:32 * s + 32]

@@ -87,11 +87,15 @@ def test_folded_sub_layernorms_match_the_unfolded_teacher(gold):
     _, _, crops = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"])
     eng = _engine(cfg, rec["seed_w"], False)
     eng.cls_only_last_block = False               # every block through the folded path
+    assert eng.fold_block_ln                      # norm1 / norm2 folded as well (bf16 copy + statistics from the residual GEMMs)
     folded = eng.encode_image(crops.flatten(0, 1), chunk=5)
+    eng.fold_block_ln = False                     # only the two sub-LayerNorms folded
+    sub_only = eng.encode_image(crops.flatten(0, 1), chunk=5)
     eng.fold_sub_ln = False
     plain = eng.encode_image(crops.flatten(0, 1), chunk=5)
-    cos = torch.nn.functional.cosine_similarity(folded.double(), plain.double(), dim=-1)
-    assert rel(folded, plain) < 1e-2 and float((1 - cos).max()) < 1e-4
+    for other in (sub_only, folded):
+        cos = torch.nn.functional.cosine_similarity(other.double(), plain.double(), dim=-1)
+        assert rel(other, plain) < 1e-2 and float((1 - cos).max()) < 1e-4
     assert rel(folded, g["teacher"]) < 2e-2
     cosg = torch.nn.functional.cosine_similarity(folded.double(), torch.as_tensor(g["teacher"]).double(), dim=-1)
     assert float((1 - cosg).max()) < 2e-4

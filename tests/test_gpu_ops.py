@@ -326,6 +326,65 @@ def test_gemm_swiglu_stats_finalize_and_folded_w3(hip, ref, Hd, Hl, M, flags):
     check(tag + ".vs_unfolded", out_d - res.cuda(), plain - res, 1e-2)
 
 
+@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x70, 0x80])
+@pytest.mark.parametrize("M,C,Hd", [(394, 768, 2048), (130, 192, 384), (1000, 1024, 2752)])
+def test_block_layernorms_folded_into_gemms(hip, ref, M, C, Hd, flags):
+    """norm1 -> q|k|v and norm2 -> W1|W2 folded into the GEMM epilogues, fed by the residual GEMM's bf16 copy + row statistics:
+    each call against its reference op, and the chain against plain LayerNorm -> GEMM on the same residual stream."""
+    K0 = 128
+    A0, Wp, res = rnd((M, K0), BF, seed=70), rnd((C, K0), BF, 0.1, seed=71), rnd((M, C), F32, 2.0, seed=72) + 0.3
+    bp = rnd((C,), F32, seed=73)
+    P = (C + 63) // 64
+    # residual GEMM emitting the bf16 copy and the per-slice statistics
+    x_r, xb_r, part_r = torch.empty(M, C), torch.zeros(M, C, dtype=BF), torch.zeros(P, M, 2)
+    ref.gemm_nt_ln(A0, Wp, x_r, bias=bp, extra=res, stats_part=part_r, xb_out=xb_r, epi=2)
+    x_d = res.cuda().clone()
+    xb_d = torch.zeros(M, C, dtype=BF, device="cuda")
+    part_d = torch.full((P, M, 2), float("nan"), device="cuda")
+    hip.gemm_nt_ln(A0.cuda(), Wp.cuda(), x_d, bias=bp.cuda(), extra=x_d, stats_part=part_d, xb_out=xb_d, epi=2, flags=flags)
+    tag = f"blockfold[{M},{C},{Hd}] flags={flags}"
+    check(tag + ".x", x_d, x_r, TOL_F32)
+    check(tag + ".xb", xb_d, xb_r, TOL_BF)
+    mean_d, rstd_d = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    hip.ln_stats_finalize(part_d, 64, C, mean_d, rstd_d, 1e-6)
+    xf = x_d.cpu()
+    check(tag + ".mean", mean_d, xf.mean(-1), 1e-5)
+    check(tag + ".rstd", rstd_d, torch.rsqrt(xf.var(-1, unbiased=False) + 1e-6), 1e-5)
+    # q|k|v-style GEMM with norm folded in
+    g, beta = rnd((C,), F32, 0.2, seed=74) + 1.0, rnd((C,), F32, 0.1, seed=75)
+    N = 3 * 64
+    W, bq = rnd((N, C), F32, 0.05, seed=76), rnd((N,), F32, seed=77)
+    Wf = (W * g).to(BF)
+    cs, d = Wf.float().sum(1), W @ beta + bq
+    q_r = torch.empty(M, N, dtype=BF)
+    ref.gemm_nt_ln(xb_d.cpu(), Wf, q_r, bias=d, ln_mean=mean_d.cpu(), ln_rstd=rstd_d.cpu(), ln_colsum=cs, epi=0)
+    q_d = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+    hip.gemm_nt_ln(xb_d, Wf.cuda(), q_d, bias=d.cuda(), ln_mean=mean_d, ln_rstd=rstd_d, ln_colsum=cs.cuda(), epi=0, flags=flags)
+    check(tag + ".qkv", q_d, q_r, TOL_BF)
+    ln = torch.empty(M, C, dtype=BF)
+    ref.layernorm_fwd(xf, g, beta, ln, None, None, 1e-6)
+    plain = torch.empty(M, N, dtype=BF)
+    ref.gemm_nt(ln, W.to(BF), plain, bq, epi=0)
+    check(tag + ".qkv_vs_unfolded", q_d, plain, 1.2e-2)
+    # W1|W2-style GEMM with norm folded in, SiLU*mul + statistics of the result
+    W12, b12 = rnd((2 * Hd, C), F32, 0.05, seed=78), rnd((2 * Hd,), F32, 0.3, seed=79)
+    W12f = (W12 * g).to(BF)
+    c12, d12 = W12f.float().sum(1), W12 @ beta + b12
+    Ph = 4 * ((Hd + 127) // 128)
+    h_r, ph_r = torch.empty(M, Hd, dtype=BF), torch.zeros(Ph, M, 2)
+    ref.gemm_nt_ln(xb_d.cpu(), W12f, h_r, bias=d12, ln_mean=mean_d.cpu(), ln_rstd=rstd_d.cpu(), ln_colsum=c12, stats_part=ph_r, epi=3, group=Hd)
+    h_d = torch.full((M, Hd), float("nan"), dtype=BF, device="cuda")
+    ph_d = torch.full((Ph, M, 2), float("nan"), device="cuda")
+    hip.gemm_nt_ln(xb_d, W12f.cuda(), h_d, bias=d12.cuda(), ln_mean=mean_d, ln_rstd=rstd_d, ln_colsum=c12.cuda(), stats_part=ph_d, epi=3,
+                   group=Hd, flags=flags)
+    check(tag + ".hid", h_d, h_r, 6e-3)
+    mh, rh = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    hip.ln_stats_finalize(ph_d, 32, Hd, mh, rh, 1e-6)
+    hf = h_d.float().cpu()
+    check(tag + ".hid_mean", mh, hf.mean(-1), 1e-4)
+    check(tag + ".hid_rstd", rh, torch.rsqrt(hf.var(-1, unbiased=False) + 1e-6), 1e-4)
+
+
 @pytest.mark.parametrize("B,Ntok,H", [(3, 197, 12), (2, 577, 16), (4, 17, 2)])
 def test_attention_fwd_stats_and_layernorm_stats_only(hip, ref, B, Ntok, H):
     C = H * 64
