@@ -150,6 +150,8 @@ def main():
                     help="run the teacher's last block over every token instead of the CLS query only (same outputs, more work)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the teacher inline on the main stream instead of one batch ahead on a side stream (A/B switch)")
+    ap.add_argument("--no-block-ln-fold", action="store_true",
+                    help="keep norm1 / norm2 of the teacher as LayerNorm kernels (only the two sub-LayerNorms folded; A/B switch)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
@@ -180,6 +182,7 @@ def main():
     teacher = create_model(MODEL, "eva", precision="amp_bf16", device=device, cache_dir=None, trainable=False)
     teacher.visual.teacher_chunk = a.teacher_chunk
     teacher.visual.engine.cls_only_last_block = not a.full_last_block
+    teacher.visual.engine.fold_block_ln = not a.no_block_ln_fold
     cfg = student.visual.cfg
     student.lock_image_tower(unlocked_groups=cfg.layers)
     student.train()

@@ -161,6 +161,25 @@ class HipOps:
                                         _p(xb_out), xb_out.stride(0) if xb_out is not None else 0, M, N, K, A.stride(0), B.stride(0),
                                         C.stride(0), epi, 1, group, flags, self._stream()), "cs_gemm_nt_ln")
 
+    def crop_resize(self, image_u8, boxes, size, pad_center=True, mean=(0.48145466, 0.4578275, 0.40821073),
+                    std=(0.26862954, 0.26130258, 0.27577711), out=None):
+        """image_u8 [H,W,3] uint8 on the GPU, boxes [K,4] f32 pixel xyxy -> [K,3,size,size] f32: crop, Pillow-exact bicubic resize of
+        the longest side to `size`, zero pad (centred or right/bottom), /255, normalise (defaults: the OpenAI CLIP statistics)."""
+        self._chk(image_u8, boxes, out)
+        assert image_u8.dtype == torch.uint8 and image_u8.dim() == 3 and image_u8.shape[2] == 3 and image_u8.is_contiguous()
+        boxes = boxes.to(torch.float32).contiguous()
+        H, W, K = image_u8.shape[0], image_u8.shape[1], boxes.shape[0]
+        if out is None:
+            out = torch.empty((K, 3, size, size), dtype=torch.float32, device=image_u8.device)
+        need = int(self.lib.cs_crop_resize_workspace(H, K, size))
+        ws = getattr(self, "_crop_ws", None)
+        if ws is None or ws.numel() < need:
+            ws = self._crop_ws = torch.empty(need, dtype=torch.uint8, device=image_u8.device)
+        m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+        self._ok(self.lib.cs_crop_resize_u8(_p(image_u8), H, W, _p(boxes), K, size, int(bool(pad_center)), m3, s3, _p(out), _p(ws),
+                                            self._stream()), "cs_crop_resize_u8")
+        return out
+
     def gemm_wgrad_workspace(self, M, N, K) -> int:
         return int(self.lib.cs_gemm_wgrad_workspace(M, N, K))
 
