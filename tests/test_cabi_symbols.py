@@ -33,3 +33,18 @@ def test_ops_refuse_to_run_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         hip.HipOps()
+
+
+def test_every_entry_point_has_a_tensor_level_wrapper_and_a_reference_op():
+    """HipOps (product) and RefOps (test infrastructure) both cover the whole C ABI: a wrapper silently dropped from either would
+    otherwise only surface on the GPU box."""
+    from clipself_amd import hip
+    from oracle.ops_ref import RefOps
+    renamed = {"cs_crop_resize_u8": "crop_resize"}
+    for sym in hip.SIGNATURES:
+        if sym == "cs_last_error" or sym == "cs_crop_resize_workspace":
+            continue
+        name = renamed.get(sym, sym[len("cs_"):])
+        assert callable(getattr(hip.HipOps, name, None)), f"HipOps.{name} missing for {sym}"
+        if sym not in ("cs_crop_resize_u8",):                 # pinned directly against Pillow (oracle/pil_crops_ref.py)
+            assert callable(getattr(RefOps, name, None)), f"RefOps.{name} missing for {sym}"
