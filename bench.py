@@ -87,12 +87,15 @@ def isolated_swiglu_gemm(ops, M, cfg, launches=5):
     bias = torch.randn(2 * Hd, device="cuda")
     hid = torch.empty(M, Hd, dtype=torch.bfloat16, device="cuda")
     part = torch.empty(4 * ((Hd + 127) // 128), M, 2, device="cuda")
+    # the same operands as in the step: norm2 folded in (row mean / rstd + column sums) and the ffn_ln partial statistics out
+    mean, rstd, colsum = torch.zeros(M, device="cuda"), torch.ones(M, device="cuda"), torch.randn(2 * Hd, device="cuda")
+    kw = dict(bias=bias, ln_mean=mean, ln_rstd=rstd, ln_colsum=colsum, stats_part=part, epi=3, group=Hd)
     torch.cuda.synchronize()
-    ops.gemm_nt_ln(A, W, hid, bias=bias, stats_part=part, epi=3, group=Hd)
+    ops.gemm_nt_ln(A, W, hid, **kw)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(launches):
-        ops.gemm_nt_ln(A, W, hid, bias=bias, stats_part=part, epi=3, group=Hd)
+        ops.gemm_nt_ln(A, W, hid, **kw)
     e1.record()
     torch.cuda.synchronize()
     return 1e3 * e0.elapsed_time(e1) / launches
@@ -251,7 +254,7 @@ def main():
                                # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs, chunk 2048 -> 4.10 + 1.86 GB);
                                # not re-measured here, scaled linearly in the chunk
                                "traffic": (5.95e9 * min(a.teacher_chunk, BATCH * CROPS) / 2048.0),
-                               "kernel": "gemm_nt_kernel<EPI_SWIGLU_BF16> (teacher W1|W2 GEMM + SiLU*mul, M=chunk*197,N=4096,K=768)",
+                               "kernel": "gemm_nt_kernel<EPI_SWIGLU_BF16> (teacher W1|W2 GEMM with norm2 folded in + SiLU*mul + ffn_ln partial statistics, M=chunk*197,N=4096,K=768)",
                                "launches": kt["launches"], "mean_us": kt["mean_us"], "flops_per_launch": kt["flops_per_launch"]}
             if not a.no_overlap:
                 # In the overlapped schedule this kernel shares the CUs with the student's kernels for part of the step, which
