@@ -152,7 +152,8 @@ __device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, const f32x16 
         if (hl < p.group) { c1 = p.ln_colsum[hl]; c2 = p.ln_colsum[p.group + hl]; }
         for (int r = lane; r < FM * 32; r += 64) {
             const int row = min(row0 + r, p.M - 1);
-            rowst[r] = make_float2(p.ln_mean[row], p.ln_rstd[row]);
+            const float rs = p.ln_rstd[row];
+            rowst[r] = make_float2(-rs * p.ln_mean[row], rs);          // value = rs * acc + (-rs * mean) * colsum + bias: two FMAs
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -163,16 +164,19 @@ __device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, const f32x16 
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
             float h[2];
+            float4 st4 = make_float4(0.f, 1.f, 0.f, 1.f);
+            if (ln) st4 = *(const float4*)(rowst + i * 32 + mfma32_row(e, lane));                    // rows r, r+1 (r even)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {        // hardware exp2/rcp (1 ulp each; the result is rounded to bf16)
                 float u = acc[i][0][e + t], v = acc[i][1][e + t];
                 if (ln) {
-                    const float2 st = rowst[i * 32 + mfma32_row(e + t, lane)];
-                    u = st.y * (u - st.x * c1);
-                    v = st.y * (v - st.x * c2);
+                    const float2 st = t ? make_float2(st4.z, st4.w) : make_float2(st4.x, st4.y);
+                    u = fmaf(st.y, u, fmaf(st.x, c1, b1));
+                    v = fmaf(st.y, v, fmaf(st.x, c2, b2));
+                } else {
+                    u += b1;
+                    v += b2;
                 }
-                u += b1;
-                v += b2;
                 h[t] = u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u)) * v;
             }
             union { bf16x2 v; uint32_t u; } pk;
@@ -248,7 +252,8 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& p, const f32x16 (&
         }
         for (int r = lane; r < FM * 32; r += 64) {
             const int row = min(row0 + r, p.M - 1);
-            rowst[r] = make_float2(p.ln_mean[row], p.ln_rstd[row]);
+            const float rs = p.ln_rstd[row];
+            rowst[r] = make_float2(-rs * p.ln_mean[row], rs);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -262,13 +267,16 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& p, const f32x16 (&
             for (int e = 0; e < 16; e += 2) {
                 float v0 = acc[i][j][e], v1 = acc[i][j][e + 1];
                 if (ln) {
-                    const float2 s0 = rowst[i * 32 + mfma32_row(e, lane)], s1 = rowst[i * 32 + mfma32_row(e + 1, lane)];
-                    v0 = s0.y * (v0 - s0.x * cj[j]);
-                    v1 = s1.y * (v1 - s1.x * cj[j]);
+                    const float4 st = *(const float4*)(rowst + i * 32 + mfma32_row(e, lane));     // rows r, r+1 (r even): one 16-byte read
+                    v0 = fmaf(st.y, v0, fmaf(st.x, cj[j], bj[j]));
+                    v1 = fmaf(st.w, v1, fmaf(st.z, cj[j], bj[j]));
+                } else {
+                    v0 += bj[j];
+                    v1 += bj[j];
                 }
                 union { bf16x2 v; uint32_t u; } pk;
-                pk.v[0] = f2bf(v0 + bj[j]);
-                pk.v[1] = f2bf(v1 + bj[j]);
+                pk.v[0] = f2bf(v0);
+                pk.v[1] = f2bf(v1);
                 const int rp = ((e & 3) >> 1) + 4 * (e >> 2) + 2 * hf;
                 slab[rp * 64 + j * 32 + l31] = pk.u;
             }
