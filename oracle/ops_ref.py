@@ -105,6 +105,15 @@ class RefOps:
                 stats_part[s, :, 0] = blk.sum(-1)
                 stats_part[s, :, 1] = (blk * blk).sum(-1)
 
+    def crop_resize(self, image_u8, boxes, size, pad_center=True, mean=None, std=None, out=None):
+        """cs_crop_resize_u8 through Pillow itself (oracle/pil_crops_ref.py)."""
+        from .pil_crops_ref import OPENAI_MEAN, OPENAI_STD, pil_crops
+        res = torch.from_numpy(pil_crops(image_u8.cpu().numpy(), boxes.cpu().numpy(), size, pad_center, mean or OPENAI_MEAN, std or OPENAI_STD))
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
     def gemm_wgrad_workspace(self, M, N, K):
         return 16
 

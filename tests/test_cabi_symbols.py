@@ -46,5 +46,4 @@ def test_every_entry_point_has_a_tensor_level_wrapper_and_a_reference_op():
             continue
         name = renamed.get(sym, sym[len("cs_"):])
         assert callable(getattr(hip.HipOps, name, None)), f"HipOps.{name} missing for {sym}"
-        if sym not in ("cs_crop_resize_u8",):                 # pinned directly against Pillow (oracle/pil_crops_ref.py)
-            assert callable(getattr(RefOps, name, None)), f"RefOps.{name} missing for {sym}"
+        assert callable(getattr(RefOps, name, None)), f"RefOps.{name} missing for {sym}"

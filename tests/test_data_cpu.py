@@ -1,0 +1,58 @@
+"""CPU: the dataset-side logic of the GPU loaders (clipself_amd/training/data.py) with the pixel work done by Pillow through the
+reference ops -- grid choices, shuffling and truncation, crop_scale enlargement, box rescaling, proposal filtering and fallback."""
+import numpy as np
+import torch
+
+from clipself_amd.training.data import GpuGridDistillLoader, GpuProposalDistillLoader, SyntheticPanopticVal, grid_boxes, grid_choices
+from oracle.ops_ref import RefOps
+
+
+def test_grid_templates_follow_the_reference_recipe():
+    ch = grid_choices(6)
+    assert len(ch) == 24 and ch[0] == (1, 1) and (6, 6) in ch and (1, 3) not in ch and (2, 5) not in ch      # n in [ceil(m/2), min(2m, 6)]
+    b = grid_boxes(2, 3)
+    assert b.shape == (6, 4)
+    assert torch.allclose(b[0], torch.tensor([0, 0, 1 / 3, 0.5])) and torch.allclose(b[4], torch.tensor([1 / 3, 0.5, 2 / 3, 1.0]))
+    assert torch.allclose((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]), torch.full((6,), 1 / 6))               # cells tile the image
+
+
+def test_grid_loader_contract_on_cpu():
+    rng = np.random.default_rng(0)
+    imgs = [torch.from_numpy(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for h, w in ((120, 200), (150, 90))]
+    loader = GpuGridDistillLoader(imgs, RefOps(), batch_size=2, max_boxes=5, det_size=64, crop_size=32, max_split=6, crop_scale=1.5, steps=2, seed=1)
+    seen = 0
+    for images, boxes, crops in loader:
+        assert images.shape == (2, 3, 64, 64) and boxes.shape == (2, 5, 5) and crops.shape == (2, 5, 3, 32, 32)
+        valid = boxes[..., 4] > 0.5
+        assert valid.any(dim=1).all() and torch.all(crops[~valid] == 0) and torch.all(boxes[~valid] == 0)
+        assert float(boxes[..., :4].min()) >= 0 and float(boxes[..., :4].max()) <= 1.0 + 1e-6
+        seen += 1
+    assert seen == 2 and len(loader) == 2
+    # the box handed to the student is the grid cell; the crop handed to the teacher is that cell enlarged 1.5x and clipped
+    det, bx, cr, crop_px = loader.sample(imgs[0])
+    k = int(bx[:, 4].sum())
+    cell = bx[:k, :4] * 64 / min(64 / 120, 64 / 200)
+    assert torch.all(crop_px[:, :2] <= cell[:, :2] + 1e-3) and torch.all(crop_px[:, 2:] >= cell[:, 2:] - 1e-3)
+    assert float(crop_px[:, 2].max()) <= 200 and float(crop_px[:, 3].max()) <= 120
+
+
+def test_proposal_loader_filters_and_falls_back_on_cpu():
+    rng = np.random.default_rng(1)
+    img = torch.from_numpy(rng.integers(0, 256, (100, 160, 3), dtype=np.uint8))
+    anns = [[10.0, 10.0, 50.0, 40.0], [0.0, 0.0, 2.0, 3.0], [60.0, 30.0, 90.0, 60.0]]                      # the second is below min_size^2
+    loader = GpuProposalDistillLoader([img, img], [anns, [[1.0, 1.0, 1.0, 1.0]]], RefOps(), batch_size=2, det_size=64, crop_size=32, steps=1, seed=3)
+    det, boxes, crops, crop_px, slots = loader.sample(img, anns)
+    assert len(slots) == 2 and int(boxes[:, 4].sum()) == 2 and boxes.shape == (20, 5)
+    assert torch.all(crops[[i for i in range(20) if i not in slots]] == 0)
+    det, boxes, crops, crop_px, slots = loader.sample(img, [[1.0, 1.0, 1.0, 1.0]])                         # nothing valid -> quarter image
+    assert slots == [0] and crop_px.tolist() == [[0, 0, 40, 25]]
+    assert torch.allclose(boxes[0], torch.tensor([0, 0, 40 * 0.4 / 64, 25 * 0.4 / 64, 1.0]))
+    b = next(iter(loader))
+    assert b[0].shape == (2, 3, 64, 64) and b[2].shape == (2, 20, 3, 32, 32)
+
+
+def test_synthetic_panoptic_val_contract():
+    val = SyntheticPanopticVal(2, 3, 4, 32, 32, 4, 16, num_classes=5, seed=2)
+    images, bboxes, crops, masks, masked = val.batches[0]
+    assert images.shape == (3, 3, 32, 32) and bboxes.shape == (3, 4, 8) and crops.shape == (3, 4, 3, 32, 32) and masks.shape == (3, 4, 4, 4)
+    assert val.embeddings.shape == (5, 16) and masks.sum(dim=(-1, -2)).min() >= 1 and set(bboxes[..., 7].unique().tolist()) <= {0.0, 1.0}
