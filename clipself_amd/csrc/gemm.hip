@@ -92,8 +92,9 @@ __device__ __forceinline__ void stage_tile(const __bf16* __restrict__ src, int l
 }
 
 // XCD-aware, grouped-raster tile assignment (block b runs on XCD b % 8; bijective for any grid size)
-__device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& tn) {
-    const int nwg = gridDim.x, bid = blockIdx.x;
+__device__ __forceinline__ void tile_of_id(const GemmArgs& p, int bid, int nwg, int& tm, int& tn);
+__device__ __forceinline__ void tile_of_block(const GemmArgs& p, int& tm, int& tn) { tile_of_id(p, blockIdx.x, gridDim.x, tm, tn); }
+__device__ __forceinline__ void tile_of_id(const GemmArgs& p, int bid, int nwg, int& tm, int& tn) {
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int per_group = p.gm * p.tiles_n;
@@ -135,10 +136,10 @@ constexpr int EP_BYTES = 32 * EP_LD * 4;        // 32 rows per wave slab
 // are packed into one bf16x2 word and only that -- 8 ds_write_b32 and 2 ds_read_b128 per 32x32 block instead of 32 and 8 --
 // goes through the wave-private slab [16 row pairs][32 columns] to become 8-byte row-contiguous global stores.
 template <int FM, int BN>
-__device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, const f32x16 (&acc)[FM][2], char* smem, int wave, int lane, int row0,
-                                                int tn, int wn) {
+__device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, const f32x16 (&acc)[FM][2], char* slab_bytes, char* rowst_bytes, int lane,
+                                                int row0, int tn, int wn) {
     const int l31 = lane & 31, hf = lane >> 5;
-    uint32_t* slab = (uint32_t*)(smem + wave * EP_BYTES);
+    uint32_t* slab = (uint32_t*)slab_bytes;
     const int hbase = tn * (BN / 2) + wn * 32;
     const int hl = hbase + l31;
     float b1 = 0.f, b2 = 0.f;
@@ -147,7 +148,7 @@ __device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, const f32x16 
     // of this wave are staged behind its slab
     const bool ln = p.ln_mean != nullptr;
     float c1 = 0.f, c2 = 0.f;
-    float2* rowst = (float2*)(smem + wave * EP_BYTES + 4096);
+    float2* rowst = (float2*)rowst_bytes;
     if (ln) {
         if (hl < p.group) { c1 = p.ln_colsum[hl]; c2 = p.ln_colsum[p.group + hl]; }
         for (int r = lane; r < FM * 32; r += 64) {
@@ -231,10 +232,10 @@ __device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, const f32x16 
 // bf16 output epilogue (acc + bias): like epilogue_swiglu, vertically adjacent results are packed into bf16x2 words in registers, so
 // the wave-private slab [16 row pairs][64 columns] sees 16 ds_write_b32 + 4 ds_read_b128 per 32x64 block instead of 32 + 8.
 template <int FM, int BN>
-__device__ __forceinline__ void epilogue_bf16(const GemmArgs& p, const f32x16 (&acc)[FM][2], char* smem, int wave, int lane, int row0,
-                                              int n0, int wn) {
+__device__ __forceinline__ void epilogue_bf16(const GemmArgs& p, const f32x16 (&acc)[FM][2], char* slab_bytes, char* rowst_bytes, int lane,
+                                              int row0, int n0, int wn) {
     const int l31 = lane & 31, hf = lane >> 5;
-    uint32_t* slab = (uint32_t*)(smem + wave * EP_BYTES);
+    uint32_t* slab = (uint32_t*)slab_bytes;
     float bj[2] = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -243,7 +244,7 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& p, const f32x16 (&
     }
     const bool ln = p.ln_mean != nullptr;      // LayerNorm folded into this GEMM (norm1 of a frozen tower), see epilogue_swiglu
     float cj[2] = {0.f, 0.f};
-    float2* rowst = (float2*)(smem + wave * EP_BYTES + 4096);
+    float2* rowst = (float2*)rowst_bytes;
     if (ln) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -303,11 +304,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                                          int n0, int tn, int wn) {
     static_assert(FN == 2, "epilogue assumes 64-column wave tiles");
     if (EPI == EPI_SWIGLU_BF16) {
-        epilogue_swiglu<FM, BN>(p, acc, smem, wave, lane, row0, tn, wn);
+        epilogue_swiglu<FM, BN>(p, acc, smem + wave * EP_BYTES, smem + wave * EP_BYTES + 4096, lane, row0, tn, wn);
         return;
     }
     if (EPI == EPI_BF16) {
-        epilogue_bf16<FM, BN>(p, acc, smem, wave, lane, row0, n0, wn);
+        epilogue_bf16<FM, BN>(p, acc, smem + wave * EP_BYTES, smem + wave * EP_BYTES + 4096, lane, row0, n0, wn);
         return;
     }
     const int l31 = lane & 31;
@@ -575,6 +576,101 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
     epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + wm * TM, n0, tn, wn);
 }
 
+// ------------------------------------------------------------------------------------------------ persistent split-ring schedule
+// The default 256x256 split-ring kernel as a persistent loop over tiles (one workgroup per CU, tile ids strided by the grid size, which
+// keeps the XCD affinity of tile_of_id): the first operand tiles of the NEXT output tile (A0, B0, A1) are put in flight before the
+// epilogue of the current one, whose packed slabs live in A slot 2 and row statistics in B slot 1, so the prologue latency and the
+// workgroup relaunch disappear behind the store phase.  bf16 and SwiGLU epilogues only (their slabs fit beside the prefetch).
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
+    static_assert(EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16, "packed epilogues only");
+    constexpr int BM = 256, BN = 256, WN = 4, NW = 8, TM = 128, TN = 64, FM = 4, FN = 2;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, A_INSTR = 4, B_INSTR = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int hf = lane >> 5, l31 = lane & 31;
+    char* const b_ring = smem + 3 * A_BYTES;
+    char* const slab = smem + 2 * A_BYTES + wave * 4096;
+    char* const rowst = b_ring + B_BYTES + wave * 1024;
+    const int ntiles = p.tiles_m * p.tiles_n, ktiles = p.K / BK;
+    const int a_base = ((wm * TM + l31) >> 1) << 8, b_base = ((wn * TN + l31) >> 1) << 8;
+    const int par8 = (l31 & 1) << 3, sw = l31 >> 1;
+
+    int tile = blockIdx.x, tm, tn;
+    tile_of_id(p, tile, ntiles, tm, tn);
+    int arow[A_INSTR], achk[A_INSTR], brow[B_INSTR], bchk[B_INSTR];
+    source_rows<EPI, BM, BN, NW, A_INSTR, B_INSTR>(p, wave, lane, tm * BM, tn * BN, tn, arow, achk, brow, bchk);
+    auto prologue = [&]() {
+        stage_tile<A_INSTR, true>(p.A, p.lda, 0, smem, wave * A_INSTR, lane, arow, achk);
+        stage_tile<B_INSTR, true>(p.B, p.ldb, 0, b_ring, wave * B_INSTR, lane, brow, bchk);
+        if (ktiles > 1) stage_tile<A_INSTR, true>(p.A, p.lda, BK, smem + A_BYTES, wave * A_INSTR, lane, arow, achk);
+    };
+    prologue();
+    bool first = true;
+    for (;;) {
+        const int m0 = tm * BM, n0 = tn * BN, tn_cur = tn;
+        f32x16 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        int cur = 0;
+        for (int kt = 0; kt < ktiles; ++kt) {
+            // pending DMA in issue order: A(kt), B(kt), A(kt+1).  On the first K tile of a later output tile the queue also holds the
+            // previous epilogue's stores (loads and stores do not retire in order with each other): drain it.
+            if ((kt == 0 && !first) || kt + 1 >= ktiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const char* la = smem + cur * A_BYTES + a_base;
+            const char* lb = b_ring + (kt & 1) * B_BYTES + b_base;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = ((par8 | (ks * 2 + hf)) ^ sw) << 4;
+                bf16x8 a[FM], b[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(la + i * (16 * 256) + off);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(lb + j * (16 * 256) + off);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {            // two DMA pieces per k-step: B(kt+1) first, then A(kt+2)
+                    const int x = (ks & 1) * 2 + h2;
+                    if (ks < 2) {
+                        if (kt + 1 < ktiles) {
+                            const int r1[1] = {brow[x]}, c1[1] = {bchk[x]};
+                            stage_tile<1, true>(p.B, p.ldb, (kt + 1) * BK, b_ring + ((kt + 1) & 1) * B_BYTES, wave * B_INSTR + x, lane, r1, c1);
+                        }
+                    } else if (kt + 2 < ktiles) {
+                        const int r1[1] = {arow[x]}, c1[1] = {achk[x]};
+                        stage_tile<1, true>(p.A, p.lda, (kt + 2) * BK, smem + ((kt + 2) % 3) * A_BYTES, wave * A_INSTR + x, lane, r1, c1);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        __syncthreads();                                  // every wave is done reading the operand rings; no DMA pending
+        const int next = tile + (int)gridDim.x;
+        if (next < ntiles) {                              // next tile's first operands fly during this tile's epilogue
+            tile_of_id(p, next, ntiles, tm, tn);
+            source_rows<EPI, BM, BN, NW, A_INSTR, B_INSTR>(p, wave, lane, tm * BM, tn * BN, tn, arow, achk, brow, bchk);
+            prologue();
+        }
+        if (EPI == EPI_SWIGLU_BF16) epilogue_swiglu<FM, BN>(p, acc, slab, rowst, lane, m0 + wm * TM, tn_cur, wn);
+        else epilogue_bf16<FM, BN>(p, acc, slab, rowst, lane, m0 + wm * TM, n0, wn);
+        if (next >= ntiles) break;
+        tile = next;
+        first = false;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ two-workgroups-per-CU schedule
 // 256x128 tile, K tiles of 32, 3-stage LDS-DMA ring (72 KiB), 8 waves of 64x64 (<=128 registers): TWO workgroups fit a CU, so one
 // workgroup's epilogue (an HBM-bound store phase that is 25-45 % of a lockstep 256x256 kernel on the K=768 shapes of the towers)
@@ -803,6 +899,20 @@ int launch_pp(GemmArgs a, int splits, hipStream_t stream) {
 }
 
 template <int EPI>
+int launch_persist(GemmArgs a, hipStream_t stream) {
+    constexpr int BM = 256, BN = 256;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + BN / 2 - 1) / (BN / 2) : (a.N + BN - 1) / BN;
+    constexpr size_t lds = 160 * 1024;
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    const long ntiles = (long)a.tiles_m * a.tiles_n;
+    hipLaunchKernelGGL(gemm_persist_kernel<EPI>, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), lds, stream, a);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int EPI>
 int launch_k32(GemmArgs a, int splits, hipStream_t stream) {
     constexpr int BM = 256, BN = 128;
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -852,11 +962,18 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
         if (a.M < 256 || ncols < 256) c3 = 1e30;
         if (a.M < 256 || ncols < 128) c2 = 1e30;
         cfg = (c3 <= c2 && c3 <= c1) ? 3 : (c2 <= c1 ? 2 : 1);
-        if (cfg == 3 && use_glds) cfg = PP_DEFAULT ? 5 : 7;      // split rings: +1..3 % over the lockstep 2-stage ring on the tower shapes
+        // split rings: +1..3 % over the lockstep 2-stage ring on the tower shapes; as a persistent tile loop (bf16 / SwiGLU epilogues,
+        // case 9 falls back to 7 for the others): another -2.4 % (q|k|v) / -4.9 % (W1|W2) per launch
+        if (cfg == 3 && use_glds) cfg = PP_DEFAULT ? 5 : 9;
     }
-    const int ns = sp[(cfg == 4 || cfg == 8) ? 2 : (cfg >= 5 ? 3 : cfg)];   // cfgs 5..7 are 256x256 variants
+    const int ns = sp[(cfg == 4 || cfg == 8) ? 2 : (cfg >= 5 ? 3 : cfg)];   // cfgs 5..7 and 9 are 256x256 variants
     a.ktiles_per_split = (ktiles + ns - 1) / ns;
     switch (cfg) {
+        case 9:                                                                                 // persistent split rings (packed epilogues)
+            if constexpr (EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16) {
+                if (use_glds && ns == 1) return launch_persist<EPI>(a, stream);
+            }
+            return launch_cfg<EPI, 256, 256, 2, 4, 32>(a, ns, use_glds, stream);
         case 8: return launch_k32<EPI>(a, ns, stream);                                          // 256x128, K-32 tiles, 3-stage ring, two workgroups per CU
         case 7: return launch_cfg<EPI, 256, 256, 2, 4, 32>(a, ns, use_glds, stream);       // 256x256, A ring 3 / B ring 2 (160 KiB)
         case 6: return launch_cfg<EPI, 256, 256, 2, 4, 2, true>(a, ns, use_glds, stream);   // 256x256 lockstep + L2 warm-up of tile kt+2
@@ -878,7 +995,7 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 // flags bit0: 0 = global_load_lds staging, 1 = register staging (debug/fallback A-B switch)
 //       bits 4-7: force schedule (1 = 128x128, 2 = 256x128, 3 = 256x256 lockstep, 4 = 256x128 3-stage ring,
 //                 5 = 256x256 ping-pong, 6 = 256x256 lockstep + L2 warm-up, 7 = 256x256 split rings A3/B2,
-//                 8 = 256x128 K-32 ring, two workgroups per CU; 0 = heuristic)
+//                 8 = 256x128 K-32 ring, two workgroups per CU, 9 = persistent split rings (bf16 / SwiGLU epilogues); 0 = heuristic)
 //       bits 8-11: raster group height override (0 = 8)
 //       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue;
 //       bit 15: split-ring schedule issues its DMA in one burst behind the barrier instead of interleaved with the MFMAs
