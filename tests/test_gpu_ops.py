@@ -64,7 +64,7 @@ def test_gemm_bf16_bias(hip, ref, M, N, K, flags):
     check(f"gemm_bf16[{M},{N},{K}] flags={flags}", Cd, Cr, TOL_BF)
 
 
-@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60, 0x70, 0x71, 0x80])
+@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60, 0x70, 0x71, 0x80, 0x90])
 def test_gemm_f32_resid_strided(hip, ref, flags):
     M, N, K = 788, 768, 2048
     Abig = rnd((M, K + 64), BF, seed=4)
