@@ -299,20 +299,31 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& p, const f32x16 (&
 
 // Epilogue through a wave-private LDS slab [32][EP_LD] fp32.  The slab is wave-private and a wave's DS operations execute in
 // order, so no workgroup barrier is needed inside (a __syncthreads() would also wait for every outstanding global store).
+template <int EPI, int FM, int FN, int BN, int LD = EP_LD>
+__device__ __forceinline__ void epilogue_at(const GemmArgs& p, const f32x16 (&acc)[FM][FN], char* slab_bytes, int lane, int row0,
+                                            int n0, int tn, int wn);
+
 template <int EPI, int FM, int FN, int BN>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[FM][FN], char* smem, int wave, int lane, int row0,
                                          int n0, int tn, int wn) {
+    epilogue_at<EPI, FM, FN, BN>(p, acc, smem + wave * EP_BYTES, lane, row0, n0, tn, wn);
+}
+
+// LD = fp32 row stride of the slab: 68 in the one-tile-per-workgroup kernels, 64 in the persistent kernel (8 KiB slabs, four per free ring slot)
+template <int EPI, int FM, int FN, int BN, int LD>
+__device__ __forceinline__ void epilogue_at(const GemmArgs& p, const f32x16 (&acc)[FM][FN], char* slab_bytes, int lane, int row0,
+                                            int n0, int tn, int wn) {
     static_assert(FN == 2, "epilogue assumes 64-column wave tiles");
     if (EPI == EPI_SWIGLU_BF16) {
-        epilogue_swiglu<FM, BN>(p, acc, smem + wave * EP_BYTES, smem + wave * EP_BYTES + 4096, lane, row0, tn, wn);
+        epilogue_swiglu<FM, BN>(p, acc, slab_bytes, slab_bytes + 4096, lane, row0, tn, wn);
         return;
     }
     if (EPI == EPI_BF16) {
-        epilogue_bf16<FM, BN>(p, acc, smem + wave * EP_BYTES, smem + wave * EP_BYTES + 4096, lane, row0, n0, wn);
+        epilogue_bf16<FM, BN>(p, acc, slab_bytes, slab_bytes + 4096, lane, row0, n0, wn);
         return;
     }
     const int l31 = lane & 31;
-    float* slab = (float*)(smem + wave * EP_BYTES);
+    float* slab = (float*)slab_bytes;
     const int rrow = lane >> 4, rcol = (lane & 15) * 4;  // read-out: 16 lanes per row, 4 consecutive columns per lane
     const int col = n0 + wn * 64 + rcol;                 // non-SwiGLU epilogues
 #pragma unroll
@@ -346,7 +357,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) slab[mfma32_row(e, lane) * EP_LD + j * 32 + l31] = acc[i][j][e];
+            for (int e = 0; e < 16; ++e) slab[mfma32_row(e, lane) * LD + j * 32 + l31] = acc[i][j][e];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         {
             float ps[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pq[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // per-row partial statistics (residual epilogues)
@@ -360,7 +371,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, const f32x16 (&acc)[
                 for (int it = 0; it < 8; ++it) {
                     const int rl = rrow + it * 4, row = row_base + rl;
                     if (!full && row >= p.M) continue;
-                    const float4 s = *(const float4*)(slab + rl * EP_LD + rcol);
+                    const float4 s = *(const float4*)(slab + rl * LD + rcol);
                     float v[4] = {s.x + bv[0], s.y + bv[1], s.z + bv[2], s.w + bv[3]};
                     if (EPI == EPI_RESID_LN_F32) {
                         const float mu = lmean[it], rs = lrstd[it];
@@ -580,10 +591,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
 // The default 256x256 split-ring kernel as a persistent loop over tiles (one workgroup per CU, tile ids strided by the grid size, which
 // keeps the XCD affinity of tile_of_id): the first operand tiles of the NEXT output tile (A0, B0, A1) are put in flight before the
 // epilogue of the current one, whose packed slabs live in A slot 2 and row statistics in B slot 1, so the prologue latency and the
-// workgroup relaunch disappear behind the store phase.  bf16 and SwiGLU epilogues only (their slabs fit beside the prefetch).
+// workgroup relaunch disappear behind the store phase.  bf16, SwiGLU and fp32 residual epilogues (their slabs fit beside the prefetch).
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
-    static_assert(EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16, "packed epilogues only");
+    static_assert(EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32, "epilogues whose slabs fit");
+    constexpr bool PACKED = EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16;
     constexpr int BM = 256, BN = 256, WN = 4, NW = 8, TM = 128, TN = 64, FM = 4, FN = 2;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, A_INSTR = 4, B_INSTR = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -592,7 +604,9 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
     const int wm = wave / WN, wn = wave - wm * WN;
     const int hf = lane >> 5, l31 = lane & 31;
     char* const b_ring = smem + 3 * A_BYTES;
-    char* const slab = smem + 2 * A_BYTES + wave * 4096;
+    // epilogue scratch lives in A slot 2 and B slot 1 -- the prefetch of the next tile only touches A0, A1 and B0.  Packed epilogues:
+    // 4 KiB slabs in A2, row statistics in B1; fp32 residual epilogues: 8 KiB slabs (row stride 64), four in A2 and four in B1.
+    char* const slab = PACKED ? smem + 2 * A_BYTES + wave * 4096 : (wave < 4 ? smem + 2 * A_BYTES + wave * 8192 : b_ring + B_BYTES + (wave - 4) * 8192);
     char* const rowst = b_ring + B_BYTES + wave * 1024;
     const int ntiles = p.tiles_m * p.tiles_n, ktiles = p.K / BK;
     const int a_base = ((wm * TM + l31) >> 1) << 8, b_base = ((wn * TN + l31) >> 1) << 8;
@@ -663,8 +677,9 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
             source_rows<EPI, BM, BN, NW, A_INSTR, B_INSTR>(p, wave, lane, tm * BM, tn * BN, tn, arow, achk, brow, bchk);
             prologue();
         }
-        if (EPI == EPI_SWIGLU_BF16) epilogue_swiglu<FM, BN>(p, acc, slab, rowst, lane, m0 + wm * TM, tn_cur, wn);
-        else epilogue_bf16<FM, BN>(p, acc, slab, rowst, lane, m0 + wm * TM, n0, wn);
+        if constexpr (EPI == EPI_SWIGLU_BF16) epilogue_swiglu<FM, BN>(p, acc, slab, rowst, lane, m0 + wm * TM, tn_cur, wn);
+        else if constexpr (EPI == EPI_BF16) epilogue_bf16<FM, BN>(p, acc, slab, rowst, lane, m0 + wm * TM, n0, wn);
+        else epilogue_at<EPI, FM, FN, BN, 64>(p, acc, slab, lane, m0 + wm * TM, n0, tn_cur, wn);
         if (next >= ntiles) break;
         tile = next;
         first = false;
@@ -970,7 +985,7 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
     a.ktiles_per_split = (ktiles + ns - 1) / ns;
     switch (cfg) {
         case 9:                                                                                 // persistent split rings (packed epilogues)
-            if constexpr (EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16) {
+            if constexpr (EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
                 if (use_glds && ns == 1) return launch_persist<EPI>(a, stream);
             }
             return launch_cfg<EPI, 256, 256, 2, 4, 32>(a, ns, use_glds, stream);
@@ -995,7 +1010,7 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 // flags bit0: 0 = global_load_lds staging, 1 = register staging (debug/fallback A-B switch)
 //       bits 4-7: force schedule (1 = 128x128, 2 = 256x128, 3 = 256x256 lockstep, 4 = 256x128 3-stage ring,
 //                 5 = 256x256 ping-pong, 6 = 256x256 lockstep + L2 warm-up, 7 = 256x256 split rings A3/B2,
-//                 8 = 256x128 K-32 ring, two workgroups per CU, 9 = persistent split rings (bf16 / SwiGLU epilogues); 0 = heuristic)
+//                 8 = 256x128 K-32 ring, two workgroups per CU, 9 = persistent split rings (bf16 / SwiGLU / residual epilogues); 0 = heuristic)
 //       bits 8-11: raster group height override (0 = 8)
 //       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue;
 //       bit 15: split-ring schedule issues its DMA in one burst behind the barrier instead of interleaved with the MFMAs
