@@ -30,7 +30,7 @@ def main():
         else:
             C, extra, group = torch.empty(M, N // 2, dtype=BF, device="cuda"), None, N // 2
         line = f"{name} M={M}: "
-        for cfg, gm, dbg in ((7, 8, 0), (9, 8, 0), (7, 8, 0), (9, 8, 0), (7, 8, 0), (9, 8, 0)):   # dbg: 1 no DMA, 2 no MFMA, 3 neither
+        for cfg, gm, dbg in ((7, 8, 0), (9, 8, 0), (7, 8, 0), (9, 8, 0), (3, 8, 0), (8, 8, 0)):   # dbg: 1 no DMA, 2 no MFMA, 3 neither
             flags = (cfg << 4) | (gm << 8) | (dbg << 12)
             for _ in range(3):
                 ops.gemm_nt(A, B, C, bias, extra, epi=epi, group=group, flags=flags)
