@@ -248,6 +248,26 @@ def gen_zeroshot(oc):
     print("zero-shot metrics", metrics)
 
 
+PARAM_CASES = [["--model", "EVA02-CLIP-B-16"],
+               ["--model", "EVA02-CLIP-L-14-336", "--lr", "1e-5", "--wd", "0.1", "--lock-image", "--lock-image-unlocked-groups", "24",
+                "--dataset-type", "proposals_distill", "--batch-size", "16", "--alpha", "0.7", "--precision", "amp_bf16", "--epochs", "6"],
+               ["--model", "ViT-B-16", "--dataset-type", "region_clip", "--max-boxes", "32", "--crop-scale", "1.5", "--multiscale",
+                "--aug-cfg", "scale=(0.4, 1.0)", "use_timm=True"]]
+
+
+def gen_params(oc):
+    """Namespaces produced by the reference's training.params.parse_args (src/training/params.py:25-476) for a few command lines:
+    every flag the reference knows, its default (incl. the model-dependent Adam defaults) and its parsed type."""
+    from training.params import parse_args as ref_parse
+    out = []
+    for argv in PARAM_CASES:
+        ns = vars(ref_parse(list(argv)))
+        out.append({"argv": argv, "namespace": {k: (v if isinstance(v, (int, float, str, bool, type(None), list, dict)) else repr(v))
+                                                 for k, v in sorted(ns.items())}})
+    (GOLD / "params_namespaces.json").write_text(json.dumps(out, indent=0))
+    print("params:", [len(c["namespace"]) for c in out])
+
+
 def gen_b16(oc):
     cfg = get_tower_cfg("EVA02-CLIP-B-16")
     rec = B16
@@ -294,10 +314,14 @@ def main():
     if "--zeroshot-only" in sys.argv:
         gen_zeroshot(oc)
         return
+    if "--params-only" in sys.argv:
+        gen_params(oc)
+        return
     gen_tiny(oc)
     gen_tiny14(oc)
     gen_regionclip(oc)
     gen_zeroshot(oc)
+    gen_params(oc)
     if "--tiny-only" not in sys.argv:
         gen_b16(oc)
 

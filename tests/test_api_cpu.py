@@ -135,3 +135,19 @@ def create_model_from_ckpt(cfg, path):
     m = CustomCLIP(cfg, ops=RefOps(), trainable=False)
     load_checkpoint(m, str(path), strict=False)
     return m
+
+
+def test_cli_flags_defaults_and_types_match_the_reference(golden_dir):
+    """training.params.parse_args: every flag of the reference (src/training/params.py:25-476) exists with the same default and parsed
+    value, for three command lines captured from the reference itself (tests/golden/params_namespaces.json)."""
+    from clipself_amd.training.params import parse_args
+    cases = json.loads((golden_dir / "params_namespaces.json").read_text())
+    assert len(cases) == 3
+    for case in cases:
+        mine = vars(parse_args(list(case["argv"])))
+        for key, want in case["namespace"].items():
+            assert key in mine, f"flag {key} missing"
+            got = mine[key]
+            got = got if isinstance(got, (int, float, str, bool, type(None), list, dict)) else repr(got)
+            got = json.loads(json.dumps(got))                      # tuples inside --aug-cfg values come back from the fixture as lists
+            assert got == want, (case["argv"][:2], key, got, want)
