@@ -268,6 +268,19 @@ def gen_params(oc):
     print("params:", [len(c["namespace"]) for c in out])
 
 
+def gen_schedules(oc):
+    """LR schedules of src/training/scheduler.py (cosine_lr :43-53, const_lr :13-21, const_lr_cooldown :24-40) sampled at fixed steps."""
+    from training import scheduler as ref_s
+    opt = SimpleNamespace(param_groups=[{"lr": 0.0}, {"lr": 0.0}])
+    steps = [0, 1, 5, 99, 100, 101, 500, 2500, 4999, 5000, 7777, 9999]
+    out = {"steps": steps,
+           "cosine": [float(ref_s.cosine_lr(opt, 1e-5, 100, 10000)(t)) for t in steps],
+           "const": [float(ref_s.const_lr(opt, 3e-4, 100, 10000)(t)) for t in steps],
+           "cooldown": [float(ref_s.const_lr_cooldown(opt, 3e-4, 100, 10000, 2000, 2.0, 1e-6)(t)) for t in steps]}
+    (GOLD / "lr_schedules.json").write_text(json.dumps(out))
+    print("schedules", out["cosine"][:4])
+
+
 def gen_b16(oc):
     cfg = get_tower_cfg("EVA02-CLIP-B-16")
     rec = B16
@@ -316,12 +329,14 @@ def main():
         return
     if "--params-only" in sys.argv:
         gen_params(oc)
+        gen_schedules(oc)
         return
     gen_tiny(oc)
     gen_tiny14(oc)
     gen_regionclip(oc)
     gen_zeroshot(oc)
     gen_params(oc)
+    gen_schedules(oc)
     if "--tiny-only" not in sys.argv:
         gen_b16(oc)
 

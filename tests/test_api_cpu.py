@@ -151,3 +151,16 @@ def test_cli_flags_defaults_and_types_match_the_reference(golden_dir):
             got = got if isinstance(got, (int, float, str, bool, type(None), list, dict)) else repr(got)
             got = json.loads(json.dumps(got))                      # tuples inside --aug-cfg values come back from the fixture as lists
             assert got == want, (case["argv"][:2], key, got, want)
+
+
+def test_lr_schedules_match_the_reference(golden_dir):
+    from clipself_amd.training import scheduler as sch
+    g = json.loads((golden_dir / "lr_schedules.json").read_text())
+    opt = SimpleNamespace(param_groups=[{"lr": 0.0}, {"lr": 0.0}])
+    fns = {"cosine": sch.cosine_lr(opt, 1e-5, 100, 10000), "const": sch.const_lr(opt, 3e-4, 100, 10000),
+           "cooldown": sch.const_lr_cooldown(opt, 3e-4, 100, 10000, 2000, 2.0, 1e-6)}
+    for name, fn in fns.items():
+        for t, want in zip(g["steps"], g[name]):
+            got = fn(t)
+            assert abs(got - want) <= 1e-15 * max(abs(want), 1e-12) + 1e-20, (name, t, got, want)
+            assert all(grp["lr"] == got for grp in opt.param_groups)
