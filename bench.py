@@ -251,9 +251,9 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": kt["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": kt["tflops"] / PEAK_BF16_TFLOPS,
                                # HBM/fabric bytes per launch from the committed PMC passes (profiles/r01_m_pmc_traffic.md:
-                               # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs, chunk 2048 -> 4.10 + 1.86 GB);
+                               # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs, chunk 2048 -> 3.97 + 1.86 GB);
                                # not re-measured here, scaled linearly in the chunk
-                               "traffic": (5.95e9 * min(a.teacher_chunk, BATCH * CROPS) / 2048.0),
+                               "traffic": (5.83e9 * min(a.teacher_chunk, BATCH * CROPS) / 2048.0),
                                "kernel": "gemm_persist_kernel<EPI_SWIGLU_BF16> (teacher W1|W2 GEMM with norm2 folded in + SiLU*mul + ffn_ln partial statistics, M=chunk*197,N=4096,K=768)",
                                "launches": kt["launches"], "mean_us": kt["mean_us"], "flops_per_launch": kt["flops_per_launch"]}
             if not a.no_overlap:
