@@ -1,10 +1,13 @@
-"""Architecture records for the EVA02 towers on the CLIPSelf hot path.
+"""Architecture records for the vision towers on the CLIPSelf hot path.
 
 The numbers mirror the reference's JSON model configs
 (reference: src/open_clip/eva_clip/model_configs/EVA02-CLIP-B-16.json,
 EVA02-CLIP-L-14-336.json) and the wiring in
 src/open_clip/eva_clip/model.py:92-131 (``_build_vision_tower``) and
-src/open_clip/eva_clip/eva_vit_model.py:396-470.
+src/open_clip/eva_clip/eva_vit_model.py:396-470; for the OpenAI-CLIP ViT family
+(``arch == "openai"``: learned positional embedding, fused-QKV attention, GELU MLP, ln_pre / ln_post / proj)
+src/open_clip/model_configs/ViT-*.json, src/open_clip/model.py:24-49,77-139 and
+src/open_clip/transformer.py:318-389.
 """
 from __future__ import annotations
 
@@ -31,6 +34,8 @@ class TowerCfg:
     text_layers: int = 12
     text_context: int = 77
     text_vocab: int = 49408
+    arch: str = "eva02"      # "eva02" (RoPE + SwiGLU + sub-LN) | "openai" (OpenAI-CLIP ViT)
+    quick_gelu: bool = False  # openai arch only: QuickGELU instead of nn.GELU (model.py:77-90)
 
     @property
     def heads(self) -> int:
@@ -56,12 +61,25 @@ class TowerCfg:
 _CFG_DIR = Path(__file__).parent / "open_clip" / "model_configs"
 
 
+_EVA_FLAGS = ("rope", "naiveswiglu", "subln", "intp_freq")
+
+
 def _from_json(name: str, blob: dict) -> TowerCfg:
     v, t = blob["vision_cfg"], blob["text_cfg"]
-    for flag in ("rope", "naiveswiglu", "subln", "intp_freq"):
+    if not any(f in v for f in _EVA_FLAGS):
+        # plain OpenAI-CLIP ViT config (model.py:24-49): integer depth, no timm / attentional-pool / patch-norm variants
+        odd = [k for k in ("timm_model_name", "attentional_pool", "global_average_pool", "input_patchnorm", "ls_init_value") if v.get(k)]
+        if odd or not isinstance(v.get("layers"), int):
+            raise NotImplementedError(f"{name}: vision_cfg options {odd or 'layers'} are outside the CLIPSelf hot path")
+        return TowerCfg(
+            name=name, embed_dim=blob["embed_dim"], image_size=v["image_size"], patch_size=v["patch_size"], width=v["width"],
+            layers=v["layers"], head_width=v.get("head_width", 64), mlp_ratio=v.get("mlp_ratio", 4.0), ln_eps=1e-5,
+            text_width=t["width"], text_heads=t["heads"], text_layers=t["layers"], text_context=t.get("context_length", 77),
+            text_vocab=t.get("vocab_size", 49408), arch="openai", quick_gelu=bool(blob.get("quick_gelu", False)))
+    for flag in _EVA_FLAGS:
         if not v.get(flag, False):
             raise NotImplementedError(
-                f"{name}: only the EVA02 (rope+swiglu+subln) tower family is on the hot path")
+                f"{name}: of the EVA family only the EVA02 (rope+swiglu+subln) towers are on the hot path")
     return TowerCfg(
         name=name, embed_dim=blob["embed_dim"], image_size=v["image_size"],
         patch_size=v["patch_size"], width=v["width"], layers=v["layers"],
@@ -96,6 +114,13 @@ def tiny14_cfg() -> TowerCfg:
     storage) and mlp_ratio 2.6667 (hidden int(128*2.6667) = 341, padded to 384) -- exercises every zero-padding path."""
     return TowerCfg(name="EVA02-tiny14-test", embed_dim=64, image_size=42, patch_size=14, width=128, layers=2,
                     head_width=64, mlp_ratio=2.6667, text_width=32, text_heads=2, text_layers=1)
+
+
+def tiny_openai_cfg(quick_gelu: bool = False) -> TowerCfg:
+    """A small OpenAI-CLIP-shaped ViT (head dim 64, mlp_ratio 4, LayerNorm eps 1e-5) for full-tensor golden vectors."""
+    return TowerCfg(name="ViT-tiny-test" + ("-quickgelu" if quick_gelu else ""), embed_dim=64, image_size=32, patch_size=8, width=128,
+                    layers=2, head_width=64, mlp_ratio=4.0, ln_eps=1e-5, text_width=32, text_heads=2, text_layers=1, text_context=8,
+                    text_vocab=64, arch="openai", quick_gelu=quick_gelu)
 
 
 def cfg_dict(cfg: TowerCfg) -> dict:

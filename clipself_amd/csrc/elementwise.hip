@@ -46,6 +46,53 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const __bf16* __restric
     }
 }
 
+// MLP activation of the OpenAI-CLIP ViT blocks (open_clip/transformer.py:209-213): nn.GELU (exact, erf) or QuickGELU
+// x*sigmoid(1.702x) (:31-34, forced for the `openai` weights).  Forward on the bf16 c_fc output kept for backward; fp32 inside.
+template <bool QUICK>
+__device__ __forceinline__ float gelu_f(float x) {
+    if (QUICK) return x / (1.f + __expf(-1.702f * x));
+    return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+}
+template <bool QUICK>
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    if (QUICK) {
+        const float s = 1.f / (1.f + __expf(-1.702f * x));
+        return s * (1.f + 1.702f * x * (1.f - s));
+    }
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+template <bool QUICK>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const __bf16* __restrict__ x, long ldx, __bf16* __restrict__ y, long ldy, int M, int N) {
+    const int vec_per_row = N >> 3;
+    const long total = (long)M * vec_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / vec_per_row), j = (int)(i - (long)m * vec_per_row) * 8;
+        U128 a, o;
+        a.u = *(const uint4*)(x + (size_t)m * ldx + j);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.e[e] = f2bf(gelu_f<QUICK>(bf2f(a.e[e])));
+        *(uint4*)(y + (size_t)m * ldy + j) = o.u;
+    }
+}
+
+// dx = dy * act'(x)
+template <bool QUICK>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const __bf16* __restrict__ dy, long lddy, const __bf16* __restrict__ x, long ldx,
+                                                       __bf16* __restrict__ dx, long lddx, int M, int N) {
+    const int vec_per_row = N >> 3;
+    const long total = (long)M * vec_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / vec_per_row), j = (int)(i - (long)m * vec_per_row) * 8;
+        U128 a, g, o;
+        a.u = *(const uint4*)(x + (size_t)m * ldx + j);
+        g.u = *(const uint4*)(dy + (size_t)m * lddy + j);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.e[e] = f2bf(bf2f(g.e[e]) * gelu_grad_f<QUICK>(bf2f(a.e[e])));
+        *(uint4*)(dx + (size_t)m * lddx + j) = o.u;
+    }
+}
+
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, long n8) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
         const float4 a = *(const float4*)(x + i * 8), b = *(const float4*)(x + i * 8 + 4);
@@ -210,6 +257,24 @@ extern "C" int cs_swiglu_bwd(const void* dh, long lddh, const void* x12, long ld
     CS_CHECK_ARG(Hd % 8 == 0 && ldx % 8 == 0 && lddh % 8 == 0 && lddx % 8 == 0 && M > 0, "cs_swiglu_bwd: Hd/ld must be multiples of 8");
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((long)M * (Hd / 8))), dim3(256), 0, stream, (const __bf16*)dh, lddh, (const __bf16*)x12, ldx,
                        (__bf16*)dx12, lddx, M, Hd);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+// y = act(x), dx = dy * act'(x) on bf16 [M, N] matrices; quick 0 = exact (erf) GELU, 1 = QuickGELU.  y may alias x only in the forward.
+extern "C" int cs_gelu_fwd(const void* x, long ldx, void* y, long ldy, int M, int N, int quick, hipStream_t stream) {
+    CS_CHECK_ARG(x && y && N % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && M > 0 && N > 0, "cs_gelu_fwd: N/ld must be multiples of 8");
+    const dim3 grid(grid_for((long)M * (N / 8))), block(256);
+    if (quick) hipLaunchKernelGGL(gelu_fwd_kernel<true>, grid, block, 0, stream, (const __bf16*)x, ldx, (__bf16*)y, ldy, M, N);
+    else hipLaunchKernelGGL(gelu_fwd_kernel<false>, grid, block, 0, stream, (const __bf16*)x, ldx, (__bf16*)y, ldy, M, N);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cs_gelu_bwd(const void* dy, long lddy, const void* x, long ldx, void* dx, long lddx, int M, int N, int quick, hipStream_t stream) {
+    CS_CHECK_ARG(dy && x && dx && N % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && M > 0 && N > 0,
+                 "cs_gelu_bwd: N/ld must be multiples of 8");
+    const dim3 grid(grid_for((long)M * (N / 8))), block(256);
+    if (quick) hipLaunchKernelGGL(gelu_bwd_kernel<true>, grid, block, 0, stream, (const __bf16*)dy, lddy, (const __bf16*)x, ldx, (__bf16*)dx, lddx, M, N);
+    else hipLaunchKernelGGL(gelu_bwd_kernel<false>, grid, block, 0, stream, (const __bf16*)dy, lddy, (const __bf16*)x, ldx, (__bf16*)dx, lddx, M, N);
     CS_LAUNCH_CHECK();
     return 0;
 }

@@ -38,7 +38,11 @@ namespace {
 
 constexpr int BK = 64;
 constexpr bool PP_DEFAULT = false;     // make the ping-pong schedule the default for 256x256 tiles (A/B knob, see tools/gemm_bench.py)
-enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID_F32 = 2, EPI_SWIGLU_BF16 = 3, EPI_ATOMIC_F32 = 4, EPI_PATCH_F32 = 5, EPI_RESID_LN_F32 = 6 };
+enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID_F32 = 2, EPI_SWIGLU_BF16 = 3, EPI_ATOMIC_F32 = 4, EPI_PATCH_F32 = 5, EPI_RESID_LN_F32 = 6,
+           EPI_GELU_BF16 = 7, EPI_QGELU_BF16 = 8 };
+// bf16 output of acc + bias, optionally through the MLP activation of the OpenAI-CLIP ViT (0 none, 1 exact GELU, 2 QuickGELU)
+constexpr bool epi_is_bf16(int e) { return e == EPI_BF16 || e == EPI_GELU_BF16 || e == EPI_QGELU_BF16; }
+constexpr int epi_act(int e) { return e == EPI_GELU_BF16 ? 1 : (e == EPI_QGELU_BF16 ? 2 : 0); }
 
 struct GemmArgs {
     const __bf16* A;
@@ -231,7 +235,14 @@ __device__ __forceinline__ void epilogue_swiglu(const GemmArgs& p, const f32x16 
 
 // bf16 output epilogue (acc + bias): like epilogue_swiglu, vertically adjacent results are packed into bf16x2 words in registers, so
 // the wave-private slab [16 row pairs][64 columns] sees 16 ds_write_b32 + 4 ds_read_b128 per 32x64 block instead of 32 + 8.
-template <int FM, int BN>
+template <int ACT>
+__device__ __forceinline__ float activate(float v) {
+    if (ACT == 1) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));                       // nn.GELU (open_clip/transformer.py:195,211)
+    if (ACT == 2) return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));   // QuickGELU (:31-34)
+    return v;
+}
+
+template <int FM, int BN, int ACT = 0>
 __device__ __forceinline__ void epilogue_bf16(const GemmArgs& p, const f32x16 (&acc)[FM][2], char* slab_bytes, char* rowst_bytes, int lane,
                                               int row0, int n0, int wn) {
     const int l31 = lane & 31, hf = lane >> 5;
@@ -276,8 +287,8 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& p, const f32x16 (&
                     v1 += bj[j];
                 }
                 union { bf16x2 v; uint32_t u; } pk;
-                pk.v[0] = f2bf(v0);
-                pk.v[1] = f2bf(v1);
+                pk.v[0] = f2bf(activate<ACT>(v0));
+                pk.v[1] = f2bf(activate<ACT>(v1));
                 const int rp = ((e & 3) >> 1) + 4 * (e >> 2) + 2 * hf;
                 slab[rp * 64 + j * 32 + l31] = pk.u;
             }
@@ -318,8 +329,8 @@ __device__ __forceinline__ void epilogue_at(const GemmArgs& p, const f32x16 (&ac
         epilogue_swiglu<FM, BN>(p, acc, slab_bytes, slab_bytes + 4096, lane, row0, tn, wn);
         return;
     }
-    if (EPI == EPI_BF16) {
-        epilogue_bf16<FM, BN>(p, acc, slab_bytes, slab_bytes + 4096, lane, row0, n0, wn);
+    if (epi_is_bf16(EPI)) {
+        epilogue_bf16<FM, BN, epi_act(EPI)>(p, acc, slab_bytes, slab_bytes + 4096, lane, row0, n0, wn);
         return;
     }
     const int l31 = lane & 31;
@@ -594,8 +605,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
 // workgroup relaunch disappear behind the store phase.  bf16, SwiGLU and fp32 residual epilogues (their slabs fit beside the prefetch).
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
-    static_assert(EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32, "epilogues whose slabs fit");
-    constexpr bool PACKED = EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16;
+    static_assert(epi_is_bf16(EPI) || EPI == EPI_SWIGLU_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32, "epilogues whose slabs fit");
+    constexpr bool PACKED = epi_is_bf16(EPI) || EPI == EPI_SWIGLU_BF16;
     constexpr int BM = 256, BN = 256, WN = 4, NW = 8, TM = 128, TN = 64, FM = 4, FN = 2;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, A_INSTR = 4, B_INSTR = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -678,7 +689,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
             prologue();
         }
         if constexpr (EPI == EPI_SWIGLU_BF16) epilogue_swiglu<FM, BN>(p, acc, slab, rowst, lane, m0 + wm * TM, tn_cur, wn);
-        else if constexpr (EPI == EPI_BF16) epilogue_bf16<FM, BN>(p, acc, slab, rowst, lane, m0 + wm * TM, n0, wn);
+        else if constexpr (epi_is_bf16(EPI)) epilogue_bf16<FM, BN, epi_act(EPI)>(p, acc, slab, rowst, lane, m0 + wm * TM, n0, wn);
         else epilogue_at<EPI, FM, FN, BN, 64>(p, acc, slab, lane, m0 + wm * TM, n0, tn_cur, wn);
         if (next >= ntiles) break;
         tile = next;
@@ -977,15 +988,15 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
         if (a.M < 256 || ncols < 256) c3 = 1e30;
         if (a.M < 256 || ncols < 128) c2 = 1e30;
         cfg = (c3 <= c2 && c3 <= c1) ? 3 : (c2 <= c1 ? 2 : 1);
-        // split rings: +1..3 % over the lockstep 2-stage ring on the tower shapes; as a persistent tile loop (bf16 / SwiGLU epilogues,
-        // case 9 falls back to 7 for the others): another -2.4 % (q|k|v) / -4.9 % (W1|W2) per launch
+        // split rings: +1..3 % over the lockstep 2-stage ring on the tower shapes; as a persistent tile loop (bf16 / GELU / SwiGLU /
+        // residual epilogues, case 9 falls back to 7 for the others): another -2.4 % (q|k|v) / -4.9 % (W1|W2) per launch
         if (cfg == 3 && use_glds) cfg = PP_DEFAULT ? 5 : 9;
     }
     const int ns = sp[(cfg == 4 || cfg == 8) ? 2 : (cfg >= 5 ? 3 : cfg)];   // cfgs 5..7 and 9 are 256x256 variants
     a.ktiles_per_split = (ktiles + ns - 1) / ns;
     switch (cfg) {
         case 9:                                                                                 // persistent split rings (packed epilogues)
-            if constexpr (EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
+            if constexpr (epi_is_bf16(EPI) || EPI == EPI_SWIGLU_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
                 if (use_glds && ns == 1) return launch_persist<EPI>(a, stream);
             }
             return launch_cfg<EPI, 256, 256, 2, 4, 32>(a, ns, use_glds, stream);
@@ -1006,11 +1017,12 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 // epi: 0 bf16 out (+bias) | 1 f32 out (+bias) | 2 f32 out = extra(residual) + acc + bias |
 //      3 fused SwiGLU (B = [W1;W2] stacked [2*group, K], bias [2*group], out bf16 [M, group]) |
 //      4 f32 atomic accumulate (split-K, C pre-zeroed or accumulating) |
-//      5 patch-embed: out row = row + row/group + 1, += extra[(row%group+1)*ldc + col]
+//      5 patch-embed: out row = row + row/group + 1, += extra[(row%group+1)*ldc + col] |
+//      6 residual with a folded LayerNorm (cs_gemm_nt_ln) | 7 bf16 out = GELU(acc + bias) (exact, erf) | 8 bf16 out = QuickGELU(acc + bias)
 // flags bit0: 0 = global_load_lds staging, 1 = register staging (debug/fallback A-B switch)
 //       bits 4-7: force schedule (1 = 128x128, 2 = 256x128, 3 = 256x256 lockstep, 4 = 256x128 3-stage ring,
 //                 5 = 256x256 ping-pong, 6 = 256x256 lockstep + L2 warm-up, 7 = 256x256 split rings A3/B2,
-//                 8 = 256x128 K-32 ring, two workgroups per CU, 9 = persistent split rings (bf16 / SwiGLU / residual epilogues); 0 = heuristic)
+//                 8 = 256x128 K-32 ring, two workgroups per CU, 9 = persistent split rings (bf16 / GELU / SwiGLU / residual epilogues); 0 = heuristic)
 //       bits 8-11: raster group height override (0 = 8)
 //       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue;
 //       bit 15: split-ring schedule issues its DMA in one burst behind the barrier instead of interleaved with the MFMAs
@@ -1041,8 +1053,8 @@ static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias
                  "cs_gemm_nt_ln: the bf16 copy exists for the residual epilogues (8-byte aligned, ldxb %% 4 == 0)");
     CS_CHECK_ARG((ln_mean == nullptr) == (ln_rstd == nullptr) && (ln_mean == nullptr || ln_colsum != nullptr),
                  "cs_gemm_nt_ln: mean, rstd and the column-sum vector come together");
-    CS_CHECK_ARG(ln_mean == nullptr || epi == EPI_BF16 || epi == EPI_SWIGLU_BF16 || epi == EPI_RESID_LN_F32,
-                 "cs_gemm_nt_ln: a folded LayerNorm exists for epilogues 0, 3 and 6");
+    CS_CHECK_ARG(ln_mean == nullptr || epi_is_bf16(epi) || epi == EPI_SWIGLU_BF16 || epi == EPI_RESID_LN_F32,
+                 "cs_gemm_nt_ln: a folded LayerNorm exists for epilogues 0, 3, 6, 7 and 8");
     if (epi == EPI_PATCH_F32 || epi == EPI_RESID_F32 || epi == EPI_RESID_LN_F32) CS_CHECK_ARG(extra != nullptr && ((uintptr_t)extra % 16) == 0, "cs_gemm_nt: epilogue %d needs 16-byte aligned extra", epi);
     if (epi == EPI_PATCH_F32) CS_CHECK_ARG(group > 0, "cs_gemm_nt: patch epilogue needs group");
     a.ktiles_per_split = K / BK;
@@ -1058,6 +1070,8 @@ static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias
         case EPI_ATOMIC_F32: return launch<EPI_ATOMIC_F32>(a, splits, glds, force, stream);
         case EPI_PATCH_F32: return launch<EPI_PATCH_F32>(a, splits, glds, force, stream);
         case EPI_RESID_LN_F32: return launch<EPI_RESID_LN_F32>(a, splits, glds, force, stream);
+        case EPI_GELU_BF16: return launch<EPI_GELU_BF16>(a, splits, glds, force, stream);
+        case EPI_QGELU_BF16: return launch<EPI_QGELU_BF16>(a, splits, glds, force, stream);
     }
     cs_set_error("cs_gemm_nt: unknown epilogue %d", epi);
     return -1;

@@ -31,11 +31,13 @@ __device__ __forceinline__ void store_bf16x4(__bf16* p, const float (&v)[4]) {
     for (int i = 0; i < 4; ++i) t.e[i] = f2bf(v[i]);
     *(uint2*)p = t.u;
 }
+__device__ __forceinline__ void store_x4(__bf16* p, const float (&v)[4]) { store_bf16x4(p, v); }
+__device__ __forceinline__ void store_x4(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 
 // ---------------------------------------------------------------------------------------------
-template <typename TX, int MAXG>
+template <typename TX, int MAXG, typename TY = __bf16>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, long ldx, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, __bf16* __restrict__ y, long ldy,
+                                                     const float* __restrict__ beta, TY* __restrict__ y, long ldy,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      int M, int C, float eps) {
     const int lane = threadIdx.x & 63;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, l
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    __bf16* yr = y + (size_t)row * ldy;
+    TY* yr = y + (size_t)row * ldy;
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) {
         const int c = (g * 64 + lane) * 4;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, l
             const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
             float o[4] = {(v[g][0] - mean) * rstd * ga.x + be.x, (v[g][1] - mean) * rstd * ga.y + be.y,
                           (v[g][2] - mean) * rstd * ga.z + be.z, (v[g][3] - mean) * rstd * ga.w + be.w};
-            store_bf16x4(yr + c, o);
+            store_x4(yr + c, o);
         }
     }
     if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
@@ -303,6 +305,21 @@ extern "C" int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const floa
     if (x_dtype == 0) { if (C <= 1024) LNF(float, 4); else if (C <= 2048) LNF(float, 8); else LNF(float, 12); }
     else { if (C <= 1024) LNF(__bf16, 4); else if (C <= 2048) LNF(__bf16, 8); else LNF(__bf16, 12); }
 #undef LNF
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+
+// fp32 in -> fp32 out (y distinct from x): ln_pre of the OpenAI-CLIP ViT, whose output *is* the residual stream
+// (open_clip/transformer.py:476-477; LayerNorm under autocast returns fp32).
+extern "C" int cs_layernorm_fwd_f32(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy, float* mean,
+                                    float* rstd, int M, int C, float eps, hipStream_t stream) {
+    CS_CHECK_ARG(x && y && gamma && beta && C <= MAXC && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && M > 0,
+                 "cs_layernorm_fwd_f32: C=%d unsupported (multiple of 4, <= %d)", C, MAXC);
+    CS_CHECK_ARG((mean == nullptr) == (rstd == nullptr), "cs_layernorm_fwd_f32: mean/rstd must both be given or both null");
+    dim3 grid((M + ROWS_PER_WG - 1) / ROWS_PER_WG), block(256);
+#define LNF32(NG) hipLaunchKernelGGL((ln_fwd_kernel<float, NG, float>), grid, block, 0, stream, x, ldx, gamma, beta, y, ldy, mean, rstd, M, C, eps)
+    if (C <= 1024) LNF32(4); else if (C <= 2048) LNF32(8); else LNF32(12);
+#undef LNF32
     CS_LAUNCH_CHECK();
     return 0;
 }

@@ -37,7 +37,7 @@ import torch.nn.functional as F
 from .config import TowerCfg
 
 BF16, F32 = torch.bfloat16, torch.float32
-EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32, EPI_RESID_LN_F32 = range(7)
+EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32, EPI_RESID_LN_F32, EPI_GELU_BF16, EPI_QGELU_BF16 = range(9)
 DX_BF16, DX_F32_ASSIGN, DX_F32_ACCUM = range(3)
 ALIGN = 64
 
@@ -86,6 +86,22 @@ def is_no_decay(name: str, ndim: int) -> bool:
 
 
 class EvaEngine:
+    BLOCK_TAG = "blocks."                     # state-dict name of the block list below the tower prefix
+
+    def _layout(self):
+        return param_groups_layout(self.cfg, self.prefix)
+
+    def block_index(self, name: str):
+        """Index of the transformer block a state-dict name belongs to, None for stem / head tensors."""
+        tag = self.prefix + self.BLOCK_TAG
+        return int(name[len(tag):].split(".")[0]) if name.startswith(tag) else None
+
+    def _never_reached(self, i: int, name: str) -> bool:
+        """Tensors of block i the dense path never differentiates.  The last block runs without attention, so its q/k projections
+        and q_bias never get a gradient and torch's AdamW skips them (no decay either) -- SURVEY.md D7."""
+        return i == self.cfg.layers - 1 and (name.rsplit(".", 2)[-2:] in (["q_proj", "weight"], ["k_proj", "weight"])
+                                             or name.endswith("attn.q_bias"))
+
     def __init__(self, cfg: TowerCfg, ops, trainable: bool = False, prefix: str = "visual."):
         self.cfg, self.ops, self.prefix, self.trainable = cfg, ops, prefix, trainable
         self.offsets = OrderedDict()          # name -> (offset, storage shape)
@@ -93,10 +109,9 @@ class EvaEngine:
         off = 0
         self.block_ranges = []                # flat [begin, end) of each block (contiguous all-reduce buckets)
         cur_block, blk_begin = None, 0
-        for grp in param_groups_layout(cfg, prefix):
+        for grp in self._layout():
             off = _round_up(off, ALIGN)
-            name0 = grp[0][0]
-            blk = int(name0[len(prefix) + 7:].split(".")[0]) if name0.startswith(prefix + "blocks.") else None
+            blk = self.block_index(grp[0][0])
             if blk != cur_block:
                 if cur_block is not None:
                     self.block_ranges.append((blk_begin, off))
@@ -244,15 +259,8 @@ class EvaEngine:
             return
         self.flags.zero_()
         for name, (o, s) in self.offsets.items():
-            if not name.startswith(self.prefix + "blocks.") or "._" in name:
-                continue
-            i = int(name[len(self.prefix) + 7:].split(".")[0])
-            if i < self.first_trainable:
-                continue
-            # the dense path runs the last block without attention: its q/k projections and q_bias never get a
-            # gradient, so torch's AdamW skips them (no decay either) -- SURVEY.md D7.
-            if i == L - 1 and name.rsplit(".", 2)[-2:] in (["q_proj", "weight"], ["k_proj", "weight"]) or \
-                    (i == L - 1 and name.endswith("attn.q_bias")):
+            i = self.block_index(name)
+            if i is None or "._" in name or i < self.first_trainable or self._never_reached(i, name):
                 continue
             n = math.prod(s)
             assert o % 64 == 0 and n % 64 == 0, f"{name}: flag granularity"
@@ -260,8 +268,7 @@ class EvaEngine:
         self.sync_transposed()
 
     def trainable_names(self):
-        return [n for n in self.public_names()
-                if n.startswith(self.prefix + "blocks.") and int(n[len(self.prefix) + 7:].split(".")[0]) >= self.first_trainable]
+        return [n for n in self.public_names() if (self.block_index(n) if self.block_index(n) is not None else -1) >= self.first_trainable]
 
     # ------------------------------------------------------------------------------------------ tables
     def rope_tables(self, grid: int):

@@ -1,0 +1,292 @@
+"""Step engine of the OpenAI-CLIP vision transformer on the CLIPSelf hot path: the same flat-buffer
+machinery and kernels as the EVA02 engine (clipself_amd/engine.py), with this tower family's schedule.  Where the reference
+does each stage (paths under /root/reference/src/open_clip/):
+
+  stem            transformer.py:551-569     conv1 (no bias; im2row + GEMM) + class_embedding + positional_embedding, ln_pre
+  block           transformer.py:232-244     x += out_proj(MHA(ln_1 x)); x += c_proj(act(c_fc(ln_2 x)))
+  attention       transformer.py:203,217-230 nn.MultiheadAttention: fused in_proj [3C,C] (+bias on q, k and v), softmax(qk^T/8)v
+  last dense blk  transformer.py:247-260     out_proj(v-slice of in_proj(ln_1 x)), no attention (maskclip style)
+  MLP             transformer.py:209-213,31-34   GELU (erf) or QuickGELU
+  image head      transformer.py:486-494     ln_post(x[:,0]) @ proj
+  dense head      transformer.py:576-587     normalize(ln_post(x[:,1:]) @ proj)
+  lock            transformer.py:391-422     groups = [stem, positional_embedding, blocks..., last block]; the last n train
+
+Differences to the EVA02 schedule: no RoPE (the attention kernels get identity tables), no sub-LayerNorms, `proj` is a bias-free
+[C,E] matrix kept transposed for the forward GEMM, and the last dense block owns no never-reached *tensor* (q/k are rows of the one
+in_proj_weight parameter, whose gradient rows stay zero -- exactly what autograd hands torch's AdamW).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from .config import TowerCfg
+from .engine import (BF16, DX_BF16, DX_F32_ACCUM, DX_F32_ASSIGN, EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_PATCH_F32, EPI_QGELU_BF16,
+                     EPI_RESID_F32, F32, EvaEngine, _round_up)
+
+
+def clip_vit_layout(cfg: TowerCfg, prefix: str = "visual."):
+    """Allocation groups in layer order with the reference's state-dict names (transformer.py:355-389,190-215)."""
+    C, Hd, E, p = cfg.width, cfg.hidden, cfg.embed_dim, cfg.patch_size
+    Kp = _round_up(3 * p * p, 64)
+    t = lambda name, shape, storage=None: (name, shape, storage if storage is not None else shape)
+    groups = [[t(prefix + "class_embedding", (C,))], [t(prefix + "positional_embedding", (cfg.tokens, C))],
+              [t(prefix + "conv1.weight", (C, 3, p, p), (C, Kp))], [t(prefix + "ln_pre.weight", (C,))], [t(prefix + "ln_pre.bias", (C,))]]
+    for i in range(cfg.layers):
+        b = f"{prefix}transformer.resblocks.{i}."
+        groups += [[t(b + "ln_1.weight", (C,))], [t(b + "ln_1.bias", (C,))],
+                   [t(b + "attn.in_proj_weight", (3 * C, C))], [t(b + "attn.in_proj_bias", (3 * C,))],
+                   [t(b + "attn.out_proj.weight", (C, C))], [t(b + "attn.out_proj.bias", (C,))],
+                   [t(b + "ln_2.weight", (C,))], [t(b + "ln_2.bias", (C,))],
+                   [t(b + "mlp.c_fc.weight", (Hd, C))], [t(b + "mlp.c_fc.bias", (Hd,))],
+                   [t(b + "mlp.c_proj.weight", (C, Hd))], [t(b + "mlp.c_proj.bias", (C,))]]
+    groups += [[t(prefix + "ln_post.weight", (C,))], [t(prefix + "ln_post.bias", (C,))], [t(prefix + "proj", (C, E))]]
+    return groups
+
+
+class ClipVitEngine(EvaEngine):
+    BLOCK_TAG = "transformer.resblocks."
+
+    def __init__(self, cfg: TowerCfg, ops, trainable: bool = False, prefix: str = "visual."):
+        if cfg.hidden % 64 or cfg.width % 64 or cfg.embed_dim % 64:
+            raise NotImplementedError(f"{cfg.name}: width, MLP width and embed_dim must be multiples of 64")
+        super().__init__(cfg, ops, trainable=trainable, prefix=prefix)
+        self.fold_sub_ln = self.fold_block_ln = False           # EVA02-only schedules
+        self.cls_only_last_block = False
+
+    def _layout(self):
+        return clip_vit_layout(self.cfg, self.prefix)
+
+    def _never_reached(self, i, name):
+        return False
+
+    # ------------------------------------------------------------------------------------------ parameters
+    def sync_transposed(self, blocks=None):
+        """proj^T [E,C] for the forward head GEMM (every tower), and W^T shadows of the trainable blocks for the dgrad GEMMs."""
+        cfg, C, Hd = self.cfg, self.cfg.width, self.cfg.hidden
+        self.ops.transpose_bf16(self.w[self.prefix + "proj"], self._wt_alloc("head_fwd", C, cfg.embed_dim))
+        if not self.trainable:
+            return
+        for i in (range(self.first_trainable, cfg.layers) if blocks is None else blocks):
+            b = f"{self.prefix}{self.BLOCK_TAG}{i}."
+            self.ops.transpose_bf16(self.w[b + "attn.in_proj_weight"], self._wt_alloc((i, "qkv"), 3 * C, C))
+            self.ops.transpose_bf16(self.w[b + "attn.out_proj.weight"], self._wt_alloc((i, "proj"), C, C))
+            self.ops.transpose_bf16(self.w[b + "mlp.c_fc.weight"], self._wt_alloc((i, "fc"), Hd, C))
+            self.ops.transpose_bf16(self.w[b + "mlp.c_proj.weight"], self._wt_alloc((i, "cproj"), C, Hd))
+
+    def sync_shadow(self):
+        self.ops.cast_f32_bf16(self.master, self.shadow)
+        self._pos_cache.clear()
+        self.sync_transposed()
+
+    def set_trainable_blocks(self, unlocked_groups: int):
+        """VisionTransformer.lock (transformer.py:391-422): of [stem, positional_embedding, block 0 .. L-1] the last n groups train;
+        n = 0 freezes everything.  Unlocking the positional embedding or the stem (n > L) is not part of any CLIPSelf recipe."""
+        L = self.cfg.layers
+        if unlocked_groups > L:
+            raise NotImplementedError(f"unlocked_groups={unlocked_groups} > {L}: training positional_embedding / conv1 / ln_pre is not supported")
+        super().set_trainable_blocks(unlocked_groups)
+        if unlocked_groups <= 0:
+            self.first_trainable = L
+            if self.trainable:
+                self.flags.zero_()
+
+    # ------------------------------------------------------------------------------------------ tables
+    def rope_tables(self, grid: int):
+        """No rotary embedding in this family: cos = 1, sin = 0 turn the attention kernels' rotation into the identity."""
+        key = ("rope", grid)
+        if key not in self._tables:
+            shape = (grid * grid, self.cfg.head_width)
+            self._tables[key] = (torch.ones(shape, dtype=F32, device=self.device), torch.zeros(shape, dtype=F32, device=self.device))
+        return self._tables[key]
+
+    def pos_for(self, grid: int):
+        """positional_embedding [N, C] fp32, bicubic-rescaled for a non-native grid (transformer.py:724-734); cached per grid."""
+        if grid not in self._pos_cache:
+            pe = self.p[self.prefix + "positional_embedding"]
+            if grid != self.cfg.grid:
+                C = pe.shape[1]
+                pe2 = pe[1:].T.contiguous().view(1, C, self.cfg.grid, self.cfg.grid)
+                pe2 = F.interpolate(pe2, (grid, grid), mode="bicubic", align_corners=False).view(C, grid * grid)
+                pe = torch.cat([pe[:1], pe2.T], dim=0)
+            self._pos_cache[grid] = pe.contiguous()
+        return self._pos_cache[grid]
+
+    # ------------------------------------------------------------------------------------------ forward pieces
+    def _stem(self, images):
+        ops, cfg, P = self.ops, self.cfg, self.prefix
+        B, _, S, _ = images.shape
+        p, C = cfg.patch_size, cfg.width
+        g = S // p
+        N = g * g + 1
+        A = ops.empty((B * g * g, self.Kpe), BF16)
+        ops.im2row(images.contiguous(), A, p)
+        x = ops.empty((B, N, C), F32)
+        pos = self.pos_for(g)
+        ops.gemm_nt(A, self.storage_of(self.shadow, P + "conv1.weight"), x.view(B * N, C), extra=pos, epi=EPI_PATCH_F32, group=g * g)
+        ops.cls_row(x, self.p[P + "class_embedding"], pos)
+        y = ops.empty((B, N, C), F32)                       # ln_pre's output is the residual stream
+        ops.layernorm_fwd_f32(x.view(B * N, C), self.p[P + "ln_pre.weight"], self.p[P + "ln_pre.bias"], y.view(B * N, C), None, None, cfg.ln_eps)
+        return y, g
+
+    def _block_fwd(self, i, x, B, N, cos, sin, with_attn=True, save=None, inplace=True):
+        ops, cfg = self.ops, self.cfg
+        C, Hd, H, eps = cfg.width, cfg.hidden, cfg.heads, cfg.ln_eps
+        b = f"{self.prefix}{self.BLOCK_TAG}{i}."
+        M = B * N
+        keep = save is not None
+        st = (lambda: (ops.empty((M,), F32), ops.empty((M,), F32))) if keep else (lambda: (None, None))
+
+        ln1 = ops.empty((M, C), BF16)
+        m1, r1 = st()
+        ops.layernorm_fwd(x, self.p[b + "ln_1.weight"], self.p[b + "ln_1.bias"], ln1, m1, r1, eps)
+        wqkv, bqkv = self.w[b + "attn.in_proj_weight"], self.p[b + "attn.in_proj_bias"]
+        qkv = lse = None
+        att = ops.empty((M, C), BF16)
+        if with_attn:
+            qkv = ops.empty((M, 3 * C), BF16)
+            ops.gemm_nt(ln1, wqkv, qkv, bias=bqkv, epi=EPI_BF16)
+            lse = ops.empty((B * H, N), F32) if keep else None
+            ops.attn_fwd(qkv, cos, sin, att, lse, B, N, H, cfg.head_width ** -0.5)
+        else:
+            ops.gemm_nt(ln1, wqkv[2 * C:], att, bias=bqkv[2 * C:], epi=EPI_BF16)        # proj_without_attn: the value rows only
+        x1 = x if inplace else ops.empty((M, C), F32)
+        ops.gemm_nt(att, self.w[b + "attn.out_proj.weight"], x1, bias=self.p[b + "attn.out_proj.bias"], extra=x, epi=EPI_RESID_F32)
+
+        ln2 = ops.empty((M, C), BF16)
+        m2, r2 = st()
+        ops.layernorm_fwd(x1, self.p[b + "ln_2.weight"], self.p[b + "ln_2.bias"], ln2, m2, r2, eps)
+        hid = ops.empty((M, Hd), BF16)
+        fc = None
+        if keep:
+            fc = ops.empty((M, Hd), BF16)
+            ops.gemm_nt(ln2, self.w[b + "mlp.c_fc.weight"], fc, bias=self.p[b + "mlp.c_fc.bias"], epi=EPI_BF16)
+            ops.gelu_fwd(fc, hid, cfg.quick_gelu)
+        else:
+            ops.gemm_nt(ln2, self.w[b + "mlp.c_fc.weight"], hid, bias=self.p[b + "mlp.c_fc.bias"],
+                        epi=EPI_QGELU_BF16 if cfg.quick_gelu else EPI_GELU_BF16)
+        x2 = x1 if inplace else ops.empty((M, C), F32)
+        ops.gemm_nt(hid, self.w[b + "mlp.c_proj.weight"], x2, bias=self.p[b + "mlp.c_proj.bias"], extra=x1, epi=EPI_RESID_F32)
+        if keep:
+            save.update(x0=x, ln1=ln1, st1=(m1, r1), qkv=qkv, lse=lse, att=att, with_attn=with_attn, x1=x1, ln2=ln2, st2=(m2, r2),
+                        fc=fc, hid=hid)
+        return x2
+
+    def _head(self, rows, out):
+        """out[M,E] f32 = bf16(rows) . proj   (no bias: transformer.py:492-493,583-584)."""
+        self.ops.gemm_nt(rows, self.wt["head_fwd"][:, :self.cfg.width], out, epi=EPI_F32)
+
+    # ------------------------------------------------------------------------------------------ teacher
+    def encode_image(self, images, chunk: int = 256):
+        """Frozen-teacher path: every block with attention, ln_post on the CLS row, proj.  [K,3,S,S] -> fp32 [K,E]."""
+        ops, cfg, P = self.ops, self.cfg, self.prefix
+        K = images.shape[0]
+        out = ops.empty((K, cfg.embed_dim), F32)
+        for k0 in range(0, K, chunk):
+            img = images[k0:k0 + chunk]
+            B = img.shape[0]
+            x, g = self._stem(img)
+            N = g * g + 1
+            cos, sin = self.rope_tables(g)
+            xf = x.view(B * N, cfg.width)
+            for i in range(cfg.layers):
+                self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
+            cls = ops.empty((B, cfg.width), BF16)
+            ops.layernorm_fwd(x[:, 0, :], self.p[P + "ln_post.weight"], self.p[P + "ln_post.bias"], cls, None, None, cfg.ln_eps)
+            self._head(cls, out[k0:k0 + B])
+        return out
+
+    # ------------------------------------------------------------------------------------------ student
+    def encode_dense(self, images, need_grad: bool = False):
+        ops, cfg, P = self.ops, self.cfg, self.prefix
+        B = images.shape[0]
+        x, g = self._stem(images)
+        N, C, E = g * g + 1, cfg.width, cfg.embed_dim
+        cos, sin = self.rope_tables(g)
+        xf = x.view(B * N, C)
+        saves = {}
+        for i in range(cfg.layers):
+            keep = need_grad and i >= self.first_trainable
+            save = {} if keep else None
+            xf = self._block_fwd(i, xf, B, N, cos, sin, with_attn=(i < cfg.layers - 1), save=save, inplace=not keep)
+            if keep:
+                saves[i] = save
+        M = B * N
+        lnf = ops.empty((M, C), BF16)
+        mean = ops.empty((M,), F32) if need_grad else None
+        rstd = ops.empty((M,), F32) if need_grad else None
+        ops.layernorm_fwd(xf, self.p[P + "ln_post.weight"], self.p[P + "ln_post.bias"], lnf, mean, rstd, cfg.ln_eps)
+        feats = ops.empty((M, E), F32)
+        self._head(lnf, feats)
+        dense = ops.empty((M, E), F32)
+        inv = ops.empty((M,), F32)
+        ops.l2norm_fwd(feats, dense, inv)
+        if need_grad:
+            self._ctx = dict(B=B, N=N, g=g, saves=saves, xL=xf, stf=(mean, rstd), dense=dense, inv=inv, cos=cos, sin=sin)
+        return dense.view(B, N, E), g
+
+    # ------------------------------------------------------------------------------------------ backward
+    def _block_bwd(self, i, s, g, B, N, cos, sin, ws):
+        """g: fp32 [M,C] gradient w.r.t. the block output; updated in place to the gradient w.r.t. its input."""
+        ops, cfg = self.ops, self.cfg
+        C, Hd, H = cfg.width, cfg.hidden, cfg.heads
+        b = f"{self.prefix}{self.BLOCK_TAG}{i}."
+        M = B * N
+        G = self.g
+        # ---- MLP: x2 = x1 + c_proj(act(c_fc(ln_2 x1))) --------------------------------------------
+        gb = ops.empty((M, C), BF16)
+        ops.cast_f32_bf16(g, gb)
+        ops.colsum_bf16(gb, G[b + "mlp.c_proj.bias"])
+        self._wgrad(gb, self._transposed(s["hid"]), G[b + "mlp.c_proj.weight"])
+        d_hid = ops.empty((M, Hd), BF16)
+        ops.gemm_nt(gb, self.wt[(i, "cproj")][:, :C], d_hid, epi=EPI_BF16)                   # [M,C] . c_proj[C,Hd]
+        d_fc = ops.empty((M, Hd), BF16)
+        ops.gelu_bwd(d_hid, s["fc"], d_fc, cfg.quick_gelu)
+        ops.colsum_bf16(d_fc, G[b + "mlp.c_fc.bias"])
+        self._wgrad(d_fc, self._transposed(s["ln2"]), G[b + "mlp.c_fc.weight"])
+        d_ln2 = ops.empty((M, C), BF16)
+        ops.gemm_nt(d_fc, self.wt[(i, "fc")][:, :Hd], d_ln2, epi=EPI_BF16)                   # [M,Hd] . c_fc[Hd,C]
+        ops.layernorm_bwd(d_ln2, s["x1"], self.p[b + "ln_2.weight"], *s["st2"], g, DX_F32_ACCUM,
+                          G[b + "ln_2.weight"], G[b + "ln_2.bias"], True, ws)
+        # ---- attention branch: x1 = x0 + out_proj(att) ------------------------------------------
+        ops.cast_f32_bf16(g, gb)
+        ops.colsum_bf16(gb, G[b + "attn.out_proj.bias"])
+        self._wgrad(gb, self._transposed(s["att"]), G[b + "attn.out_proj.weight"])
+        d_att = ops.empty((M, C), BF16)
+        ops.gemm_nt(gb, self.wt[(i, "proj")][:, :C], d_att, epi=EPI_BF16)
+        ln1_t = self._transposed(s["ln1"])
+        d_ln1 = ops.empty((M, C), BF16)
+        Gw, Gb = G[b + "attn.in_proj_weight"], G[b + "attn.in_proj_bias"]
+        if s["with_attn"]:
+            d_qkv = ops.empty((M, 3 * C), BF16)
+            ops.attn_bwd(s["qkv"], s["att"], d_att, s["lse"], cos, sin, d_qkv, ws, B, N, H, cfg.head_width ** -0.5)
+            ops.colsum_bf16(d_qkv, Gb)                                                       # q, k and v all carry a bias here
+            self._wgrad(d_qkv, ln1_t, Gw)
+            ops.gemm_nt(d_qkv, self.wt[(i, "qkv")][:, :3 * C], d_ln1, epi=EPI_BF16)
+        else:
+            ops.colsum_bf16(d_att, Gb[2 * C:])                                               # q/k rows keep their zero gradient
+            self._wgrad(d_att, ln1_t, Gw[2 * C:])
+            ops.gemm_nt(d_att, self.wt[(i, "qkv")][:, 2 * C:3 * C], d_ln1, epi=EPI_BF16)
+        ops.layernorm_bwd(d_ln1, s["x0"], self.p[b + "ln_1.weight"], *s["st1"], g, DX_F32_ACCUM,
+                          G[b + "ln_1.weight"], G[b + "ln_1.bias"], True, ws)
+
+    def backward_dense(self, d_dense):
+        ops, cfg, P = self.ops, self.cfg, self.prefix
+        c = self._ctx
+        if c is None:
+            raise RuntimeError("backward_dense() without a preceding encode_dense(need_grad=True)")
+        self._ctx = None
+        B, N, C, E = c["B"], c["N"], cfg.width, cfg.embed_dim
+        M = B * N
+        d_feats = ops.empty((M, E), BF16)
+        ops.l2norm_bwd(d_dense.reshape(M, E), c["dense"], c["inv"], d_feats)
+        d_lnf = ops.empty((M, C), BF16)
+        ops.gemm_nt(d_feats, self.w[P + "proj"], d_lnf, epi=EPI_BF16)                        # [M,E] . proj^T: proj [C,E] is already "W^T"; frozen
+        g = ops.empty((M, C), F32)
+        ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "ln_post.weight"], *c["stf"], g, DX_F32_ASSIGN)   # ln_post frozen (transformer.py:405)
+        ws_bytes = max(ops.layernorm_bwd_workspace(M, C), ops.attn_bwd_workspace(B, N, cfg.heads))
+        ws = ops.empty((ws_bytes,), torch.uint8)
+        for i in range(cfg.layers - 1, self.first_trainable - 1, -1):
+            self._block_bwd(i, c["saves"].pop(i), g, B, N, c["cos"], c["sin"], ws)
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(i)

@@ -17,7 +17,7 @@ import torch
 _CSRC = Path(__file__).resolve().parent / "csrc"
 _LIB_PATH = _CSRC / "libclipself_hip.so"
 
-EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32, EPI_RESID_LN_F32 = range(7)
+EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32, EPI_RESID_LN_F32, EPI_GELU_BF16, EPI_QGELU_BF16 = range(9)
 DX_BF16, DX_F32_ASSIGN, DX_F32_ACCUM = range(3)
 
 _vp, _i, _l, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_size_t
@@ -34,6 +34,7 @@ SIGNATURES = {
     "cs_ln_stats_finalize": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "cs_attn_fwd_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_layernorm_fwd": (_i, [_vp, _i, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _vp]),
+    "cs_layernorm_fwd_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _vp]),
     "cs_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "cs_layernorm_bwd": (_i, [_vp, _l, _vp, _i, _l, _vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "cs_l2norm_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
@@ -44,6 +45,8 @@ SIGNATURES = {
     "cs_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_swiglu_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
     "cs_swiglu_bwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _vp]),
+    "cs_gelu_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp]),
+    "cs_gelu_bwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _vp]),
     "cs_cast_f32_bf16": (_i, [_vp, _vp, _l, _vp]),
     "cs_transpose_bf16": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
     "cs_colsum_bf16": (_i, [_vp, _l, _vp, _i, _i, _vp]),
@@ -211,6 +214,15 @@ class HipOps:
         self._ok(self.lib.cs_layernorm_fwd(_p(x), _dt(x), x.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0) if y is not None else 0,
                                            _p(mean), _p(rstd), M, C, eps, self._stream()), "cs_layernorm_fwd")
 
+    def layernorm_fwd_f32(self, x, gamma, beta, y, mean=None, rstd=None, eps=1e-5):
+        """fp32 rows -> fp32 rows (ln_pre of the OpenAI-CLIP ViT: its output is the residual stream)."""
+        self._chk(x, gamma, beta, y, mean, rstd)
+        M, C = x.shape
+        assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.stride(1) == 1 and y.stride(1) == 1
+        assert x.data_ptr() != y.data_ptr(), "layernorm_fwd_f32 is out of place"
+        self._ok(self.lib.cs_layernorm_fwd_f32(_p(x), x.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), _p(mean), _p(rstd), M, C, eps,
+                                               self._stream()), "cs_layernorm_fwd_f32")
+
     def layernorm_bwd_workspace(self, M, C) -> int:
         return int(self.lib.cs_layernorm_bwd_workspace(M, C))
 
@@ -262,6 +274,17 @@ class HipOps:
         M, Hd = dh.shape
         self._ok(self.lib.cs_swiglu_bwd(_p(dh), dh.stride(0), _p(x12), x12.stride(0), _p(dx12), dx12.stride(0), M, Hd,
                                         self._stream()), "cs_swiglu_bwd")
+
+    def gelu_fwd(self, x, y, quick=False):
+        self._chk(x, y)
+        M, N = x.shape
+        self._ok(self.lib.cs_gelu_fwd(_p(x), x.stride(0), _p(y), y.stride(0), M, N, int(bool(quick)), self._stream()), "cs_gelu_fwd")
+
+    def gelu_bwd(self, dy, x, dx, quick=False):
+        self._chk(dy, x, dx)
+        M, N = x.shape
+        self._ok(self.lib.cs_gelu_bwd(_p(dy), dy.stride(0), _p(x), x.stride(0), _p(dx), dx.stride(0), M, N, int(bool(quick)),
+                                      self._stream()), "cs_gelu_bwd")
 
     def cast_f32_bf16(self, x, y):
         self._chk(x, y)

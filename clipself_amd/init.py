@@ -24,9 +24,26 @@ def _rng(name: str, seed: int) -> np.random.Generator:
     return np.random.Generator(np.random.PCG64((zlib.crc32(name.encode()) << 16) ^ (seed & 0xFFFF)))
 
 
+def clip_vit_param_shapes(cfg: TowerCfg, prefix: str = "visual.") -> "dict[str, tuple]":
+    """Shapes of every parameter of the OpenAI-CLIP vision transformer, in the reference's registration order
+    (src/open_clip/transformer.py:355-389 and :190-215)."""
+    C, Hd, E, p = cfg.width, cfg.hidden, cfg.embed_dim, cfg.patch_size
+    out = {prefix + "class_embedding": (C,), prefix + "positional_embedding": (cfg.tokens, C), prefix + "proj": (C, E),
+           prefix + "conv1.weight": (C, 3, p, p), prefix + "ln_pre.weight": (C,), prefix + "ln_pre.bias": (C,)}
+    for i in range(cfg.layers):
+        b = f"{prefix}transformer.resblocks.{i}."
+        out.update({b + "ln_1.weight": (C,), b + "ln_1.bias": (C,), b + "attn.in_proj_weight": (3 * C, C), b + "attn.in_proj_bias": (3 * C,),
+                    b + "attn.out_proj.weight": (C, C), b + "attn.out_proj.bias": (C,), b + "ln_2.weight": (C,), b + "ln_2.bias": (C,),
+                    b + "mlp.c_fc.weight": (Hd, C), b + "mlp.c_fc.bias": (Hd,), b + "mlp.c_proj.weight": (C, Hd), b + "mlp.c_proj.bias": (C,)})
+    out[prefix + "ln_post.weight"] = (C,)
+    out[prefix + "ln_post.bias"] = (C,)
+    return out
+
+
 def visual_param_shapes(cfg: TowerCfg, prefix: str = "visual.") -> "dict[str, tuple]":
-    """Shapes of every parameter of the EVA02 vision tower, in the reference's
-    registration order (eva_vit_model.py:411-453)."""
+    """Shapes of every parameter of the vision tower, in the reference's registration order (EVA02: eva_vit_model.py:411-453)."""
+    if getattr(cfg, "arch", "eva02") == "openai":
+        return clip_vit_param_shapes(cfg, prefix)
     C, Hd, E, p = cfg.width, cfg.hidden, cfg.embed_dim, cfg.patch_size
     out = {}
     out[prefix + "cls_token"] = (1, 1, C)
@@ -84,6 +101,8 @@ def seeded_visual_state(cfg: TowerCfg, seed: int = 0, prefix: str = "visual.") -
             if ".blocks." in name and (name.endswith("attn.proj.weight") or name.endswith("mlp.w3.weight")):
                 layer = int(name.split(".blocks.")[1].split(".")[0])
                 t = t / math.sqrt(2.0 * (layer + 1))
+            elif name.endswith("visual.proj") or name.endswith("positional_embedding"):
+                t = t * (50.0 * cfg.width ** -0.5)          # scale * randn with scale = width^-0.5 (transformer.py:360-362,387)
         del leaf
         sd[name] = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
     return sd

@@ -1,9 +1,10 @@
 """`open_clip` factory surface for the CLIPSelf hot path.
 
-Mirrors the call signatures of the reference (src/open_clip/factory.py:111-149 `create_model`, :267-350
+Mirrors the call signatures of the reference (src/open_clip/factory.py:111-264 `create_model`, :267-350
 `create_model_and_transforms`; src/open_clip/eva_clip/factory.py:211-355) for the EVA towers
-(`pretrained='eva'`, checkpoint path passed as `cache_dir`).  Anything else the reference's zoo can build
-(ResNets, timm, CoCa, OpenAI ViT) is outside the hot path and raises.
+(`pretrained='eva'`, checkpoint path passed as `cache_dir`) and the plain OpenAI-CLIP ViT configs (`ViT-B-16`, `ViT-L-14`,
+`ViT-L-14-336`; `pretrained='openai'` or a checkpoint path).  Anything else the reference's zoo can build
+(ResNets, timm, CoCa, HF text towers) is outside the hot path and raises.
 """
 from __future__ import annotations
 
@@ -13,8 +14,10 @@ from typing import Optional
 
 import torch
 
+import dataclasses
+
 from ..config import get_tower_cfg, list_models as _list_models
-from .model import CustomCLIP
+from .model import CLIP, CustomCLIP
 
 
 def list_models():
@@ -79,11 +82,13 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
     fp32 accumulation/statistics and fp32 master weights.  `device` must be a ROCm device.
     """
     model_name = model_name.replace("/", "-")
-    if pretrained not in ("eva", None, ""):
-        raise NotImplementedError(f"pretrained={pretrained!r}: only the EVA towers (pretrained='eva') are on the CLIPSelf hot path")
     if jit:
         raise NotImplementedError("torchscript is not supported by the HIP engine")
     cfg = get_tower_cfg(model_name)
+    if cfg.arch == "openai":
+        return _create_openai_vit(cfg, model_name, pretrained, force_quick_gelu, cache_dir, require_pretrained, ops, trainable)
+    if pretrained not in ("eva", None, ""):
+        raise NotImplementedError(f"pretrained={pretrained!r}: the EVA towers load with pretrained='eva' (checkpoint path in cache_dir)")
     os.environ["RoPE"] = "1"                      # side effect of the reference factory (eva_clip/factory.py:249-253)
     model = CustomCLIP(cfg, ops=ops, trainable=trainable)
     if cache_dir and os.path.exists(cache_dir) and os.path.isfile(cache_dir):
@@ -94,6 +99,42 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
     else:
         from ..init import seeded_visual_state
         logging.info(f"No checkpoint at {cache_dir!r}: {model_name} starts from the seeded random initialisation")
+        model.visual.engine.load_state(seeded_visual_state(cfg, seed=0))
+    return model
+
+
+def load_openai_state_dict(path: str):
+    """State dict of an OpenAI release file (a TorchScript archive, or a plain state dict): the keys are already the `CLIP` names
+    (src/open_clip/openai.py:44-76, model.py:417-474); the three shape scalars are dropped like the reference does."""
+    try:
+        sd = torch.jit.load(path, map_location="cpu").state_dict()
+    except RuntimeError:
+        sd = torch.load(path, map_location="cpu", weights_only=False)
+        sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd.state_dict()
+    return {k: v.float() for k, v in sd.items() if k not in ("input_resolution", "context_length", "vocab_size")}
+
+
+def _create_openai_vit(cfg, model_name, pretrained, force_quick_gelu, cache_dir, require_pretrained, ops, trainable):
+    """factory.py:150-232: `pretrained='openai'` = the OpenAI release (QuickGELU, file <cache_dir>/<model>.pt -- there is no network
+    to download it from); another non-empty `pretrained` = path of an open_clip checkpoint; otherwise seeded random initialisation."""
+    openai = bool(pretrained) and pretrained.lower() == "openai"
+    if openai or force_quick_gelu:
+        cfg = dataclasses.replace(cfg, quick_gelu=True)
+    model = CLIP(cfg, ops=ops, trainable=trainable)
+    path = None
+    if openai:
+        path = os.path.join(cache_dir or "", f"{model_name}.pt")
+    elif pretrained:
+        path = pretrained
+    if path and os.path.isfile(path):
+        logging.info(f"Loading pretrained {model_name} weights ({path}).")
+        sd = load_openai_state_dict(path) if openai else load_state_dict(path)
+        model.load_state_dict(sd, strict=False)
+    elif path and require_pretrained:
+        raise RuntimeError(f"Pretrained weights ({path}) not found for model {model_name}.")
+    else:
+        from ..init import seeded_visual_state
+        logging.info(f"No checkpoint at {path!r}: {model_name} starts from the seeded random initialisation")
         model.visual.engine.load_state(seeded_visual_state(cfg, seed=0))
     return model
 

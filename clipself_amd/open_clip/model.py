@@ -1,4 +1,5 @@
-"""Model objects behind the reference's `open_clip` API for the EVA02 towers, backed by the HIP step engine.
+"""Model objects behind the reference's `open_clip` API for the EVA02 towers (and, SURVEY.md §8 N4, the OpenAI-CLIP ViT family:
+`CLIP` / `ClipVisionTower` at the end of this file), backed by the HIP step engines.
 
 Surface mirrored (reference: src/open_clip/eva_clip/model.py:272-346 `CustomCLIP`,
 src/open_clip/eva_clip/eva_vit_model.py:396-711 `EVAVisionTransformer`):
@@ -23,6 +24,7 @@ import torch.nn.functional as F
 
 from ..config import TowerCfg
 from ..engine import EvaEngine, F32
+from ..engine_openai import ClipVitEngine
 
 OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)
 OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -75,6 +77,7 @@ class _Node(nn.Module):
 
 class EVAVisionTower(_Node):
     """`model.visual`: EVA02 ViT (RoPE + SwiGLU + sub-LN) executing on the HIP engine."""
+    ENGINE = EvaEngine
 
     def __init__(self, cfg: TowerCfg, ops=None, trainable: bool = True, teacher_chunk: int = 2048):
         super().__init__()
@@ -82,10 +85,9 @@ class EVAVisionTower(_Node):
         self.image_size = cfg.image_size
         self.image_mean, self.image_std = OPENAI_DATASET_MEAN, OPENAI_DATASET_STD
         self.num_heads, self.embed_dim, self.num_classes = cfg.heads, cfg.width, cfg.embed_dim
-        self.engine = EvaEngine(cfg, ops if ops is not None else _default_ops(), trainable=trainable, prefix="visual.")
+        self.engine = self.ENGINE(cfg, ops if ops is not None else _default_ops(), trainable=trainable, prefix="visual.")
         self.teacher_chunk = teacher_chunk
         self._flat = {}                                   # full name -> nn.Parameter (view of the flat master)
-        cos, sin = self.engine.rope_tables(cfg.grid)
         for full in self.engine.public_names():
             parts = full[len("visual."):].split(".")
             node = self
@@ -94,13 +96,18 @@ class EVAVisionTower(_Node):
             param = nn.Parameter(self.engine.p[full], requires_grad=trainable)
             node.register_parameter(parts[-1], param)
             self._flat[full] = param
+        self._register_tables()
+        self._anchor = torch.zeros((), device=self.engine.device, requires_grad=True)
+        self.grad_checkpointing = False
+
+    def _register_tables(self):
         # the reference registers the RoPE tables as buffers of the tower and (shared module) of every attention
         # (rope.py:138-139); kept for checkpoint-key compatibility
+        cfg = self.cfg
+        cos, sin = self.engine.rope_tables(cfg.grid)
         for node in [self.child("rope")] + [self.child("blocks").child(str(i)).child("attn").child("rope") for i in range(cfg.layers)]:
             node.register_buffer("freqs_cos", cos)
             node.register_buffer("freqs_sin", sin)
-        self._anchor = torch.zeros((), device=self.engine.device, requires_grad=True)
-        self.grad_checkpointing = False
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
@@ -113,8 +120,8 @@ class EVAVisionTower(_Node):
         self.engine.set_trainable_blocks(unlocked_groups)
         first = self.engine.first_trainable
         for full, p in self._flat.items():
-            local = full[len("visual."):]
-            p.requires_grad = local.startswith("blocks.") and int(local.split(".")[1]) >= first
+            blk = self.engine.block_index(full)
+            p.requires_grad = blk is not None and blk >= first
 
     def set_grad_checkpointing(self, enable=True):
         self.grad_checkpointing = enable       # activations are kept; 288 GB of HBM makes recompute pointless here
@@ -196,8 +203,9 @@ class FrozenTextTower(nn.Module):
     (eva_clip/model.py:284-288).  Only its state-dict keys/shapes matter; they are held here as
     frozen parameters so checkpoints round-trip."""
 
-    def __init__(self, cfg: TowerCfg, device):
+    def __init__(self, cfg: TowerCfg, device, mask_in_state_dict: bool = True):
         super().__init__()
+        self.mask_in_state_dict = mask_in_state_dict
         W, L, E = cfg.text_width, cfg.text_layers, cfg.embed_dim
         shapes = {"positional_embedding": (cfg.text_context, W), "text_projection": (W, E),
                   "token_embedding.weight": (cfg.text_vocab, W), "ln_final.weight": (W,), "ln_final.bias": (W,)}
@@ -219,7 +227,8 @@ class FrozenTextTower(nn.Module):
         for safe, k in self._names.items():
             p = self._parameters[safe]
             destination[prefix + k] = p if keep_vars else p.detach()
-        destination[prefix + "attn_mask"] = self.attn_mask
+        if self.mask_in_state_dict:
+            destination[prefix + "attn_mask"] = self.attn_mask
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         with torch.no_grad():
@@ -288,3 +297,51 @@ class CustomCLIP(nn.Module):
         if normalize:
             mask_pooled = F.normalize(mask_pooled, dim=-1)
         return mask_pooled
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# OpenAI-CLIP ViT family: reference src/open_clip/model.py:181-311 `CLIP`, transformer.py:318-734
+# `VisionTransformer` -- same API surface as above on the ClipVitEngine schedule.
+# ------------------------------------------------------------------------------------------------------------------
+class ClipVisionTower(EVAVisionTower):
+    """`model.visual` of the OpenAI-CLIP family: class/positional embeddings, ln_pre, fused-QKV blocks with a GELU MLP, ln_post, proj."""
+    ENGINE = ClipVitEngine
+
+    def __init__(self, cfg: TowerCfg, ops=None, trainable: bool = True, teacher_chunk: int = 2048):
+        super().__init__(cfg, ops=ops, trainable=trainable, teacher_chunk=teacher_chunk)
+        self.output_dim = cfg.embed_dim
+        self.grid_size = (cfg.grid, cfg.grid)
+        self.patch_size = (cfg.patch_size, cfg.patch_size)
+
+    def _register_tables(self):
+        pass                                                # no rotary tables in this family
+
+    def lock(self, unlocked_groups=0, freeze_bn_stats=False):
+        """transformer.py:391-422: of [stem, positional_embedding, block 0 .. L-1] the last `unlocked_groups` train (0 = all frozen)."""
+        super().lock(unlocked_groups=unlocked_groups, freeze_bn_stats=freeze_bn_stats)
+
+
+class CLIP(CustomCLIP):
+    """model.py:181-311: the text tower's tensors sit at the top level of the state dict (`transformer.*`, `token_embedding.weight`,
+    `positional_embedding`, `ln_final.*`, `text_projection`), frozen and never executed by the distillation step."""
+
+    def __init__(self, cfg: TowerCfg, ops=None, trainable: bool = True, with_text: bool = True):
+        nn.Module.__init__(self)
+        self.visual = ClipVisionTower(cfg, ops=ops, trainable=trainable)
+        self.text = None
+        text = FrozenTextTower(cfg, self.visual.engine.device, mask_in_state_dict=False) if with_text else None
+        object.__setattr__(self, "_text", text)             # not a registered child: its keys carry no prefix
+        self.embed_dim, self.vocab_size = cfg.embed_dim, cfg.text_vocab
+        self.logit_scale = nn.Parameter(torch.ones([], device=self.visual.engine.device) * np.log(1 / 0.07))
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self._text is not None:
+            self._text._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        if self._text is not None:
+            own = {prefix + k for k in self._text._names.values()}
+            self._text._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, [], error_msgs)
+            state_dict = {k: v for k, v in state_dict.items() if k not in own}     # not "unexpected" for the parameters of this module
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)

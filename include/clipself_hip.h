@@ -29,7 +29,9 @@ const char* cs_last_error(void);
  * epi: 0 bf16 = acc+bias | 1 f32 = acc+bias | 2 f32 = extra(residual)+acc+bias (in-place allowed) |
  *      3 fused SwiGLU: B=[W1;W2] [2*group,K], bias [2*group], out bf16 [M,group] = silu(x1)*x2 |
  *      4 f32 atomic accumulate (split-K allowed: `splits` >= 1, or <= 0 = chosen by the library) |
- *      5 patch embed: out row = row + row/group + 1, value += extra[(row%group+1)*ldc + col]   (cls/pos layout :540-543)
+ *      5 patch embed: out row = row + row/group + 1, value += extra[(row%group+1)*ldc + col]   (cls/pos layout :540-543) |
+ *      7 bf16 = GELU(acc+bias), 8 bf16 = QuickGELU(acc+bias): c_fc + activation of the OpenAI-CLIP ViT MLP
+ *        (src/open_clip/transformer.py:209-213 `mlp`, :31-34 `QuickGELU`)
  * flags bit0: use register staging instead of the global_load_lds DMA path. */
 int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
                int lda, int ldb, int ldc, int epi, int splits, int group, int flags, cs_stream_t stream);
@@ -63,6 +65,9 @@ int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, c
 /* part [P][M][2] f32 = per-slice (sum, sum of squares) over npp columns each (slices past C ignored) -> LayerNorm mean/rstd [M]
  * of a C-wide row; producers: cs_gemm_nt_ln epi 3 (npp 32) and cs_attn_fwd_stats (npp 64, P = heads). */
 int cs_ln_stats_finalize(const float* part, int P, int npp, int C, int M, float eps, float* mean, float* rstd, cs_stream_t stream);
+/* f32 in -> f32 out: `ln_pre` of the OpenAI-CLIP ViT (src/open_clip/transformer.py:371,477), whose output is the residual stream */
+int cs_layernorm_fwd_f32(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy, float* mean, float* rstd,
+                         int M, int C, float eps, cs_stream_t stream);
 size_t cs_layernorm_bwd_workspace(int M, int C);
 /* dx_mode 0: bf16 write, 1: f32 write, 2: f32 accumulate (residual gradient stream).  dgamma/dbeta nullable (frozen). */
 int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
@@ -96,6 +101,11 @@ int cs_attn_bwd(const void* qkv, const void* o, const void* dout, const float* l
 /* --- SwiGLU elementwise: eva_vit_model.py:101  hidden = silu(x1) * x2   (x12 = [x1 | x2], each Hd wide) */
 int cs_swiglu_fwd(const void* x12, long ldx, void* h, long ldh, int M, int Hd, cs_stream_t stream);
 int cs_swiglu_bwd(const void* dh, long lddh, const void* x12, long ldx, void* dx12, long lddx, int M, int Hd, cs_stream_t stream);
+
+/* --- GELU / QuickGELU elementwise on bf16 [M,N] (training path keeps the c_fc output): src/open_clip/transformer.py:31-34,211
+ *     y = act(x); dx = dy * act'(x); quick 0 = nn.GELU (erf), 1 = x*sigmoid(1.702x) */
+int cs_gelu_fwd(const void* x, long ldx, void* y, long ldy, int M, int N, int quick, cs_stream_t stream);
+int cs_gelu_bwd(const void* dy, long lddy, const void* x, long ldx, void* dx, long lddx, int M, int N, int quick, cs_stream_t stream);
 
 /* --- data movement helpers of the step */
 int cs_cast_f32_bf16(const float* x, void* y, long n, cs_stream_t stream);

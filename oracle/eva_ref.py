@@ -227,13 +227,23 @@ def split_valid(normed_boxes, image_crops):
     return rois_list, torch.cat(crops_list)
 
 
+def _tower(cfg):
+    """The module restating cfg's tower family: this one (EVA02) or oracle/clip_vit_ref.py (OpenAI-CLIP ViT)."""
+    if getattr(cfg, "arch", "eva02") == "openai":
+        from . import clip_vit_ref
+        return clip_vit_ref
+    import sys
+    return sys.modules[__name__]
+
+
 def clipself_loss(student_sd, teacher_sd, cfg, batch, cosine_weight=1.0, emulate_bf16=False):
     """CLIPSelf.__call__ (clipself.py:7-49) -> (loss, student_roi, teacher_feats)."""
     images, normed_boxes, image_crops = batch
     rois_list, crops = split_valid(normed_boxes, image_crops)
+    tower = _tower(cfg)
     with torch.no_grad():
-        teacher = encode_image(teacher_sd, cfg, crops, emulate_bf16)
-    student = encode_pseudo_boxes(student_sd, cfg, images, rois_list, emulate_bf16)
+        teacher = tower.encode_image(teacher_sd, cfg, crops, emulate_bf16)
+    student = tower.encode_pseudo_boxes(student_sd, cfg, images, rois_list, emulate_bf16)
     ns = F.normalize(student, dim=-1)
     nt = F.normalize(teacher, dim=-1)
     loss = (1.0 - (ns * nt).sum(-1).mean()) * cosine_weight
@@ -286,7 +296,7 @@ def train_steps(student_sd, teacher_sd, cfg, batches, lr=1e-5, wd=0.1, warmup=10
     unlocked_groups = cfg.layers if unlocked_groups is None else unlocked_groups
     if "logit_scale" not in student_sd:
         student_sd["logit_scale"] = torch.ones([]) * math.log(1 / 0.07)
-    names = trainable_names(student_sd, cfg, unlocked_groups)
+    names = _tower(cfg).trainable_names(student_sd, cfg, unlocked_groups)
     for n in student_sd:
         student_sd[n].requires_grad_(n in names)
     opt = make_optimizer({n: student_sd[n] for n in names}, lr, wd)

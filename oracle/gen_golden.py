@@ -34,7 +34,7 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
-from clipself_amd.config import tiny_cfg, tiny14_cfg, get_tower_cfg          # noqa: E402
+from clipself_amd.config import tiny_cfg, tiny14_cfg, tiny_openai_cfg, get_tower_cfg          # noqa: E402
 from clipself_amd.init import seeded_visual_state, synthetic_batch  # noqa: E402
 from oracle.ref_import import import_reference                   # noqa: E402
 
@@ -84,12 +84,28 @@ def _optimizer(model, lr, wd):
     return opt, groups
 
 
-def _run_steps(oc, cfg, rec, image_size, crop_size):
+def _build_openai(oc, cfg, seed):
+    """open_clip.create_model(name, '') -> model.CLIP with the OpenAI-style VisionTransformer (src/open_clip/factory.py:163-205)."""
+    from open_clip import factory
+    factory._MODEL_CONFIGS[cfg.name] = {
+        "embed_dim": cfg.embed_dim, "quick_gelu": cfg.quick_gelu,
+        "vision_cfg": {"image_size": cfg.image_size, "layers": cfg.layers, "width": cfg.width, "patch_size": cfg.patch_size},
+        "text_cfg": {"context_length": cfg.text_context, "vocab_size": cfg.text_vocab, "width": cfg.text_width, "heads": cfg.text_heads,
+                     "layers": cfg.text_layers}}
+    model = oc.create_model(cfg.name, "", device="cpu", precision="fp32")
+    res = model.load_state_dict(seeded_visual_state(cfg, seed), strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert not any(k.startswith("visual.") for k in res.missing_keys), res.missing_keys
+    return model
+
+
+def _run_steps(oc, cfg, rec, image_size, crop_size, build=None):
     from training.clipself import CLIPSelf
     from training.scheduler import cosine_lr
-    student = _build(oc, cfg, rec["seed_w"])
-    teacher = _build(oc, cfg, rec["seed_w"])          # main.py:150-157 loads the same checkpoint
-    student.lock_image_tower(unlocked_groups=cfg.layers)
+    build = build or _build
+    student = build(oc, cfg, rec["seed_w"])
+    teacher = build(oc, cfg, rec["seed_w"])          # main.py:150-157 loads the same checkpoint
+    student.lock_image_tower(unlocked_groups=rec.get("unlocked", cfg.layers))
     student.train()
     teacher.eval()
     opt, groups = _optimizer(student, rec["lr"], rec["wd"])
@@ -171,6 +187,39 @@ def gen_tiny14(oc):
     blob["recipe"] = np.array(json.dumps(rec))
     np.savez_compressed(GOLD / "tiny14_step.npz", **blob)
     print("tiny14 losses", out["losses"])
+
+
+def gen_tiny_openai(oc):
+    """OpenAI-CLIP ViT family: the CLIPSelf step through model.CLIP / transformer.VisionTransformer, GELU and
+    QuickGELU variants, plus a non-native grid (positional-embedding rescale)."""
+    blob = {}
+    for tag, quick, steps in (("", False, 3), ("q/", True, 1)):
+        cfg = tiny_openai_cfg(quick)
+        rec = dict(TINY, seed_w=3, seed_b=21, steps=steps, unlocked=cfg.layers)
+        student, teacher, out, first, groups = _run_steps(oc, cfg, rec, cfg.image_size, cfg.image_size, build=_build_openai)
+        blob.update({tag + "losses": np.array(out["losses"], np.float64), tag + "lrs": np.array(out["lrs"], np.float64),
+                     tag + "teacher": first["teacher"].numpy(), tag + "student_roi": first["student_roi"].numpy(),
+                     tag + "dense": first["dense"].numpy()})
+        none = []
+        for n, g in first["grads"].items():
+            if g is None:
+                none.append(n)
+            elif not quick or n.endswith(("mlp.c_fc.weight", "ln_1.weight")):
+                blob[tag + "grad/" + n] = g.numpy()
+        blob[tag + "grad_none"] = np.array(none)
+        if not quick:
+            for n, p in student.named_parameters():
+                if n.startswith("visual.") and p.requires_grad:
+                    blob["final/" + n] = p.detach().numpy()
+            blob["frozen"] = np.array([n for n, p in student.named_parameters() if n.startswith("visual.") and not p.requires_grad])
+            fresh = _build_openai(oc, cfg, rec["seed_w"])
+            fresh.eval()
+            im, bx, _ = synthetic_batch(2, 3, 64, cfg.image_size, seed=78)
+            with torch.no_grad():
+                blob["roi64"] = fresh.encode_pseudo_boxes(im, [b[:, :4] for b in bx], normalize=False, extract_type="v2").numpy()
+            blob["recipe"] = np.array(json.dumps(rec))
+        print("tiny openai", "quick" if quick else "gelu", "losses", out["losses"], "grad_none", none)
+    np.savez_compressed(GOLD / "tiny_openai_step.npz", **blob)
 
 
 def regionclip_inputs(cfg, n_nouns=150, batch=5, boxes=24, seed=31):
@@ -327,6 +376,9 @@ def main():
     if "--zeroshot-only" in sys.argv:
         gen_zeroshot(oc)
         return
+    if "--openai-only" in sys.argv:
+        gen_tiny_openai(oc)
+        return
     if "--params-only" in sys.argv:
         gen_params(oc)
         gen_schedules(oc)
@@ -334,6 +386,7 @@ def main():
     gen_tiny(oc)
     gen_tiny14(oc)
     gen_regionclip(oc)
+    gen_tiny_openai(oc)
     gen_zeroshot(oc)
     gen_params(oc)
     gen_schedules(oc)

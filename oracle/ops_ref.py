@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from .roi_align_ref import roi_align_1x1
 
-EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32, EPI_RESID_LN_F32 = range(7)
+EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32, EPI_RESID_LN_F32, EPI_GELU_BF16, EPI_QGELU_BF16 = range(9)
 DX_BF16, DX_F32_ASSIGN, DX_F32_ACCUM = range(3)
 
 
@@ -36,6 +36,11 @@ def _rope_rows(t, cos, sin, inverse=False):
         y1 = x1 * c[..., 1] - x0 * s[..., 0]
     out = torch.stack((y0, y1), dim=-1).flatten(-2)
     return torch.cat((t[..., :1, :], out), dim=-2)
+
+
+def _act(x, quick):
+    """MLP activation of the OpenAI-CLIP ViT: nn.GELU (erf) or QuickGELU (open_clip/transformer.py:31-34,211)."""
+    return x * torch.sigmoid(1.702 * x) if quick else F.gelu(x)
 
 
 class RefOps:
@@ -60,6 +65,8 @@ class RefOps:
             acc = acc + bias
         if epi == EPI_BF16:
             C.copy_(acc.to(torch.bfloat16))
+        elif epi in (EPI_GELU_BF16, EPI_QGELU_BF16):
+            C.copy_(_act(acc, epi == EPI_QGELU_BF16).to(torch.bfloat16))
         elif epi == EPI_F32:
             C.copy_(acc)
         elif epi == EPI_RESID_F32:
@@ -94,6 +101,9 @@ class RefOps:
             return
         if epi == EPI_BF16:
             C.copy_(acc.to(torch.bfloat16))
+            return
+        if epi in (EPI_GELU_BF16, EPI_QGELU_BF16):
+            C.copy_(_act(acc, epi == EPI_QGELU_BF16).to(torch.bfloat16))
             return
         assert epi == EPI_SWIGLU_BF16
         x1, x2 = acc[:, :group], acc[:, group:]
@@ -134,6 +144,24 @@ class RefOps:
         o = out[:, :H * 64].float().reshape(B * Ntok, H, 64)
         stats_part[:, :, 0] = o.sum(-1).T
         stats_part[:, :, 1] = (o * o).sum(-1).T
+
+    def gelu_fwd(self, x, y, quick=False):
+        y.copy_(_act(x.float(), quick).to(y.dtype))
+
+    def gelu_bwd(self, dy, x, dx, quick=False):
+        with torch.enable_grad():                                  # autograd is the derivative oracle (also when called inside a backward)
+            xf = x.float().detach().requires_grad_(True)
+            (g,) = torch.autograd.grad(_act(xf, quick), xf, dy.float())
+        dx.copy_(g.to(dx.dtype))
+
+    def layernorm_fwd_f32(self, x, gamma, beta, y, mean=None, rstd=None, eps=1e-5):
+        mu = x.mean(-1, keepdim=True)
+        var = ((x - mu) ** 2).mean(-1, keepdim=True)
+        r = torch.rsqrt(var + eps)
+        y.copy_((x - mu) * r * gamma + beta)
+        if mean is not None:
+            mean.copy_(mu[:, 0])
+            rstd.copy_(r[:, 0])
 
     def layernorm_fwd(self, x, gamma, beta, y, mean=None, rstd=None, eps=1e-6):
         xf = x.float()

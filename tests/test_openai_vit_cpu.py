@@ -1,0 +1,235 @@
+"""CPU: the OpenAI-CLIP ViT family on the CLIPSelf hot path.
+
+(1) pins the restatement oracle/clip_vit_ref.py against vectors captured from the real reference (model.CLIP +
+    transformer.VisionTransformer; tests/golden/tiny_openai_step.npz, made by `python -m oracle.gen_golden --openai-only`);
+(2) drives the engine schedule clipself_amd/engine_openai.py -- forward decomposition and hand-written backward -- with the per-kernel
+    references (oracle/ops_ref.py) and checks it against the same vectors;
+(3) the reference-compatible API: state-dict keys at the reference's names, lock semantics, factory dispatch, the method's step."""
+import json
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from clipself_amd.config import get_tower_cfg, tiny_openai_cfg
+from clipself_amd.engine_openai import ClipVitEngine
+from clipself_amd.init import seeded_visual_state, synthetic_batch
+from oracle import clip_vit_ref, eva_ref
+from oracle.ops_ref import RefOps
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def one_minus_cos(a, b):
+    return float((1 - torch.nn.functional.cosine_similarity(torch.as_tensor(a).double(), torch.as_tensor(b).double(), dim=-1)).max())
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    g = np.load(golden_dir / "tiny_openai_step.npz")
+    return g, json.loads(str(g["recipe"]))
+
+
+def _batches(cfg, rec, n):
+    return [synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"] + s) for s in range(n)]
+
+
+def _rois(boxes):
+    return torch.cat([torch.cat([torch.full((len(b), 1), float(i)), b[:, :4]], dim=1) for i, b in enumerate(boxes)])
+
+
+def _engine(cfg, seed, trainable):
+    eng = ClipVitEngine(cfg, RefOps(), trainable=trainable)
+    eng.load_state(seeded_visual_state(cfg, seed))
+    if trainable:
+        eng.set_trainable_blocks(cfg.layers)
+    return eng
+
+
+# ------------------------------------------------------------------------------------------------ (1) oracle vs the reference
+@pytest.mark.parametrize("quick", [False, True])
+def test_oracle_forward_matches_reference(gold, quick):
+    g, rec = gold
+    cfg, tag = tiny_openai_cfg(quick), "q/" if quick else ""
+    sd = seeded_visual_state(cfg, rec["seed_w"])
+    batch = _batches(cfg, rec, 1)[0]
+    with torch.no_grad():
+        loss, student, teacher = eva_ref.clipself_loss(sd, sd, cfg, batch)
+        dense, _ = clip_vit_ref.encode_dense(sd, cfg, batch[0])
+    assert rel(teacher, g[tag + "teacher"]) < 2e-6 and rel(student, g[tag + "student_roi"]) < 2e-6 and rel(dense, g[tag + "dense"]) < 2e-6
+    assert abs(float(loss) - g[tag + "losses"][0]) < 2e-6
+    if quick:                                              # the two activations are different functions of the same weights
+        assert rel(g["q/teacher"], g["teacher"]) > 1e-4
+
+
+def test_oracle_rescaled_grid_matches_reference(gold):
+    g, rec = gold
+    cfg = tiny_openai_cfg()
+    sd = seeded_visual_state(cfg, rec["seed_w"])
+    im, bx, _ = synthetic_batch(2, 3, 64, cfg.image_size, seed=78)
+    with torch.no_grad():
+        roi = clip_vit_ref.encode_pseudo_boxes(sd, cfg, im, [b[:, :4] for b in bx])
+    assert rel(roi, g["roi64"]) < 2e-6
+
+
+def test_oracle_three_steps_grads_and_adamw(gold):
+    g, rec = gold
+    cfg = tiny_openai_cfg()
+    student, teacher = seeded_visual_state(cfg, rec["seed_w"]), seeded_visual_state(cfg, rec["seed_w"])
+    batches = _batches(cfg, rec, rec["steps"])
+    kw = dict(lr=rec["lr"], wd=rec["wd"], warmup=rec["warmup"], total_steps=rec["total"], unlocked_groups=rec["unlocked"])
+    _, grads = eva_ref.train_steps({k: v.clone() for k, v in student.items()}, teacher, cfg, batches[:1], **kw)
+    assert sorted(n for n, v in grads.items() if v is None) == sorted(str(x) for x in g["grad_none"])
+    for n, v in grads.items():
+        if v is not None:
+            assert rel(v, g["grad/" + n]) < 1e-4, n
+    # the last block runs without attention: the q and k rows of its single in_proj parameter get an exactly zero gradient ...
+    C, last = cfg.width, f"visual.transformer.resblocks.{cfg.layers - 1}.attn."
+    assert float(np.abs(g["grad/" + last + "in_proj_weight"][:2 * C]).max()) == 0.0 and float(np.abs(g["grad/" + last + "in_proj_bias"][:2 * C]).max()) == 0.0
+    log, _ = eva_ref.train_steps(student, teacher, cfg, batches, **kw)
+    assert np.allclose([l["loss"] for l in log], g["losses"], atol=5e-6) and np.allclose([l["lr"] for l in log], g["lrs"], rtol=1e-12)
+    for k in g.files:
+        if k.startswith("final/"):
+            assert rel(student[k[6:]].detach(), g[k]) < 1e-3, k
+    # ... yet they are decayed by AdamW (the parameter has a gradient tensor), unlike EVA02's separate q/k tensors
+    w0 = seeded_visual_state(cfg, rec["seed_w"])[last + "in_proj_weight"][:2 * C]
+    shrink = torch.as_tensor(g["final/" + last + "in_proj_weight"][:2 * C]) / w0
+    expect = np.prod([1 - lr * rec["wd"] for lr in g["lrs"]])
+    assert torch.allclose(shrink, torch.full_like(shrink, float(expect)), rtol=1e-5)
+    frozen = {str(x) for x in g["frozen"]}
+    assert frozen == {"visual.class_embedding", "visual.positional_embedding", "visual.proj", "visual.conv1.weight", "visual.ln_pre.weight",
+                      "visual.ln_pre.bias", "visual.ln_post.weight", "visual.ln_post.bias"}
+
+
+# ------------------------------------------------------------------------------------------------ (2) engine schedule
+@pytest.mark.parametrize("quick", [False, True])
+def test_engine_forward_matches_bf16_oracle_and_reference(gold, quick):
+    g, rec = gold
+    cfg, tag = tiny_openai_cfg(quick), "q/" if quick else ""
+    sd = seeded_visual_state(cfg, rec["seed_w"])
+    images, boxes, crops = _batches(cfg, rec, 1)[0]
+    eng = _engine(cfg, rec["seed_w"], False)
+    teacher = eng.encode_image(crops.flatten(0, 1), chunk=4)
+    dense, grid = eng.encode_dense(images)
+    pooled = eng.roi_pool(dense, _rois(boxes), grid)
+    with torch.no_grad():
+        t_bf = clip_vit_ref.encode_image(sd, cfg, crops.flatten(0, 1), emulate_bf16=True)
+        s_bf = clip_vit_ref.encode_pseudo_boxes(sd, cfg, images, [b[:, :4] for b in boxes], emulate_bf16=True)
+    assert rel(teacher, t_bf) < 1.5e-2 and rel(pooled, s_bf) < 1.5e-2
+    assert rel(teacher, g[tag + "teacher"]) < 2e-2 and rel(pooled, g[tag + "student_roi"]) < 2e-2 and rel(dense[:, 1:], g[tag + "dense"]) < 2e-2
+    assert one_minus_cos(teacher, g[tag + "teacher"]) < 2e-4 and one_minus_cos(pooled, g[tag + "student_roi"]) < 2e-4
+
+
+def test_engine_rescaled_grid(gold):
+    g, rec = gold
+    cfg = tiny_openai_cfg()
+    im, bx, _ = synthetic_batch(2, 3, 64, cfg.image_size, seed=78)
+    eng = _engine(cfg, rec["seed_w"], False)
+    dense, grid = eng.encode_dense(im)
+    assert grid == 8
+    pooled = eng.roi_pool(dense, _rois(bx), grid)
+    assert rel(pooled, g["roi64"]) < 2e-2 and one_minus_cos(pooled, g["roi64"]) < 2e-4
+
+
+@pytest.mark.parametrize("quick", [False, True])
+def test_engine_backward_chain_is_the_gradient(gold, quick):
+    g, rec = gold
+    cfg, tag = tiny_openai_cfg(quick), "q/" if quick else ""
+    images, boxes, _ = _batches(cfg, rec, 1)[0]
+    eng = _engine(cfg, rec["seed_w"], True)
+    ops, rois = eng.ops, _rois(boxes)
+    dense, grid = eng.encode_dense(images, need_grad=True)
+    pooled = eng.roi_pool(dense, rois, grid)
+    teacher = torch.from_numpy(g[tag + "teacher"])
+    K, E = pooled.shape
+    stats, loss, dpool = torch.empty(K, 3), torch.empty(1), torch.empty(K, E)
+    ops.cosine_loss_fwd(pooled, teacher, stats, loss, 1.0)
+    ops.cosine_loss_bwd(pooled, teacher, stats, dpool, 1.0, 1.0)
+    eng.zero_grad()
+    fired = []
+    eng.grad_ready_hook = fired.append
+    eng.backward_dense(eng.roi_pool_backward(dpool, rois, images.shape[0], dense.shape[1], grid))
+    assert fired == list(range(cfg.layers - 1, -1, -1))
+    assert abs(float(loss) - g[tag + "losses"][0]) < 5e-3
+    checked = 0
+    for name in eng.trainable_names():
+        if tag + "grad/" + name not in g.files:
+            continue
+        r = rel(eng.g[name], g[tag + "grad/" + name])
+        assert r < 6e-2, f"{name}: rel {r:.3e}"
+        checked += 1
+    assert checked == (2 * cfg.layers if quick else 12 * cfg.layers)
+    C = cfg.width
+    assert float(eng.g[f"visual.transformer.resblocks.{cfg.layers - 1}.attn.in_proj_weight"][:2 * C].abs().max()) == 0.0
+
+
+def test_engine_three_steps_track_reference(gold):
+    g, rec = gold
+    cfg = tiny_openai_cfg()
+    eng, teacher_eng = _engine(cfg, rec["seed_w"], True), _engine(cfg, rec["seed_w"], False)
+    ops, losses = eng.ops, []
+    for step, (images, boxes, crops) in enumerate(_batches(cfg, rec, rec["steps"])):
+        rois = _rois(boxes)
+        teacher = teacher_eng.encode_image(crops.flatten(0, 1))
+        dense, grid = eng.encode_dense(images, need_grad=True)
+        pooled = eng.roi_pool(dense, rois, grid)
+        K, E = pooled.shape
+        stats, loss, dpool = torch.empty(K, 3), torch.empty(1), torch.empty(K, E)
+        ops.cosine_loss_fwd(pooled, teacher, stats, loss, 1.0)
+        ops.cosine_loss_bwd(pooled, teacher, stats, dpool, 1.0, 1.0)
+        eng.zero_grad()
+        eng.backward_dense(eng.roi_pool_backward(dpool, rois, images.shape[0], dense.shape[1], grid))
+        eng.adamw_step(step + 1, eva_ref.cosine_lr_value(step, rec["lr"], rec["warmup"], rec["total"]), rec["wd"])
+        losses.append(float(loss))
+    assert np.allclose(losses, g["losses"], atol=1e-2), (losses, g["losses"])
+    sd0 = seeded_visual_state(cfg, rec["seed_w"])
+    for n in ("visual.proj", "visual.positional_embedding", "visual.ln_post.weight", "visual.conv1.weight"):
+        assert torch.equal(eng.p[n], sd0[n].reshape(eng.p[n].shape)), n
+    last = f"visual.transformer.resblocks.{cfg.layers - 1}.attn.in_proj_weight"
+    assert rel(eng.p[last], g["final/" + last]) < 2e-2                      # includes the decayed-but-gradient-free q/k rows
+    assert rel(eng.p["visual.transformer.resblocks.0.mlp.c_fc.weight"], g["final/visual.transformer.resblocks.0.mlp.c_fc.weight"]) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ (3) API
+def test_api_state_dict_lock_and_method_step(gold):
+    from clipself_amd.open_clip import CLIP, create_model
+    from clipself_amd.training.clipself import CLIPSelf
+    g, rec = gold
+    cfg = tiny_openai_cfg()
+    student, teacher = CLIP(cfg, ops=RefOps(), trainable=True), CLIP(cfg, ops=RefOps(), trainable=False)
+    for m in (student, teacher):
+        m.visual.engine.load_state(seeded_visual_state(cfg, rec["seed_w"]))
+    keys = set(student.state_dict())
+    assert {"logit_scale", "positional_embedding", "text_projection", "token_embedding.weight", "ln_final.weight",
+            "transformer.resblocks.0.attn.in_proj_weight", "visual.class_embedding", "visual.positional_embedding", "visual.proj",
+            "visual.conv1.weight", "visual.ln_pre.weight", "visual.transformer.resblocks.1.mlp.c_proj.bias", "visual.ln_post.bias"} <= keys
+    assert "attn_mask" not in keys and not any(k.startswith("text.") for k in keys)
+    assert tuple(student.state_dict()["visual.conv1.weight"].shape) == (cfg.width, 3, cfg.patch_size, cfg.patch_size)
+    res = CLIP(cfg, ops=RefOps(), trainable=False).load_state_dict(student.state_dict())
+    assert not res.missing_keys and not res.unexpected_keys
+
+    student.lock_image_tower(unlocked_groups=0)            # transformer.py:395: 0 groups = everything frozen (EVA02 differs)
+    assert not any(p.requires_grad for n, p in student.named_parameters() if n.startswith("visual."))
+    student.lock_image_tower(unlocked_groups=1)
+    assert {n for n, p in student.named_parameters() if p.requires_grad and n.startswith("visual.")} == \
+        {n for n in keys if n.startswith(f"visual.transformer.resblocks.{cfg.layers - 1}.")}
+    with pytest.raises(NotImplementedError):
+        student.lock_image_tower(unlocked_groups=cfg.layers + 1)
+    student.lock_image_tower(unlocked_groups=cfg.layers)
+    student.train()
+
+    batch = _batches(cfg, rec, 1)[0]
+    args = SimpleNamespace(multiscale=False, extract_type="v2", cosine_weight=1.0)
+    losses, bs, scale = CLIPSelf()(batch, student, teacher, None, "cpu", None, False, args)
+    assert bs == rec["batch"] and abs(float(losses["loss_cosine"].detach()) - g["losses"][0]) < 5e-3
+    sum(losses.values()).backward()
+    name = "visual.transformer.resblocks.0.mlp.c_fc.weight"
+    assert rel(dict(student.named_parameters())[name].grad, g["grad/" + name]) < 6e-2
+
+    with pytest.raises(RuntimeError):
+        create_model("ViT-tiny-unknown", "", ops=RefOps())
+    assert get_tower_cfg("ViT-B/16").arch == "openai" and get_tower_cfg("ViT-L-14-336").tokens == 577
