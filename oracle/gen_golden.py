@@ -222,6 +222,32 @@ def gen_tiny_openai(oc):
     np.savez_compressed(GOLD / "tiny_openai_step.npz", **blob)
 
 
+def gen_vitb16(oc):
+    """OpenAI-CLIP ViT-B/16 at BASELINE cfg-1 size (2 images x 8 boxes, 224^2), nn.GELU variant (`--pretrained ''` path of the factory):
+    loss trajectory, feature slices, every gradient norm."""
+    cfg = get_tower_cfg("ViT-B-16")
+    rec = dict(B16, seed_w=5, seed_b=4321, steps=2, unlocked=cfg.layers)
+    student, teacher, out, first, groups = _run_steps(oc, cfg, rec, 224, 224, build=_build_openai)
+    names, norms, none = [], [], []
+    for n, g in first["grads"].items():
+        if g is None:
+            none.append(n)
+        else:
+            names.append(n)
+            norms.append(float(g.double().norm()))
+    blob = {"losses": np.array(out["losses"], np.float64), "lrs": np.array(out["lrs"], np.float64),
+            "teacher_slice": first["teacher"][:4, :16].numpy(), "student_roi_slice": first["student_roi"][:4, :16].numpy(),
+            "teacher_rownorm": first["teacher"].norm(dim=-1).numpy(), "student_rownorm": first["student_roi"].norm(dim=-1).numpy(),
+            "cos": torch.nn.functional.cosine_similarity(first["teacher"], first["student_roi"], dim=-1).numpy(),
+            "grad_names": np.array(names), "grad_norms": np.array(norms, np.float64), "grad_none": np.array(none),
+            "recipe": np.array(json.dumps(rec))}
+    for n in ("visual.transformer.resblocks.11.mlp.c_proj.bias", "visual.transformer.resblocks.0.ln_1.weight",
+              "visual.transformer.resblocks.5.attn.in_proj_bias", "visual.transformer.resblocks.11.attn.in_proj_bias"):
+        blob["grad/" + n] = first["grads"][n].numpy()
+    np.savez_compressed(GOLD / "vitb16_cfg1.npz", **blob)
+    print("vit-b/16 losses", out["losses"], "grad_none", none)
+
+
 def regionclip_inputs(cfg, n_nouns=150, batch=5, boxes=24, seed=31):
     """Seeded RegionCLIP batch: (images, boxes [B,k,6] = xyxy, label, valid) with >= 100 distinct labels so that the
     federated column set is deterministic (no multinomial draw), and a seeded noun-embedding bank."""
@@ -378,6 +404,8 @@ def main():
         return
     if "--openai-only" in sys.argv:
         gen_tiny_openai(oc)
+        if "--tiny-only" not in sys.argv:
+            gen_vitb16(oc)
         return
     if "--params-only" in sys.argv:
         gen_params(oc)
@@ -392,6 +420,7 @@ def main():
     gen_schedules(oc)
     if "--tiny-only" not in sys.argv:
         gen_b16(oc)
+        gen_vitb16(oc)
 
 
 if __name__ == "__main__":

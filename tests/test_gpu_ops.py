@@ -579,3 +579,74 @@ def test_fed_bce(hip, ref):
     check("fed_bce.loss", l_d, l_r, 1e-5)
     check("fed_bce.dz", dz_d, dz_r, TOL_BF)
     assert float(dz_d[:, ns:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ OpenAI-CLIP ViT family (N4)
+@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x50, 0x70, 0x80, 0x90])
+@pytest.mark.parametrize("quick", [False, True])
+@pytest.mark.parametrize("M,N,K", [(394, 3072, 768), (130, 512, 128), (1000, 4096, 1024)])
+def test_gemm_gelu_epilogues(hip, ref, M, N, K, quick, flags):
+    """c_fc + bias + GELU / QuickGELU fused into the GEMM epilogue (epi 7 / 8) on every schedule."""
+    epi = 8 if quick else 7
+    A, B, bias = rnd((M, K), BF, 1.5, seed=61), rnd((N, K), BF, 0.05, seed=62), rnd((N,), F32, seed=63)
+    Cr = torch.empty(M, N, dtype=BF)
+    ref.gemm_nt(A, B, Cr, bias, epi=epi)
+    assert float((Cr.float() < 0).float().mean()) > 0.2          # both signs: the non-linear part of the activation is exercised
+    Cd = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+    hip.gemm_nt(A.cuda(), B.cuda(), Cd, bias.cuda(), epi=epi, flags=flags)
+    check(f"gemm_gelu[{M},{N},{K}] quick={quick} flags={flags}", Cd, Cr, TOL_BF)
+
+
+@pytest.mark.parametrize("quick", [False, True])
+def test_gemm_gelu_with_folded_layernorm(hip, ref, quick):
+    """epi 7 / 8 through cs_gemm_nt_ln: the LayerNorm in front of c_fc applied in the epilogue, then the activation."""
+    M, N, K, epi = 394, 3072, 768, 8 if quick else 7
+    X = rnd((M, K), F32, 2.0, seed=64) + 0.5
+    gamma, beta = 1 + 0.1 * rnd((K,), F32, seed=65), 0.1 * rnd((K,), F32, seed=66)
+    W, b = rnd((N, K), F32, 0.05, seed=67), rnd((N,), F32, 0.1, seed=68)
+    mean, var = X.mean(-1), X.var(-1, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    Xb, Wf = X.to(BF), (W * gamma[None, :]).to(BF)
+    colsum, bias = Wf.float().sum(1).contiguous(), (W @ beta + b).contiguous()
+    Cr = torch.empty(M, N, dtype=BF)
+    ref.gemm_nt_ln(Xb, Wf, Cr, bias=bias, ln_mean=mean, ln_rstd=rstd, ln_colsum=colsum, epi=epi)
+    plain = torch.empty(M, N, dtype=BF)                           # the unfolded computation it replaces
+    ln = torch.nn.functional.layer_norm(X, (K,), gamma, beta, 1e-5).to(BF)
+    ref.gemm_nt(ln, W.to(BF), plain, b, epi=epi)
+    assert rel(Cr, plain) < 2e-2
+    Cd = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+    hip.gemm_nt_ln(Xb.cuda(), Wf.cuda(), Cd, bias=bias.cuda(), ln_mean=mean.cuda(), ln_rstd=rstd.cuda(), ln_colsum=colsum.cuda(), epi=epi)
+    check(f"gemm_gelu_lnfold quick={quick}", Cd, Cr, TOL_BF)
+
+
+@pytest.mark.parametrize("quick", [False, True])
+def test_gelu_fwd_bwd(hip, ref, quick):
+    M, N = 394, 3072
+    xbig = rnd((M, N + 64), BF, 2.0, seed=70)
+    x, dy = xbig[:, :N], rnd((M, N), BF, seed=71)                  # strided input rows
+    yr, dxr = torch.empty(M, N, dtype=BF), torch.empty(M, N, dtype=BF)
+    ref.gelu_fwd(x, yr, quick)
+    ref.gelu_bwd(dy, x, dxr, quick)
+    xd = xbig.cuda()[:, :N]
+    yd, dxd = torch.full((M, N), float("nan"), dtype=BF, device="cuda"), torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+    hip.gelu_fwd(xd, yd, quick)
+    hip.gelu_bwd(dy.cuda(), xd, dxd, quick)
+    check(f"gelu_fwd quick={quick}", yd, yr, TOL_BF)
+    check(f"gelu_bwd quick={quick}", dxd, dxr, TOL_BF)
+
+
+@pytest.mark.parametrize("C", [128, 768, 1024, 1280])
+def test_layernorm_fwd_f32_out(hip, ref, C):
+    M = 395
+    x = rnd((M, C), F32, 3.0, seed=72) + 1.0
+    gamma, beta = 1 + 0.1 * rnd((C,), F32, seed=73), 0.1 * rnd((C,), F32, seed=74)
+    yr, mr, rr = torch.empty(M, C), torch.empty(M), torch.empty(M)
+    ref.layernorm_fwd_f32(x, gamma, beta, yr, mr, rr, 1e-5)
+    yd, md, rd = torch.full((M, C), float("nan"), device="cuda"), torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    hip.layernorm_fwd_f32(x.cuda(), gamma.cuda(), beta.cuda(), yd, md, rd, 1e-5)
+    check(f"layernorm_f32[{C}] y", yd, yr, TOL_F32)
+    check(f"layernorm_f32[{C}] mean", md, mr, TOL_F32)
+    check(f"layernorm_f32[{C}] rstd", rd, rr, TOL_F32)
+    y2 = torch.full((M, C), float("nan"), device="cuda")
+    hip.layernorm_fwd_f32(x.cuda(), gamma.cuda(), beta.cuda(), y2, None, None, 1e-5)
+    assert torch.equal(y2, yd)

@@ -445,3 +445,152 @@ def test_ragged_batch_with_an_image_without_valid_boxes_matches_oracle():
     assert bs == 4 and abs(got - float(want)) < 2e-3 * abs(float(want))
     for n in ("visual.blocks.0.mlp.w3.weight", "visual.blocks.1.attn.v_bias", "visual.blocks.0.norm1.weight"):
         assert rel(dict(student.named_parameters())[n].grad, leaves[n].grad) < 6e-2, n
+
+
+# ------------------------------------------------------------------------------------------------ OpenAI-CLIP ViT family (N4)
+def _pair_openai(cfg, seed):
+    from clipself_amd.open_clip.model import CLIP
+    student, teacher = CLIP(cfg, trainable=True), CLIP(cfg, trainable=False)
+    for m in (student, teacher):
+        m.visual.engine.load_state(seeded_visual_state(cfg, seed))
+    student.lock_image_tower(unlocked_groups=cfg.layers)
+    student.train()
+    teacher.eval()
+    return student, teacher
+
+
+@pytest.mark.parametrize("quick", [False, True])
+def test_tiny_openai_vit_step_matches_reference_goldens(golden_dir, quick):
+    """model.CLIP / transformer.VisionTransformer of the reference (GELU and QuickGELU): features, every gradient, 3-step trajectory."""
+    from clipself_amd.config import tiny_openai_cfg
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.scheduler import cosine_lr
+    from clipself_amd.training.train import train_step
+    g = np.load(golden_dir / "tiny_openai_step.npz")
+    rec, tag = json.loads(str(g["recipe"])), "q/" if quick else ""
+    cfg = tiny_openai_cfg(quick)
+    student, teacher = _pair_openai(cfg, rec["seed_w"])
+    assert type(student.visual.engine.ops).__name__ == "HipOps" and type(student.visual.engine).__name__ == "ClipVitEngine"
+    images, boxes, crops = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"])
+    with torch.no_grad():
+        t = teacher.encode_image(crops.flatten(0, 1).cuda())
+        s = student.encode_pseudo_boxes(images.cuda(), [b[:, :4].cuda() for b in boxes])
+        d = student.encode_dense(images.cuda(), keep_shape=False)
+    _log(f"tiny-openai quick={quick} teacher rel={rel(t, g[tag + 'teacher']):.3e} 1-cos={one_minus_cos(t, g[tag + 'teacher']):.2e}; "
+         f"roi rel={rel(s, g[tag + 'student_roi']):.3e} 1-cos={one_minus_cos(s, g[tag + 'student_roi']):.2e}; dense rel={rel(d, g[tag + 'dense']):.3e}")
+    assert rel(t, g[tag + "teacher"]) < 2e-2 and one_minus_cos(t, g[tag + "teacher"]) < 1e-3
+    assert rel(s, g[tag + "student_roi"]) < 2e-2 and one_minus_cos(s, g[tag + "student_roi"]) < 1e-3
+    assert rel(d, g[tag + "dense"]) < 2e-2
+    if not quick:
+        im64, bx64, _ = synthetic_batch(2, 3, 64, cfg.image_size, seed=78)
+        with torch.no_grad():
+            r64 = student.encode_pseudo_boxes(im64.cuda(), [b[:, :4].cuda() for b in bx64])
+        assert rel(r64, g["roi64"]) < 2e-2                  # rescaled positional embedding (8x8 grid)
+    opt = FlatAdamW(student, lr=rec["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=rec["wd"])
+    sched = cosine_lr(opt, rec["lr"], rec["warmup"], rec["total"])
+    losses, steps = [], len(g[tag + "losses"])
+    for step in range(steps):
+        batch = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"] + step)
+        out, bs, _ = train_step(student, CLIPSelf(), batch, opt, sched, step, teacher, _args())
+        losses.append(float(out["loss"]))
+        if step == 0:
+            worst, checked = 0.0, 0
+            for n, p in student.named_parameters():
+                if not p.requires_grad or tag + "grad/" + n not in g.files:
+                    continue
+                r = rel(p.grad, g[tag + "grad/" + n])
+                worst, checked = max(worst, r), checked + 1
+                assert r < 6e-2, f"{n}: {r:.3e}"
+            assert checked == (2 if quick else 12) * cfg.layers
+            _log(f"tiny-openai quick={quick} worst grad rel={worst:.3e}")
+    _log(f"tiny-openai quick={quick} losses {losses} vs {g[tag + 'losses'].tolist()}")
+    assert np.allclose(losses, g[tag + "losses"], atol=1e-2)
+    if not quick:
+        last = f"visual.transformer.resblocks.{cfg.layers - 1}.attn.in_proj_weight"
+        w = dict(student.named_parameters())
+        assert rel(w[last], g["final/" + last]) < 2e-2       # q/k rows: zero gradient, still decayed
+        assert rel(w["visual.transformer.resblocks.0.mlp.c_fc.weight"], g["final/visual.transformer.resblocks.0.mlp.c_fc.weight"]) < 2e-2
+
+
+def test_vitb16_openai_cfg1_matches_reference_goldens(golden_dir):
+    """OpenAI-CLIP ViT-B/16, 2 images x 8 boxes, 224^2 through `create_model('ViT-B-16')`: loss within the north-star tolerance,
+    feature directions, every gradient norm of the real reference."""
+    from clipself_amd.open_clip import create_model
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.scheduler import cosine_lr
+    from clipself_amd.training.train import train_step
+    g = np.load(golden_dir / "vitb16_cfg1.npz")
+    rec = json.loads(str(g["recipe"]))
+    student, teacher = create_model("ViT-B-16", "", device="cuda"), create_model("ViT-B/16", "", device="cuda", trainable=False)
+    cfg = student.visual.cfg
+    assert cfg.arch == "openai" and not cfg.quick_gelu
+    for m in (student, teacher):
+        m.visual.engine.load_state(seeded_visual_state(cfg, rec["seed_w"]))
+    student.lock_image_tower(unlocked_groups=rec["unlocked"])
+    student.train()
+    teacher.eval()
+    opt = FlatAdamW(student, lr=rec["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=rec["wd"])
+    sched = cosine_lr(opt, rec["lr"], rec["warmup"], rec["total"])
+    losses = []
+    for step in range(rec["steps"]):
+        batch = synthetic_batch(rec["batch"], rec["boxes"], 224, 224, seed=rec["seed_b"] + step)
+        if step == 0:
+            with torch.no_grad():
+                t = teacher.encode_image(batch[2].flatten(0, 1).cuda())
+                s = student.encode_pseudo_boxes(batch[0].cuda(), [b[:, :4].cuda() for b in batch[1]])
+            cos = torch.nn.functional.cosine_similarity(t, s, dim=-1).cpu()
+            _log(f"vitb16 teacher_slice rel={rel(t[:4, :16], g['teacher_slice']):.3e} roi_slice rel={rel(s[:4, :16], g['student_roi_slice']):.3e} "
+                 f"cos maxabs={float((cos - torch.from_numpy(g['cos'])).abs().max()):.3e}")
+            assert rel(t[:4, :16], g["teacher_slice"]) < 3e-2 and rel(s[:4, :16], g["student_roi_slice"]) < 3e-2
+            assert rel(t.norm(dim=-1), g["teacher_rownorm"]) < 1e-2 and rel(s.norm(dim=-1), g["student_rownorm"]) < 1e-2
+            assert float((cos - torch.from_numpy(g["cos"])).abs().max()) < 5e-3
+        out, bs, _ = train_step(student, CLIPSelf(), batch, opt, sched, step, teacher, _args())
+        losses.append(float(out["loss"]))
+        if step == 0:
+            norms = dict(zip((str(x) for x in g["grad_names"]), g["grad_norms"]))
+            worst = ("", 0.0)
+            for n, p in student.named_parameters():
+                if not p.requires_grad or n == "logit_scale":
+                    continue
+                r = abs(float(p.grad.double().norm()) - norms[n]) / norms[n]
+                worst = max(worst, (n, r), key=lambda x: x[1])
+                assert r < 5e-2, f"{n}: grad-norm rel {r:.3e}"
+            for n in ("visual.transformer.resblocks.11.mlp.c_proj.bias", "visual.transformer.resblocks.0.ln_1.weight",
+                      "visual.transformer.resblocks.5.attn.in_proj_bias", "visual.transformer.resblocks.11.attn.in_proj_bias"):
+                r = rel(dict(student.named_parameters())[n].grad, g["grad/" + n])
+                _log(f"vitb16 grad {n} rel={r:.3e}")
+                assert r < 6e-2, n
+            _log(f"vitb16 worst grad-norm rel {worst}")
+    _log(f"vitb16 losses {losses} vs {g['losses'].tolist()}")
+    assert abs(losses[0] - g["losses"][0]) / g["losses"][0] < 1e-3
+    assert np.allclose(losses, g["losses"], rtol=2e-3)
+
+
+def test_training_main_entrypoint_openai_vit(tmp_path):
+    """`python -m clipself_amd.training.main --model ViT-B-16` (OpenAI-CLIP family, seeded weights): train, evaluate the alpha-ensemble,
+    checkpoint with the reference's `CLIP` state-dict names, reload."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, "-m", "clipself_amd.training.main", "--model", "ViT-B-16", "--train-data", "synthetic", "--dataset-type", "grid_distill",
+           "--batch-size", "2", "--max-boxes", "4", "--det-image-size", "224", "--synthetic-steps", "2", "--epochs", "1", "--lock-image",
+           "--lock-image-unlocked-groups", "6", "--alpha", "0.5", "--lr", "1e-5", "--wd", "0.1", "--warmup", "10", "--log-every-n-steps", "1",
+           "--logs", str(tmp_path), "--name", "vit", "--val-data", "synthetic", "--zeroshot-frequency", "1"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("Train Epoch: 0") == 2 and "Loss_cosine" in r.stderr and r.stderr.count("Eval Epoch:") == 2
+    assert "beta2: 0.98" in r.stderr and "eps: 1e-06" in r.stderr            # params.py:5-11: names containing "vit" get the CLIP-paper Adam values
+    blob = torch.load(tmp_path / "vit" / "checkpoints" / "epoch_1.pt", map_location="cpu", weights_only=False)
+    sd = blob["state_dict"]
+    assert {"visual.proj", "visual.class_embedding", "visual.transformer.resblocks.11.mlp.c_fc.weight", "token_embedding.weight",
+            "transformer.resblocks.0.attn.in_proj_weight", "logit_scale"} <= set(sd)
+    assert len(blob["optimizer"]["state"]) == 6 * 12                         # six unlocked blocks x 12 tensors
+    from clipself_amd.open_clip import create_model
+    m = create_model("ViT-B-16", str(tmp_path / "vit" / "checkpoints" / "epoch_1.pt"), trainable=False)
+    assert rel(m.state_dict()["visual.transformer.resblocks.9.attn.out_proj.weight"], sd["visual.transformer.resblocks.9.attn.out_proj.weight"]) == 0.0
+    # blocks 0..5 stayed frozen: the ensemble of equal tensors is the tensor itself
+    from clipself_amd.init import seeded_visual_state as seeded
+    assert rel(sd["visual.transformer.resblocks.2.mlp.c_proj.weight"], seeded(m.visual.cfg, 0)["visual.transformer.resblocks.2.mlp.c_proj.weight"]) < 1e-7

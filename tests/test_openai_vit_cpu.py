@@ -233,3 +233,21 @@ def test_api_state_dict_lock_and_method_step(gold):
     with pytest.raises(RuntimeError):
         create_model("ViT-tiny-unknown", "", ops=RefOps())
     assert get_tower_cfg("ViT-B/16").arch == "openai" and get_tower_cfg("ViT-L-14-336").tokens == 577
+
+
+@pytest.mark.slow
+def test_oracle_vitb16_cfg1_matches_reference(golden_dir):
+    """Full-size ViT-B/16 (2 images x 8 boxes, 224^2): loss, lr and every gradient norm of the real reference."""
+    g = np.load(golden_dir / "vitb16_cfg1.npz")
+    rec = json.loads(str(g["recipe"]))
+    cfg = get_tower_cfg("ViT-B-16")
+    student, teacher = seeded_visual_state(cfg, rec["seed_w"]), seeded_visual_state(cfg, rec["seed_w"])
+    batches = [synthetic_batch(rec["batch"], rec["boxes"], 224, 224, seed=rec["seed_b"])]
+    log, grads = eva_ref.train_steps(student, teacher, cfg, batches, lr=rec["lr"], wd=rec["wd"], warmup=rec["warmup"],
+                                     total_steps=rec["total"], unlocked_groups=rec["unlocked"])
+    assert abs(log[0]["loss"] - g["losses"][0]) < 5e-6 and log[0]["lr"] == pytest.approx(g["lrs"][0])
+    norms = dict(zip((str(x) for x in g["grad_names"]), g["grad_norms"]))
+    assert sorted(n for n, v in grads.items() if v is None) == sorted(str(x) for x in g["grad_none"])
+    for n, v in grads.items():
+        if v is not None:
+            assert abs(float(v.double().norm()) - norms[n]) <= 2e-4 * norms[n] + 1e-12, n
