@@ -57,6 +57,8 @@ struct GemmArgs {
     long split_stride;    // EPI_F32 with split-K: slice y writes its partial product to C + y*split_stride (cs_gemm_wgrad)
     int group;            // EPI_PATCH: tokens-1 per image ; EPI_SWIGLU: hidden width Hd
     int gm;               // M panels per raster group
+    int rm;               // persistent kernel: raster / cache-policy mode (template parameter RM), host-side selector
+    int nsplit;           // B-stationary raster (persistent kernel, RM 1/2): N parts the XCDs are divided over (1, 2, 4 or 8)
     // LayerNorm folded into the GEMM (frozen towers): A holds the *un-normalised* rows, B = gamma (.) W, and the epilogue applies
     // out = extra + rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]   with ln_colsum[n] = sum_k B[n,k], bias[n] = beta.W[n] + b[n].
     const float* ln_mean;
@@ -79,7 +81,8 @@ __device__ __forceinline__ void lane_source(int rg, int lane, int& tile_row, int
     chunk = c16 & 7;
 }
 
-template <int NINSTR, bool GLDS>
+// AUX = cache-policy bits of the DMA load (gfx950: 1 = sc0, 2 = nt "streaming, evict first", 16 = sc1)
+template <int NINSTR, bool GLDS, int AUX = 0>
 __device__ __forceinline__ void stage_tile(const __bf16* __restrict__ src, int ld, int k0, char* lds_tile, int rg0, int lane,
                                            const int (&grow)[NINSTR], const int (&gchunk)[NINSTR]) {
 #pragma unroll
@@ -88,7 +91,7 @@ __device__ __forceinline__ void stage_tile(const __bf16* __restrict__ src, int l
         char* dst = lds_tile + (rg0 + i) * 1024;          // wave-uniform
         if (GLDS) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, AUX);
         } else {
             *(uint4*)(dst + lane * 16) = *(const uint4*)g;
         }
@@ -106,6 +109,21 @@ __device__ __forceinline__ void tile_of_id(const GemmArgs& p, int bid, int nwg, 
     const int rows = min(p.gm, p.tiles_m - grp * p.gm);
     tn = rem / rows;
     tm = grp * p.gm + (rem - tn * rows);
+}
+
+// B-stationary raster of the persistent kernel: XCD x owns N part x % NP and M part x / NP (NP = p.nsplit, 8 / NP M parts) and walks
+// its tiles N-fastest, so the CUs of an XCD keep re-reading the same <= tiles_n / NP weight panels (they stay in that XCD's 4 MiB L2
+// for the whole launch) while the activation panels stream through once per N part.  lt = XCD-local tile index; false past the end.
+__device__ __forceinline__ bool tile_bstat(const GemmArgs& p, int xcd, int lt, int& tm, int& tn) {
+    const int NP = p.nsplit, MP = 8 / NP;
+    const int np = xcd % NP, mp = xcd / NP;
+    const int n_lo = np * p.tiles_n / NP, nn = (np + 1) * p.tiles_n / NP - n_lo;
+    const int m_lo = mp * p.tiles_m / MP, mm = (mp + 1) * p.tiles_m / MP - m_lo;
+    if (lt >= mm * nn) return false;
+    const int q = lt / nn;
+    tm = m_lo + q;
+    tn = n_lo + (lt - q * nn);
+    return true;
 }
 
 template <int EPI, int BM, int BN, int NW, int A_INSTR, int B_INSTR>
@@ -603,8 +621,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
 // keeps the XCD affinity of tile_of_id): the first operand tiles of the NEXT output tile (A0, B0, A1) are put in flight before the
 // epilogue of the current one, whose packed slabs live in A slot 2 and row statistics in B slot 1, so the prologue latency and the
 // workgroup relaunch disappear behind the store phase.  bf16, SwiGLU and fp32 residual epilogues (their slabs fit beside the prefetch).
-template <int EPI>
+// RM = raster / cache-policy mode: 0 grouped raster (tile_of_id) | 1 B-stationary raster (tile_bstat) | 2 = 1 + non-temporal A loads |
+// 3 = grouped raster + non-temporal B loads
+template <int EPI, int RM = 0>
 __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
+    constexpr int AUX_A = RM == 2 ? 2 : 0, AUX_B = RM == 3 ? 2 : 0;
+    constexpr bool BSTAT = RM == 1 || RM == 2;
     static_assert(epi_is_bf16(EPI) || EPI == EPI_SWIGLU_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32, "epilogues whose slabs fit");
     constexpr bool PACKED = epi_is_bf16(EPI) || EPI == EPI_SWIGLU_BF16;
     constexpr int BM = 256, BN = 256, WN = 4, NW = 8, TM = 128, TN = 64, FM = 4, FN = 2;
@@ -623,14 +645,19 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
     const int a_base = ((wm * TM + l31) >> 1) << 8, b_base = ((wn * TN + l31) >> 1) << 8;
     const int par8 = (l31 & 1) << 3, sw = l31 >> 1;
 
-    int tile = blockIdx.x, tm, tn;
-    tile_of_id(p, tile, ntiles, tm, tn);
+    int tile = BSTAT ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, tm, tn;      // BSTAT: XCD-local index, XCD = blockIdx.x & 7
+    const int tstep = BSTAT ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    if constexpr (BSTAT) {
+        if (!tile_bstat(p, blockIdx.x & 7, tile, tm, tn)) return;
+    } else {
+        tile_of_id(p, tile, ntiles, tm, tn);
+    }
     int arow[A_INSTR], achk[A_INSTR], brow[B_INSTR], bchk[B_INSTR];
     source_rows<EPI, BM, BN, NW, A_INSTR, B_INSTR>(p, wave, lane, tm * BM, tn * BN, tn, arow, achk, brow, bchk);
     auto prologue = [&]() {
-        stage_tile<A_INSTR, true>(p.A, p.lda, 0, smem, wave * A_INSTR, lane, arow, achk);
-        stage_tile<B_INSTR, true>(p.B, p.ldb, 0, b_ring, wave * B_INSTR, lane, brow, bchk);
-        if (ktiles > 1) stage_tile<A_INSTR, true>(p.A, p.lda, BK, smem + A_BYTES, wave * A_INSTR, lane, arow, achk);
+        stage_tile<A_INSTR, true, AUX_A>(p.A, p.lda, 0, smem, wave * A_INSTR, lane, arow, achk);
+        stage_tile<B_INSTR, true, AUX_B>(p.B, p.ldb, 0, b_ring, wave * B_INSTR, lane, brow, bchk);
+        if (ktiles > 1) stage_tile<A_INSTR, true, AUX_A>(p.A, p.lda, BK, smem + A_BYTES, wave * A_INSTR, lane, arow, achk);
     };
     prologue();
     bool first = true;
@@ -667,11 +694,11 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
                     if (ks < 2) {
                         if (kt + 1 < ktiles) {
                             const int r1[1] = {brow[x]}, c1[1] = {bchk[x]};
-                            stage_tile<1, true>(p.B, p.ldb, (kt + 1) * BK, b_ring + ((kt + 1) & 1) * B_BYTES, wave * B_INSTR + x, lane, r1, c1);
+                            stage_tile<1, true, AUX_B>(p.B, p.ldb, (kt + 1) * BK, b_ring + ((kt + 1) & 1) * B_BYTES, wave * B_INSTR + x, lane, r1, c1);
                         }
                     } else if (kt + 2 < ktiles) {
                         const int r1[1] = {arow[x]}, c1[1] = {achk[x]};
-                        stage_tile<1, true>(p.A, p.lda, (kt + 2) * BK, smem + ((kt + 2) % 3) * A_BYTES, wave * A_INSTR + x, lane, r1, c1);
+                        stage_tile<1, true, AUX_A>(p.A, p.lda, (kt + 2) * BK, smem + ((kt + 2) % 3) * A_BYTES, wave * A_INSTR + x, lane, r1, c1);
                     }
                 }
 #pragma unroll
@@ -682,16 +709,21 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
             cur = cur == 2 ? 0 : cur + 1;
         }
         __syncthreads();                                  // every wave is done reading the operand rings; no DMA pending
-        const int next = tile + (int)gridDim.x;
-        if (next < ntiles) {                              // next tile's first operands fly during this tile's epilogue
-            tile_of_id(p, next, ntiles, tm, tn);
+        const int next = tile + tstep;
+        bool more;
+        if constexpr (BSTAT) more = tile_bstat(p, blockIdx.x & 7, next, tm, tn);
+        else {
+            more = next < ntiles;
+            if (more) tile_of_id(p, next, ntiles, tm, tn);
+        }
+        if (more) {                                       // next tile's first operands fly during this tile's epilogue
             source_rows<EPI, BM, BN, NW, A_INSTR, B_INSTR>(p, wave, lane, tm * BM, tn * BN, tn, arow, achk, brow, bchk);
             prologue();
         }
         if constexpr (EPI == EPI_SWIGLU_BF16) epilogue_swiglu<FM, BN>(p, acc, slab, rowst, lane, m0 + wm * TM, tn_cur, wn);
         else if constexpr (epi_is_bf16(EPI)) epilogue_bf16<FM, BN, epi_act(EPI)>(p, acc, slab, rowst, lane, m0 + wm * TM, n0, wn);
         else epilogue_at<EPI, FM, FN, BN, 64>(p, acc, slab, lane, m0 + wm * TM, n0, tn_cur, wn);
-        if (next >= ntiles) break;
+        if (!more) break;
         tile = next;
         first = false;
     }
@@ -787,7 +819,25 @@ __global__ __launch_bounds__(512, 2) void gemm_k32_kernel(GemmArgs p) {
 //   group 1:     -    | L(kt,0) | C(kt,0) | L(kt,1) | C(kt,1)   ...                 2h,2h+1);  C(kt,h): the 16 MFMAs on them
 // Tile kt+1's DMA is issued during interval 4kt (group 0 in L(kt,0), group 1 in C(kt-1,1)): the buffer it overwrites was last
 // read in interval 4kt-1.  It is waited for (vmcnt(0)) just before the barrier that ends interval 4kt+3.
-template <int EPI>
+// Pieces [X0, X1) of one wave's share of a K tile (pieces 0..A_INSTR-1 = its A row groups, the rest its B row groups), one DMA each.
+template <int X0, int X1, int A_INSTR, int B_INSTR>
+__device__ __forceinline__ void stage_pieces(const GemmArgs& p, int k0, char* dst, int a_bytes, int wave, int lane, const int (&arow)[A_INSTR],
+                                             const int (&achk)[A_INSTR], const int (&brow)[B_INSTR], const int (&bchk)[B_INSTR]) {
+#pragma unroll
+    for (int x = X0; x < X1; ++x) {
+        if (x < A_INSTR) {
+            const int r1[1] = {arow[x]}, c1[1] = {achk[x]};
+            stage_tile<1, true>(p.A, p.lda, k0, dst, wave * A_INSTR + x, lane, r1, c1);
+        } else {
+            const int r1[1] = {brow[x - A_INSTR]}, c1[1] = {bchk[x - A_INSTR]};
+            stage_tile<1, true>(p.B, p.ldb, k0, dst + a_bytes, wave * B_INSTR + (x - A_INSTR), lane, r1, c1);
+        }
+    }
+}
+
+// V = 1: the DMA of the next K tile is spread over three barrier intervals (3 + 3 + 2 pieces per wave) instead of one burst of 8, and the
+// MFMA clusters run at raised wave priority, so the other row group's ds_reads / DMA issue fill the gaps instead of delaying them.
+template <int EPI, int V = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     constexpr int BM = 256, BN = 256, NW = 8, WN = 4, TM = 128, FM = 4, FN = 2;
     constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
@@ -840,13 +890,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
         }
     };
     auto mfma_half = [&]() {
+        if (V) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+        if (V) __builtin_amdgcn_s_setprio(0);
     };
+#define PP_PIECES(X0, X1, KT, BUF) \
+    stage_pieces<X0, X1, A_INSTR, B_INSTR>(p, (KT) * BK, smem + (BUF) * STAGE, A_BYTES, wave, lane, arow, achk, brow, bchk)
     // sched_barrier(0): MFMAs are register-only, nothing else stops the scheduler from moving them across the s_barrier
 #define PP_BARRIER()                                        \
     do {                                                    \
@@ -865,25 +919,80 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     if (g == 1) PP_BARRIER();           // interval 0: group 1 idles one interval behind
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int cur = (kt - kt_begin) & 1;
-        // ---- L(kt,0)
-        if (g == 0 && kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
-        load_frags(cur, 0);
-        PP_BARRIER();
-        // ---- C(kt,0)
-        mfma_half();
-        PP_BARRIER();
-        // ---- L(kt,1)
-        load_frags(cur, 1);
-        if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 (issued in C(kt-1,1)) has landed
-        PP_BARRIER();
-        // ---- C(kt,1)
-        if (g == 1 && kt + 2 < kt_end) issue(kt + 2, cur);               // buffer `cur` was last read in this group's L(kt,1)
-        mfma_half();
-        if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 (issued in L(kt,0)) has landed
-        PP_BARRIER();
+        if constexpr (V == 0) {
+            // ---- L(kt,0)
+            if (g == 0 && kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
+            load_frags(cur, 0);
+            PP_BARRIER();
+            // ---- C(kt,0)
+            mfma_half();
+            PP_BARRIER();
+            // ---- L(kt,1)
+            load_frags(cur, 1);
+            if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 (issued in C(kt-1,1)) has landed
+            PP_BARRIER();
+            // ---- C(kt,1)
+            if (g == 1 && kt + 2 < kt_end) issue(kt + 2, cur);               // buffer `cur` was last read in this group's L(kt,1)
+            mfma_half();
+            if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 (issued in L(kt,0)) has landed
+            PP_BARRIER();
+        } else if constexpr (V == 2) {
+            // All DMA in the L intervals (4 pieces beside the 12 ds_reads), none beside the MFMA clusters.  Pieces 0-3 of a wave are its
+            // A row groups -- rows of its OWN row group's half of A, read by nobody else -- pieces 4-7 its B row groups (read by everyone).
+            // Global interval numbers (group 1 runs one behind): tile kt+1 is first read by group 0 in 4kt+4, by group 1 in 4kt+5.
+            //   group 0: B pieces in L(kt,0) = 4kt, A pieces in L(kt,1) = 4kt+2, all waited for at the end of C(kt,1) = 4kt+3;
+            //   group 1: B pieces in L(kt,0) = 4kt+1, A pieces in L(kt,1) = 4kt+3 where the B pieces are waited for (vmcnt(4): loads
+            //            retire in order), the A pieces at the end of C(kt,1) = 4kt+4, in front of its own first read.
+            const bool nxt = kt + 1 < kt_end && (g == 0 || kt > kt_begin);        // group 1's tile kt_begin+1 comes from the prologue
+            // ---- L(kt,0)
+            load_frags(cur, 0);
+            if (nxt) PP_PIECES(4, 8, kt + 1, cur ^ 1);
+            PP_BARRIER();
+            // ---- C(kt,0)
+            mfma_half();
+            PP_BARRIER();
+            // ---- L(kt,1)
+            load_frags(cur, 1);
+            if (nxt) PP_PIECES(0, 4, kt + 1, cur ^ 1);
+            if (g == 1) {
+                if (nxt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PP_BARRIER();
+            // ---- C(kt,1)
+            mfma_half();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PP_BARRIER();
+        } else {
+            // Group 0 spreads tile kt+1 over L(kt,0) | C(kt,0) | L(kt,1) and waits in C(kt,1); group 1 (one interval behind) spreads
+            // tile kt+2 over C(kt,1) | L(kt+1,0) | C(kt+1,0) and waits in L(kt+1,1) -- the same four global intervals, ending at the
+            // barrier in front of the first read of that tile.  Tile kt_begin+1 of group 1 comes from the prologue.
+            const bool g0_next = g == 0 && kt + 1 < kt_end, g1_next = g == 1 && kt > kt_begin && kt + 1 < kt_end;
+            // ---- L(kt,0)
+            load_frags(cur, 0);
+            if (g0_next) PP_PIECES(0, 3, kt + 1, cur ^ 1);
+            if (g1_next) PP_PIECES(3, 6, kt + 1, cur ^ 1);
+            PP_BARRIER();
+            // ---- C(kt,0)
+            if (g0_next) PP_PIECES(3, 6, kt + 1, cur ^ 1);
+            if (g1_next) PP_PIECES(6, 8, kt + 1, cur ^ 1);
+            mfma_half();
+            PP_BARRIER();
+            // ---- L(kt,1)
+            load_frags(cur, 1);
+            if (g0_next) PP_PIECES(6, 8, kt + 1, cur ^ 1);
+            if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 has landed (this wave's share)
+            PP_BARRIER();
+            // ---- C(kt,1)
+            if (g == 1 && kt + 2 < kt_end) PP_PIECES(0, 3, kt + 2, cur);     // buffer `cur` was last read in this group's L(kt,1)
+            mfma_half();
+            if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 has landed (this wave's share)
+            PP_BARRIER();
+        }
     }
     if (g == 0) PP_BARRIER();           // group 0 waits for group 1's last interval
 #undef PP_BARRIER
+#undef PP_PIECES
     __syncthreads();
     epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + g * TM, n0, tn, wn);
 }
@@ -917,9 +1026,33 @@ int launch_pp(GemmArgs a, int splits, hipStream_t stream) {
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + 127) / 128 : (a.N + 255) / 256;
     constexpr size_t lds = (size_t)512 * BK * 2 * 2;
+    if (a.rm == 1) {                                        // flags bits 16-17 = 1 with the ping-pong schedule: spread DMA + MFMA priority
+        static bool once1 = ((void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once1;
+        hipLaunchKernelGGL((gemm_pp_kernel<EPI, 1>), dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
+        CS_LAUNCH_CHECK();
+        return 0;
+    }
+    if (a.rm == 2) {                                        // = 2: all DMA in the fragment-load intervals + MFMA priority
+        static bool once2 = ((void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once2;
+        hipLaunchKernelGGL((gemm_pp_kernel<EPI, 2>), dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
+        CS_LAUNCH_CHECK();
+        return 0;
+    }
     static bool once = ((void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int EPI, int RM>
+int launch_persist_rm(const GemmArgs& a, unsigned grid, hipStream_t stream) {
+    constexpr size_t lds = 160 * 1024;
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI, RM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL((gemm_persist_kernel<EPI, RM>), dim3(grid), dim3(512), lds, stream, a);
     CS_LAUNCH_CHECK();
     return 0;
 }
@@ -929,13 +1062,15 @@ int launch_persist(GemmArgs a, hipStream_t stream) {
     constexpr int BM = 256, BN = 256;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + BN / 2 - 1) / (BN / 2) : (a.N + BN - 1) / BN;
-    constexpr size_t lds = 160 * 1024;
-    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-    (void)once;
     const long ntiles = (long)a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL(gemm_persist_kernel<EPI>, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), lds, stream, a);
-    CS_LAUNCH_CHECK();
-    return 0;
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16) {           // the wide-N GEMMs of the towers (q|k|v, W1|W2)
+        const bool parts_ok = grid == 256 && a.tiles_n >= a.nsplit && a.tiles_m >= 8 / a.nsplit;
+        if (a.rm == 1 && parts_ok) return launch_persist_rm<EPI, 1>(a, grid, stream);
+        if (a.rm == 2 && parts_ok) return launch_persist_rm<EPI, 2>(a, grid, stream);
+        if (a.rm == 3) return launch_persist_rm<EPI, 3>(a, grid, stream);
+    }
+    return launch_persist_rm<EPI, 0>(a, grid, stream);
 }
 
 template <int EPI>
@@ -1026,6 +1161,8 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 //       bits 8-11: raster group height override (0 = 8)
 //       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue;
 //       bit 15: split-ring schedule issues its DMA in one burst behind the barrier instead of interleaved with the MFMAs
+//       bits 16-17 (persistent kernel, epilogues 0 and 3): 1 = B-stationary raster (each XCD keeps its share of B in L2; bits 8-11 = N parts,
+//                 0 = automatic), 2 = the same with non-temporal A loads, 3 = grouped raster with non-temporal B loads
 static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias, const float* extra, const float* ln_mean,
                         const float* ln_rstd, const float* ln_colsum, float* stats_part, void* xb_out, int ldxb, int M, int N, int K, int lda,
                         int ldb, int ldc, int epi, int splits, int group, int flags, hipStream_t stream) {
@@ -1045,6 +1182,17 @@ static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias
     a.xb_out = (__bf16*)xb_out; a.ldxb = ldxb;
     a.tiles_m = a.tiles_n = 0;
     a.gm = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : 8;
+    a.rm = (flags >> 16) & 3;
+    a.nsplit = 1;
+    if (a.rm == 1 || a.rm == 2) {                          // B-stationary raster: the raster field carries the number of N parts
+        const int f = (flags >> 8) & 15;
+        CS_CHECK_ARG(f == 0 || f == 1 || f == 2 || f == 4 || f == 8, "cs_gemm_nt: B-stationary raster needs 1, 2, 4 or 8 N parts (got %d)", f);
+        // automatic: the fewest parts whose share of B (bf16 [N/parts, K]) leaves room beside the streaming operands in a 4 MiB L2
+        int parts = f;
+        if (parts == 0) for (parts = 1; parts < 8 && (double)N * K * 2 / parts > 3.3e6; parts *= 2) {}
+        a.nsplit = parts;
+        a.gm = 8;
+    }
     if (epi == EPI_SWIGLU_BF16) CS_CHECK_ARG(group > 0 && N == 2 * group, "cs_gemm_nt: swiglu epilogue needs N == 2*group");
     if (epi == EPI_RESID_LN_F32) CS_CHECK_ARG(ln_mean && ln_rstd && ln_colsum && ((uintptr_t)ln_colsum % 16) == 0, "cs_gemm_nt_ln: epilogue 6 needs mean, rstd and a 16-byte aligned column-sum vector");
     CS_CHECK_ARG(stats_part == nullptr || epi == EPI_SWIGLU_BF16 || epi == EPI_RESID_F32 || epi == EPI_RESID_LN_F32,
@@ -1086,7 +1234,7 @@ static int gemm_nt_split_f32(const void* A, const void* B, float* C, int M, int 
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = N; a.group = 0;
     a.split_stride = (long)M * N;
     a.ln_mean = a.ln_rstd = a.ln_colsum = nullptr; a.stats_part = nullptr; a.xb_out = nullptr; a.ldxb = 0;
-    a.tiles_m = a.tiles_n = 0; a.gm = 8; a.dbg = 0;
+    a.tiles_m = a.tiles_n = 0; a.gm = 8; a.dbg = 0; a.rm = 0; a.nsplit = 1;
     a.ktiles_per_split = K / BK;
     return launch<EPI_F32>(a, splits, 1, cfg, stream);
 }

@@ -52,7 +52,7 @@ def both(cpu_tensors):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x31, 0x40, 0x41, 0x50, 0x60, 0x70, 0x71, 0x80, 0x8070, 0x90])      # heuristic, register staging, forced 128x128 / 256x128 / 256x256 / 3-stage
+@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x31, 0x40, 0x41, 0x50, 0x10050, 0x20050, 0x60, 0x70, 0x71, 0x80, 0x8070, 0x90])      # heuristic, register staging, forced 128x128 / 256x128 / 256x256 / 3-stage
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (3152, 768, 768), (300, 192, 64), (128, 64, 256), (1000, 2304, 768)])
 def test_gemm_bf16_bias(hip, ref, M, N, K, flags):
     A, B, bias = rnd((M, K), BF, seed=1), rnd((N, K), BF, 0.05, seed=2), rnd((N,), F32, seed=3)
@@ -83,7 +83,7 @@ def test_gemm_f32_resid_strided(hip, ref, flags):
     check(f"gemm_f32_nobias flags={flags}", Cd2, Cr2, TOL_F32)
 
 
-@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60, 0x70, 0x71, 0x80, 0x8070, 0x90])
+@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x40, 0x50, 0x10050, 0x20050, 0x60, 0x70, 0x71, 0x80, 0x8070, 0x90])
 @pytest.mark.parametrize("Hd,M", [(2048, 394), (256, 34), (96, 130)])
 def test_gemm_swiglu(hip, ref, Hd, M, flags):
     K = 128
@@ -650,3 +650,24 @@ def test_layernorm_fwd_f32_out(hip, ref, C):
     y2 = torch.full((M, C), float("nan"), device="cuda")
     hip.layernorm_fwd_f32(x.cuda(), gamma.cuda(), beta.cuda(), y2, None, None, 1e-5)
     assert torch.equal(y2, yd)
+
+
+# ------------------------------------------------------------------------------------------------ persistent-kernel raster / cache-policy modes
+@pytest.mark.parametrize("mode", [0x10090, 0x10190, 0x10290, 0x10490, 0x10890, 0x20090, 0x20290, 0x30090])
+@pytest.mark.parametrize("M,N,K,epi", [(65536 + 300, 2304, 128, 0), (70000, 4096, 64, 3), (66000, 768, 192, 0), (300, 512, 64, 0)])
+def test_gemm_persistent_raster_modes_cover_every_tile(hip, ref, M, N, K, epi, mode):
+    """flags bits 16-17: B-stationary raster (N parts in bits 8-11; 0 = automatic), with non-temporal A loads, and non-temporal B loads on the
+    grouped raster -- every output tile written exactly as by the default raster (NaN-prefilled output, bitwise comparison)."""
+    A, B, bias = rnd((M, K), BF, seed=81), rnd((N, K), BF, 0.05, seed=82), rnd((N,), F32, seed=83)
+    Ad, Bd, bd = both([A, B, bias])
+    cols, group = (N // 2, N // 2) if epi == 3 else (N, 0)
+    base = torch.full((M, cols), float("nan"), dtype=BF, device="cuda")
+    hip.gemm_nt(Ad, Bd, base, bd, epi=epi, group=group, flags=0x90)
+    assert torch.isfinite(base.float()).all()
+    got = torch.full((M, cols), float("nan"), dtype=BF, device="cuda")
+    hip.gemm_nt(Ad, Bd, got, bd, epi=epi, group=group, flags=mode)
+    assert torch.equal(got, base), f"mode {mode:#x}: {int((got != base).sum())} elements differ"
+    if M < 1000:
+        Cr = torch.empty(M, cols, dtype=BF)
+        ref.gemm_nt(A, B, Cr, bias, epi=epi, group=group)
+        check(f"gemm_raster_mode[{M},{N},{K}] epi={epi} mode={mode:#x}", got, Cr, TOL_BF)

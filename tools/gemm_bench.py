@@ -56,6 +56,91 @@ def main():
 
 
 
+def raster_ab():
+    """Persistent kernel: grouped raster vs B-stationary raster (N parts 1/2/4) vs non-temporal operand loads, interleaved twice
+    (usage: python tools/gemm_bench.py 2048 raster)."""
+    ops = HipOps()
+    M = int(sys.argv[1]) * 197
+    for name, N, K, epi in (("w12 N=4096 K=768 epi3", 4096, 768, 3), ("qkv N=2304 K=768 epi0", 2304, 768, 0)):
+        A = torch.randn(M, K, device="cuda").to(BF)
+        B = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
+        bias = torch.randn(N, device="cuda")
+        C = torch.empty(M, N // 2 if epi == 3 else N, dtype=BF, device="cuda")
+        group = N // 2 if epi == 3 else 0
+        modes = [("grouped", 0x90), ("bstat/auto", 0x10090), ("bstat/1", 0x10190), ("bstat/2", 0x10290), ("bstat/4", 0x10490),
+                 ("bstat+ntA/auto", 0x20090), ("bstat+ntA/1", 0x20190), ("bstat+ntA/2", 0x20290), ("grouped+ntB", 0x30090)]
+        for rep in range(2):
+            line = f"{name} M={M} pass {rep}: "
+            for tag, flags in modes:
+                for _ in range(2):
+                    ops.gemm_nt(A, B, C, bias, epi=epi, group=group, flags=flags)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    ops.gemm_nt(A, B, C, bias, epi=epi, group=group, flags=flags)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 10
+                line += f"{tag} {us:7.1f} us ({2.0 * M * N * K / us / 1e6:4.0f} TF/s) | "
+            print(line, flush=True)
+
+
+def square():
+    """Calibration against published square-GEMM numbers: M = N = K in {4096, 8192}, bf16 out, uniform random [-1, 1) operands
+    (usage: python tools/gemm_bench.py 0 square)."""
+    ops = HipOps()
+    for n in (4096, 8192):
+        A = (torch.rand(n, n, device="cuda") * 2 - 1).to(BF)
+        B = (torch.rand(n, n, device="cuda") * 2 - 1).to(BF)
+        C = torch.empty(n, n, dtype=BF, device="cuda")
+        line = f"{n}^3: "
+        for cfg in (9, 7, 5, 0x1005, 0x2005):               # 0x1005: ping-pong with spread DMA + MFMA priority (flags bit 16)
+            flags = cfg << 4
+            for _ in range(3):
+                ops.gemm_nt(A, B, C, epi=0, flags=flags)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.gemm_nt(A, B, C, epi=0, flags=flags)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 20
+            line += f"cfg{cfg:#x} {us:7.1f} us ({2.0 * n ** 3 / us / 1e6:5.0f} TF/s) | "
+        print(line, flush=True)
+        ref = torch.empty_like(C)
+        ops.gemm_nt(A, B, ref, epi=0, flags=3 << 4)
+        bad = 0
+        for _ in range(10):
+            C.fill_(float("nan"))
+            ops.gemm_nt(A, B, C, epi=0, flags=0x10050)
+            bad += int(not torch.equal(C, ref))
+            C.fill_(float("nan"))
+            ops.gemm_nt(A, B, C, epi=0, flags=0x20050)
+            bad += 100 * int(not torch.equal(C, ref))
+        print(f"   spread ping-pong (v1 + 100 * v2) vs lockstep bitwise mismatches in 10 runs: {bad}", flush=True)
+    M = 2048 * 197
+    for name, N, K, epi in (("w12 N=4096 K=768 epi3", 4096, 768, 3), ("qkv N=2304 K=768 epi0", 2304, 768, 0), ("w3 N=768 K=2048 epi2", 768, 2048, 2)):
+        A = torch.randn(M, K, device="cuda").to(BF)
+        B = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
+        bias = torch.randn(N, device="cuda")
+        C = torch.randn(M, N, device="cuda") if epi == 2 else torch.empty(M, N // 2 if epi == 3 else N, dtype=BF, device="cuda")
+        group = N // 2 if epi == 3 else 0
+        line = f"{name} M={M}: "
+        for rep in range(2):
+            for tag, flags in (("persist", 0x90), ("pp-v1", 0x10050), ("pp-v2", 0x20050)):
+                for _ in range(2):
+                    ops.gemm_nt(A, B, C, bias, C if epi == 2 else None, epi=epi, group=group, flags=flags)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    ops.gemm_nt(A, B, C, bias, C if epi == 2 else None, epi=epi, group=group, flags=flags)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 10
+                line += f"{tag} {us:7.1f} us ({2.0 * M * N * K / us / 1e6:4.0f} TF/s) | "
+        print(line, flush=True)
+
+
 def fold_ab():
     """A/B of the folded-LayerNorm operands: SwiGLU GEMM with / without the statistics output, residual GEMM with / without the
     folded epilogue, and the finalize kernel (usage: python tools/gemm_bench.py 512 fold)."""
@@ -138,4 +223,4 @@ def wgrad_ab():
 
 if __name__ == "__main__":
     mode = sys.argv[2] if len(sys.argv) > 2 else ""
-    {"fold": fold_ab, "wgrad": wgrad_ab}.get(mode, main)()
+    {"fold": fold_ab, "wgrad": wgrad_ab, "raster": raster_ab, "square": square}.get(mode, main)()
