@@ -11,6 +11,9 @@ does each stage (paths under /root/reference/src/open_clip/):
   dense head      transformer.py:576-587     normalize(ln_post(x[:,1:]) @ proj)
   lock            transformer.py:391-422     groups = [stem, positional_embedding, blocks..., last block]; the last n train
 
+The frozen teacher uses the EVA02 engine's schedule tricks unchanged: CLS-query-only last block, ln_1 / ln_2 folded into the in_proj / c_fc
+GEMMs with the residual GEMMs emitting the bf16 copy and the row statistics of the stream (`_teacher_block_folded`).
+
 Differences to the EVA02 schedule: no RoPE (the attention kernels get identity tables), no sub-LayerNorms, `proj` is a bias-free
 [C,E] matrix kept transposed for the forward GEMM, and the last dense block owns no never-reached *tensor* (q/k are rows of the one
 in_proj_weight parameter, whose gradient rows stay zero -- exactly what autograd hands torch's AdamW).
@@ -21,7 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from .config import TowerCfg
-from .engine import (BF16, DX_BF16, DX_F32_ACCUM, DX_F32_ASSIGN, EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_PATCH_F32, EPI_QGELU_BF16,
+from .engine import (BF16, DX_F32_ACCUM, DX_F32_ASSIGN, EPI_BF16, EPI_F32, EPI_GELU_BF16, EPI_PATCH_F32, EPI_QGELU_BF16,
                      EPI_RESID_F32, F32, EvaEngine, _round_up)
 
 
@@ -51,8 +54,12 @@ class ClipVitEngine(EvaEngine):
         if cfg.hidden % 64 or cfg.width % 64 or cfg.embed_dim % 64:
             raise NotImplementedError(f"{cfg.name}: width, MLP width and embed_dim must be multiples of 64")
         super().__init__(cfg, ops, trainable=trainable, prefix=prefix)
-        self.fold_sub_ln = self.fold_block_ln = False           # EVA02-only schedules
-        self.cls_only_last_block = False
+        self.fold_sub_ln = False                                # there are no sub-LayerNorms in this family
+        # Frozen towers, encode_image(): ln_1 / ln_2 are applied inside the in_proj / c_fc GEMM epilogues (gamma folded into a bf16 copy
+        # of the weight, the residual GEMMs emit the bf16 copy of the stream and its row statistics), and the last block runs for the
+        # CLS query only (forward() consumes x[:, 0] alone, transformer.py:486-494).  Same switches as the EVA02 engine.
+        self.fold_block_ln = not trainable
+        self.cls_only_last_block = True
 
     def _layout(self):
         return clip_vit_layout(self.cfg, self.prefix)
@@ -78,6 +85,21 @@ class ClipVitEngine(EvaEngine):
         self.ops.cast_f32_bf16(self.master, self.shadow)
         self._pos_cache.clear()
         self.sync_transposed()
+        if self.fold_block_ln:
+            self._build_folds()
+
+    def _build_folds(self):
+        """gamma (.) W in bf16, its row sums and W.beta + b for ln_1 -> in_proj and ln_2 -> c_fc of every block (one-time, after a load)."""
+        self.fold = {}
+        with torch.no_grad():
+            for i in range(self.cfg.layers):
+                b = f"{self.prefix}{self.BLOCK_TAG}{i}."
+                out = {}
+                for key, wname, bname, ln in (("qkv", "attn.in_proj_weight", "attn.in_proj_bias", "ln_1"), ("fc", "mlp.c_fc.weight", "mlp.c_fc.bias", "ln_2")):
+                    W, bias = self.p[b + wname], self.p[b + bname]
+                    Wf = (W * self.p[b + ln + ".weight"][None, :]).to(BF16).contiguous()
+                    out[key] = (Wf, Wf.float().sum(dim=1).contiguous(), (W @ self.p[b + ln + ".bias"] + bias).contiguous())
+                self.fold[i] = out
 
     def set_trainable_blocks(self, unlocked_groups: int):
         """VisionTransformer.lock (transformer.py:391-422): of [stem, positional_embedding, block 0 .. L-1] the last n groups train;
@@ -172,6 +194,67 @@ class ClipVitEngine(EvaEngine):
                         fc=fc, hid=hid)
         return x2
 
+    def _teacher_block_folded(self, i, x, xb, st, B, N, cos, sin, emit_next):
+        """One frozen-tower block with both LayerNorms folded into the GEMMs (in place on x).  xb / st = bf16 copy and (mean, rstd) of x as
+        left by the previous block's c_proj GEMM, or None (first block: plain ln_1 kernel).  Returns (xb, st) for the next block when
+        emit_next."""
+        ops, cfg = self.ops, self.cfg
+        C, Hd, H, eps = cfg.width, cfg.hidden, cfg.heads, cfg.ln_eps
+        b = f"{self.prefix}{self.BLOCK_TAG}{i}."
+        M = B * N
+        f = self.fold[i]
+        qkv = ops.empty((M, 3 * C), BF16)
+        if xb is None:
+            ln1 = ops.empty((M, C), BF16)
+            ops.layernorm_fwd(x, self.p[b + "ln_1.weight"], self.p[b + "ln_1.bias"], ln1, None, None, eps)
+            ops.gemm_nt(ln1, self.w[b + "attn.in_proj_weight"], qkv, bias=self.p[b + "attn.in_proj_bias"], epi=EPI_BF16)
+        else:
+            Wq, cq, dq = f["qkv"]
+            ops.gemm_nt_ln(xb, Wq, qkv, bias=dq, ln_mean=st[0], ln_rstd=st[1], ln_colsum=cq, epi=EPI_BF16)
+        att = ops.empty((M, C), BF16)
+        ops.attn_fwd(qkv, cos, sin, att, None, B, N, H, cfg.head_width ** -0.5)
+        part = ops.empty(((C + 63) // 64, M, 2), F32)
+        xb2 = ops.empty((M, C), BF16)
+        ops.gemm_nt_ln(att, self.w[b + "attn.out_proj.weight"], x, bias=self.p[b + "attn.out_proj.bias"], extra=x, stats_part=part, xb_out=xb2,
+                       epi=EPI_RESID_F32)
+        mean, rstd = ops.empty((M,), F32), ops.empty((M,), F32)
+        ops.ln_stats_finalize(part, 64, C, mean, rstd, eps)
+        Wf, cf, df = f["fc"]
+        hid = ops.empty((M, Hd), BF16)
+        ops.gemm_nt_ln(xb2, Wf, hid, bias=df, ln_mean=mean, ln_rstd=rstd, ln_colsum=cf, epi=EPI_QGELU_BF16 if cfg.quick_gelu else EPI_GELU_BF16)
+        wp, bp = self.w[b + "mlp.c_proj.weight"], self.p[b + "mlp.c_proj.bias"]
+        if not emit_next:
+            ops.gemm_nt(hid, wp, x, bias=bp, extra=x, epi=EPI_RESID_F32)
+            return None, None
+        ops.gemm_nt_ln(hid, wp, x, bias=bp, extra=x, stats_part=part, xb_out=xb2, epi=EPI_RESID_F32)
+        ops.ln_stats_finalize(part, 64, C, mean, rstd, eps)
+        return xb2, (mean, rstd)
+
+    def _block_fwd_cls(self, i, x, B, N, cos, sin):
+        """Last teacher block restricted to what forward() consumes: the CLS row.  x fp32 [B*N, C] -> fp32 [B, C]; keys and values still
+        come from every token.  Row-for-row the same arithmetic as _block_fwd."""
+        ops, cfg = self.ops, self.cfg
+        C, Hd, H, eps = cfg.width, cfg.hidden, cfg.heads, cfg.ln_eps
+        b = f"{self.prefix}{self.BLOCK_TAG}{i}."
+        M = B * N
+        ln1 = ops.empty((M, C), BF16)
+        ops.layernorm_fwd(x, self.p[b + "ln_1.weight"], self.p[b + "ln_1.bias"], ln1, None, None, eps)
+        wqkv, bqkv = self.w[b + "attn.in_proj_weight"], self.p[b + "attn.in_proj_bias"]
+        kv = ops.empty((M, 2 * C), BF16)
+        ops.gemm_nt(ln1, wqkv[C:], kv, bias=bqkv[C:], epi=EPI_BF16)
+        q = ops.empty((B, C), BF16)
+        ops.gemm_nt(ln1.view(B, N, C)[:, 0, :], wqkv[:C], q, bias=bqkv[:C], epi=EPI_BF16)
+        att = ops.empty((B, C), BF16)
+        ops.attn_cls_fwd(q, kv, cos, sin, att, B, N, H, cfg.head_width ** -0.5)
+        xc = x.view(B, N, C)[:, 0, :].contiguous()
+        ops.gemm_nt(att, self.w[b + "attn.out_proj.weight"], xc, bias=self.p[b + "attn.out_proj.bias"], extra=xc, epi=EPI_RESID_F32)
+        ln2 = ops.empty((B, C), BF16)
+        ops.layernorm_fwd(xc, self.p[b + "ln_2.weight"], self.p[b + "ln_2.bias"], ln2, None, None, eps)
+        hid = ops.empty((B, Hd), BF16)
+        ops.gemm_nt(ln2, self.w[b + "mlp.c_fc.weight"], hid, bias=self.p[b + "mlp.c_fc.bias"], epi=EPI_QGELU_BF16 if cfg.quick_gelu else EPI_GELU_BF16)
+        ops.gemm_nt(hid, self.w[b + "mlp.c_proj.weight"], xc, bias=self.p[b + "mlp.c_proj.bias"], extra=xc, epi=EPI_RESID_F32)
+        return xc
+
     def _head(self, rows, out):
         """out[M,E] f32 = bf16(rows) . proj   (no bias: transformer.py:492-493,583-584)."""
         self.ops.gemm_nt(rows, self.wt["head_fwd"][:, :self.cfg.width], out, epi=EPI_F32)
@@ -189,10 +272,16 @@ class ClipVitEngine(EvaEngine):
             N = g * g + 1
             cos, sin = self.rope_tables(g)
             xf = x.view(B * N, cfg.width)
-            for i in range(cfg.layers):
-                self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
+            last = cfg.layers - 1 if self.cls_only_last_block else cfg.layers
+            xb = st = None
+            for i in range(last):
+                if self.fold_block_ln:
+                    xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last)
+                else:
+                    self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
+            xc = self._block_fwd_cls(last, xf, B, N, cos, sin) if last < cfg.layers else x[:, 0, :]
             cls = ops.empty((B, cfg.width), BF16)
-            ops.layernorm_fwd(x[:, 0, :], self.p[P + "ln_post.weight"], self.p[P + "ln_post.bias"], cls, None, None, cfg.ln_eps)
+            ops.layernorm_fwd(xc, self.p[P + "ln_post.weight"], self.p[P + "ln_post.bias"], cls, None, None, cfg.ln_eps)
             self._head(cls, out[k0:k0 + B])
         return out
 

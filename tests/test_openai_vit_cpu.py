@@ -124,6 +124,29 @@ def test_engine_forward_matches_bf16_oracle_and_reference(gold, quick):
     assert one_minus_cos(teacher, g[tag + "teacher"]) < 2e-4 and one_minus_cos(pooled, g[tag + "student_roi"]) < 2e-4
 
 
+@pytest.mark.parametrize("quick", [False, True])
+def test_engine_teacher_schedule_variants_are_the_same_function(gold, quick):
+    """encode_image(): CLS-query-only last block and ln_1 / ln_2 folded into the GEMM epilogues (defaults of a frozen tower) against the plain
+    every-token schedule: identical per row without the fold, bf16-rounding-close with it; both within tolerance of the reference."""
+    g, rec = gold
+    cfg, tag = tiny_openai_cfg(quick), "q/" if quick else ""
+    _, _, crops = _batches(cfg, rec, 1)[0]
+    eng = _engine(cfg, rec["seed_w"], False)
+    assert eng.cls_only_last_block and eng.fold_block_ln and not _engine(cfg, rec["seed_w"], True).fold_block_ln
+    fast = eng.encode_image(crops.flatten(0, 1), chunk=4)
+    eng.fold_block_ln = False
+    cls_only = eng.encode_image(crops.flatten(0, 1), chunk=4)
+    eng.cls_only_last_block = False
+    plain = eng.encode_image(crops.flatten(0, 1), chunk=4)
+    assert rel(cls_only, plain) < 1e-6
+    assert rel(fast, plain) < 1e-2 and one_minus_cos(fast, plain) < 1e-4
+    eng.fold_block_ln, eng.cls_only_last_block = True, False          # every block through the folded path
+    folded_all = eng.encode_image(crops.flatten(0, 1), chunk=5)
+    assert rel(folded_all, plain) < 1e-2 and one_minus_cos(folded_all, plain) < 1e-4
+    for t in (fast, folded_all):
+        assert rel(t, g[tag + "teacher"]) < 2e-2 and one_minus_cos(t, g[tag + "teacher"]) < 2e-4
+
+
 def test_engine_rescaled_grid(gold):
     g, rec = gold
     cfg = tiny_openai_cfg()
