@@ -877,6 +877,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
         stage_tile<B_INSTR, true>(p.B, p.ldb, kt * BK, dst + A_BYTES, wave * B_INSTR, lane, brow, bchk);
     };
     bf16x8 fa[2][FM], fb[2][FN];
+    if (V == 2 && (p.dbg & 2)) {                      // ablation without ds_reads: defined (zero) fragments
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[s2][i] = bf16x8{};
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[s2][j] = bf16x8{};
+        }
+    }
     auto load_frags = [&](int buf, int h) {
         const char* la = smem + buf * STAGE + a_base;
         const char* lb = smem + buf * STAGE + A_BYTES + b_base;
@@ -943,16 +952,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
             //   group 0: B pieces in L(kt,0) = 4kt, A pieces in L(kt,1) = 4kt+2, all waited for at the end of C(kt,1) = 4kt+3;
             //   group 1: B pieces in L(kt,0) = 4kt+1, A pieces in L(kt,1) = 4kt+3 where the B pieces are waited for (vmcnt(4): loads
             //            retire in order), the A pieces at the end of C(kt,1) = 4kt+4, in front of its own first read.
-            const bool nxt = kt + 1 < kt_end && (g == 0 || kt > kt_begin);        // group 1's tile kt_begin+1 comes from the prologue
+            // timing ablations (flags bits 12-13, results wrong): 1 = no operand DMA in the loop, 2 = no fragment ds_reads
+            const bool nxt = kt + 1 < kt_end && (g == 0 || kt > kt_begin) && !(p.dbg & 1);   // group 1's tile kt_begin+1 comes from the prologue
             // ---- L(kt,0)
-            load_frags(cur, 0);
+            if (!(p.dbg & 2)) load_frags(cur, 0);
             if (nxt) PP_PIECES(4, 8, kt + 1, cur ^ 1);
             PP_BARRIER();
             // ---- C(kt,0)
             mfma_half();
             PP_BARRIER();
             // ---- L(kt,1)
-            load_frags(cur, 1);
+            if (!(p.dbg & 2)) load_frags(cur, 1);
             if (nxt) PP_PIECES(0, 4, kt + 1, cur ^ 1);
             if (g == 1) {
                 if (nxt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -994,6 +1004,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 #undef PP_BARRIER
 #undef PP_PIECES
     __syncthreads();
+    if (p.dbg & 4) return;
     epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + g * TM, n0, tn, wn);
 }
 

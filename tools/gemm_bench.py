@@ -118,6 +118,19 @@ def square():
             ops.gemm_nt(A, B, C, epi=0, flags=0x20050)
             bad += 100 * int(not torch.equal(C, ref))
         print(f"   spread ping-pong (v1 + 100 * v2) vs lockstep bitwise mismatches in 10 runs: {bad}", flush=True)
+        line = f"{n}^3 ping-pong v2 ablations: "
+        for tag, dbg in (("full", 0), ("no DMA", 1), ("no ds_read", 2), ("MFMA + barriers only", 3), ("no epilogue", 4), ("MFMA + barriers, no epilogue", 7)):
+            flags = 0x20050 | (dbg << 12)
+            for _ in range(3):
+                ops.gemm_nt(A, B, C, epi=0, flags=flags)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.gemm_nt(A, B, C, epi=0, flags=flags)
+            e1.record()
+            torch.cuda.synchronize()
+            line += f"{tag} {e0.elapsed_time(e1) * 1e3 / 20:7.1f} us | "
+        print(line, flush=True)
     M = 2048 * 197
     for name, N, K, epi in (("w12 N=4096 K=768 epi3", 4096, 768, 3), ("qkv N=2304 K=768 epi0", 2304, 768, 0), ("w3 N=768 K=2048 epi2", 768, 2048, 2)):
         A = torch.randn(M, K, device="cuda").to(BF)
