@@ -23,14 +23,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _cfg(family):
+    from clipself_amd.config import tiny_cfg, tiny_openai_cfg
+    return tiny_openai_cfg() if family == "openai" else tiny_cfg()
+
+
 def _build(cfg, device):
     from clipself_amd.init import seeded_visual_state
-    from clipself_amd.open_clip.model import CustomCLIP
+    from clipself_amd.open_clip.model import CLIP, CustomCLIP
     if device == "cpu":
         from oracle.ops_ref import RefOps as Ops
     else:
         from clipself_amd.hip import HipOps as Ops
-    student, teacher = CustomCLIP(cfg, ops=Ops(), trainable=True), CustomCLIP(cfg, ops=Ops(), trainable=False)
+    Model = CLIP if cfg.arch == "openai" else CustomCLIP
+    student, teacher = Model(cfg, ops=Ops(), trainable=True), Model(cfg, ops=Ops(), trainable=False)
     return student, teacher, seeded_visual_state
 
 
@@ -39,19 +45,18 @@ def _args(distributed, device):
                            multiscale=False, extract_type="v2", cosine_weight=1.0)
 
 
-def _worker(rank, world, port, out_dir, device):
+def _worker(rank, world, port, out_dir, device, family="eva02"):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from clipself_amd.config import tiny_cfg
     from clipself_amd.init import synthetic_batch
     from clipself_amd.training.clipself import CLIPSelf
     from clipself_amd.training.distributed import FrozenDataParallel, StudentDataParallel
     from clipself_amd.training.optim import FlatAdamW
     from clipself_amd.training.train import train_step
     torch.set_num_threads(2)
-    cfg = tiny_cfg()
+    cfg = _cfg(family)
     student, teacher, seeded = _build(cfg, device)
     # deliberately different initial weights per rank: the wrapper must broadcast rank 0's
     student.visual.engine.load_state(seeded(cfg, 1 + rank))
@@ -67,19 +72,18 @@ def _worker(rank, world, port, out_dir, device):
     dist.destroy_process_group()
 
 
-def run_two_rank_equivalence(device, tmp_path, tol):
+def run_two_rank_equivalence(device, tmp_path, tol, family="eva02"):
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), device), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), device, family), nprocs=world, join=True)
     r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
     assert torch.equal(r0["master"], r1["master"]), "ranks diverged after the step"
     assert torch.equal(r0["grad"], r1["grad"]), "all-reduced gradients differ between ranks"
 
-    from clipself_amd.config import tiny_cfg
     from clipself_amd.init import synthetic_batch
     from clipself_amd.training.clipself import CLIPSelf
     from clipself_amd.training.optim import FlatAdamW
     from clipself_amd.training.train import train_step
-    cfg = tiny_cfg()
+    cfg = _cfg(family)
     student, teacher, seeded = _build(cfg, device)
     student.visual.engine.load_state(seeded(cfg, 1))
     teacher.visual.engine.load_state(seeded(cfg, 1))
@@ -101,3 +105,8 @@ def test_two_rank_step_equals_single_process_on_the_union_batch(tmp_path):
     # The CPU reference ops round to bf16 after torch matmuls whose last fp32 bits depend on the batch size (BLAS blocking), so a few
     # bf16 roundings flip between "2 x B" and "1 x 2B"; the HIP kernels tile independently of M and agree to 6e-8 (tests/test_gpu_step.py).
     run_two_rank_equivalence("cpu", tmp_path, 1e-3)
+
+
+def test_two_rank_step_equals_single_process_openai_vit(tmp_path):
+    """The same scenario on the OpenAI-CLIP ViT family (block buckets found through ClipVitEngine.block_index)."""
+    run_two_rank_equivalence("cpu", tmp_path, 1e-3, family="openai")

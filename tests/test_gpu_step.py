@@ -594,3 +594,10 @@ def test_training_main_entrypoint_openai_vit(tmp_path):
     # blocks 0..5 stayed frozen: the ensemble of equal tensors is the tensor itself
     from clipself_amd.init import seeded_visual_state as seeded
     assert rel(sd["visual.transformer.resblocks.2.mlp.c_proj.weight"], seeded(m.visual.cfg, 0)["visual.transformer.resblocks.2.mlp.c_proj.weight"]) < 1e-7
+
+
+def test_two_ranks_on_one_gpu_equal_single_process_openai_vit(tmp_path):
+    """The 2-rank data-parallel scenario of SURVEY §8(e) on the OpenAI-CLIP ViT family, through the HIP kernels."""
+    from test_distributed_cpu import run_two_rank_equivalence
+    g, p = run_two_rank_equivalence("cuda", tmp_path, 2e-2, family="openai")
+    _log(f"2-rank DP on one GPU vs union batch (OpenAI ViT): grad rel={g:.3e} param rel={p:.3e}")
