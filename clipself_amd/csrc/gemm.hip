@@ -1008,6 +1008,124 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + g * TM, n0, tn, wn);
 }
 
+
+// ------------------------------------------------------------------------------------------------ persistent ping-pong schedule
+// The v2 ping-pong loop (all LDS-DMA pieces in the fragment-load intervals, MFMA clusters at raised priority) inside a persistent tile
+// loop, for the packed epilogues.  LDS: two 64 KiB operand stages + 32 KiB of wave-private epilogue slabs (no aliasing with the
+// stages), row statistics of a folded LayerNorm in the first 8 KiB of stage 1.  After the last K tile of an output tile every wave puts
+// its share of the NEXT tile's K tile 0 in flight (stage 0) and only then runs its epilogue; stage 1 is refilled after the barrier that
+// follows the epilogues (row group 1 in its idle first interval, row group 0 in its first two load intervals, as in the one-tile kernel).
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp_persist_kernel(GemmArgs p) {
+    static_assert(epi_is_bf16(EPI) || EPI == EPI_SWIGLU_BF16, "packed epilogues only");
+    constexpr int BM = 256, BN = 256, NW = 8, TM = 128, FM = 4, FN = 2;
+    constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
+    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wn = wave & 3;
+    const int hf = lane >> 5, l31 = lane & 31;
+    char* const slab = smem + 2 * STAGE + wave * 4096;
+    char* const rowst = smem + STAGE + wave * 1024;
+    const int ntiles = p.tiles_m * p.tiles_n, ktiles = p.K / BK;
+    const int a_base = ((g * TM + l31) >> 1) << 8, b_base = ((wn * 64 + l31) >> 1) << 8;
+    const int par8 = (l31 & 1) << 3, sw = l31 >> 1;
+
+    int tile = blockIdx.x, tm, tn;
+    tile_of_id(p, tile, ntiles, tm, tn);
+    int arow[A_INSTR], achk[A_INSTR], brow[B_INSTR], bchk[B_INSTR];
+    source_rows<EPI, BM, BN, NW, A_INSTR, B_INSTR>(p, wave, lane, tm * BM, tn * BN, tn, arow, achk, brow, bchk);
+#define PP_PIECES(X0, X1, KT, BUF) \
+    stage_pieces<X0, X1, A_INSTR, B_INSTR>(p, (KT) * BK, smem + (BUF) * STAGE, A_BYTES, wave, lane, arow, achk, brow, bchk)
+#define PP_BARRIER()                                        \
+    do {                                                    \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+        __builtin_amdgcn_s_barrier();                       \
+        __builtin_amdgcn_sched_barrier(0);                  \
+    } while (0)
+    PP_PIECES(0, 8, 0, 0);
+    bf16x8 fa[2][FM], fb[2][FN];
+    for (;;) {
+        const int m0 = tm * BM, n0 = tn * BN, tn_cur = tn;
+        f32x16 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        auto load_frags = [&](int buf, int h) {
+            const char* la = smem + buf * STAGE + a_base;
+            const char* lb = smem + buf * STAGE + A_BYTES + b_base;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int off = ((par8 | ((h * 2 + s2) * 2 + hf)) ^ sw) << 4;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) fa[s2][i] = *(const bf16x8*)(la + i * (16 * 256) + off);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) fb[s2][j] = *(const bf16x8*)(lb + j * (16 * 256) + off);
+            }
+        };
+        auto mfma_half = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][i], fb[s2][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // K tile 0 of this output tile (issued before the previous epilogue, or above) has landed; the previous epilogue's stores share
+        // the queue and do not retire in order with the loads: drain it.  The barrier also ends every wave's use of the slabs / row stats.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        if (g == 1) {                                       // interval 0: row group 1 idles one interval behind and refills stage 1
+            if (ktiles > 1) PP_PIECES(0, 8, 1, 1);
+            PP_BARRIER();
+        }
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int cur = kt & 1;
+            const bool nxt = kt + 1 < ktiles && (g == 0 || kt > 0);
+            // ---- L(kt,0)
+            load_frags(cur, 0);
+            if (nxt) PP_PIECES(4, 8, kt + 1, cur ^ 1);
+            PP_BARRIER();
+            // ---- C(kt,0)
+            mfma_half();
+            PP_BARRIER();
+            // ---- L(kt,1)
+            load_frags(cur, 1);
+            if (nxt) PP_PIECES(0, 4, kt + 1, cur ^ 1);
+            if (g == 1) {
+                if (nxt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PP_BARRIER();
+            // ---- C(kt,1)
+            mfma_half();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PP_BARRIER();
+        }
+        if (g == 0) PP_BARRIER();                           // row group 0 waits for group 1's last interval: both stages are free now
+        const int next = tile + (int)gridDim.x;
+        const bool more = next < ntiles;
+        if (more) {                                         // the next tile's K tile 0 flies during this tile's epilogue
+            tile_of_id(p, next, ntiles, tm, tn);
+            source_rows<EPI, BM, BN, NW, A_INSTR, B_INSTR>(p, wave, lane, tm * BM, tn * BN, tn, arow, achk, brow, bchk);
+            PP_PIECES(0, 8, 0, 0);
+        }
+        if constexpr (EPI == EPI_SWIGLU_BF16) epilogue_swiglu<FM, BN>(p, acc, slab, rowst, lane, m0 + g * TM, tn_cur, wn);
+        else epilogue_bf16<FM, BN, epi_act(EPI)>(p, acc, slab, rowst, lane, m0 + g * TM, n0, wn);
+        if (!more) break;
+        tile = next;
+    }
+#undef PP_BARRIER
+#undef PP_PIECES
+}
+
 // ------------------------------------------------------------------------------------------------ launch
 template <int EPI, int BM, int BN, int WM, int WN, int NS, bool PF = false>
 int launch_cfg(GemmArgs a, int splits, int use_glds, hipStream_t stream) {
@@ -1085,6 +1203,19 @@ int launch_persist(GemmArgs a, hipStream_t stream) {
 }
 
 template <int EPI>
+int launch_pp_persist(GemmArgs a, hipStream_t stream) {
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + 127) / 128 : (a.N + 255) / 256;
+    constexpr size_t lds = 160 * 1024;
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_pp_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    const long ntiles = (long)a.tiles_m * a.tiles_n;
+    hipLaunchKernelGGL(gemm_pp_persist_kernel<EPI>, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), lds, stream, a);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int EPI>
 int launch_k32(GemmArgs a, int splits, hipStream_t stream) {
     constexpr int BM = 256, BN = 128;
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -1138,9 +1269,14 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
         // residual epilogues, case 9 falls back to 7 for the others): another -2.4 % (q|k|v) / -4.9 % (W1|W2) per launch
         if (cfg == 3 && use_glds) cfg = PP_DEFAULT ? 5 : 9;
     }
-    const int ns = sp[(cfg == 4 || cfg == 8) ? 2 : (cfg >= 5 ? 3 : cfg)];   // cfgs 5..7 and 9 are 256x256 variants
+    const int ns = sp[(cfg == 4 || cfg == 8) ? 2 : (cfg >= 5 ? 3 : cfg)];   // cfgs 5..7, 9 and 10 are 256x256 variants
     a.ktiles_per_split = (ktiles + ns - 1) / ns;
     switch (cfg) {
+        case 10:                                                                                // persistent ping-pong (packed epilogues)
+            if constexpr (epi_is_bf16(EPI) || EPI == EPI_SWIGLU_BF16) {
+                if (use_glds && ns == 1) return launch_pp_persist<EPI>(a, stream);
+            }
+            [[fallthrough]];
         case 9:                                                                                 // persistent split rings (packed epilogues)
             if constexpr (epi_is_bf16(EPI) || EPI == EPI_SWIGLU_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
                 if (use_glds && ns == 1) return launch_persist<EPI>(a, stream);
@@ -1168,7 +1304,8 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 // flags bit0: 0 = global_load_lds staging, 1 = register staging (debug/fallback A-B switch)
 //       bits 4-7: force schedule (1 = 128x128, 2 = 256x128, 3 = 256x256 lockstep, 4 = 256x128 3-stage ring,
 //                 5 = 256x256 ping-pong, 6 = 256x256 lockstep + L2 warm-up, 7 = 256x256 split rings A3/B2,
-//                 8 = 256x128 K-32 ring, two workgroups per CU, 9 = persistent split rings (bf16 / GELU / SwiGLU / residual epilogues); 0 = heuristic)
+//                 8 = 256x128 K-32 ring, two workgroups per CU, 9 = persistent split rings (bf16 / GELU / SwiGLU / residual epilogues),
+//                 10 = persistent ping-pong (bf16 / GELU / SwiGLU epilogues; others fall back to 9); 0 = heuristic)
 //       bits 8-11: raster group height override (0 = 8)
 //       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue;
 //       bit 15: split-ring schedule issues its DMA in one burst behind the barrier instead of interleaved with the MFMAs

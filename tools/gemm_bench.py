@@ -140,7 +140,7 @@ def square():
         group = N // 2 if epi == 3 else 0
         line = f"{name} M={M}: "
         for rep in range(2):
-            for tag, flags in (("persist", 0x90), ("pp-v1", 0x10050), ("pp-v2", 0x20050)):
+            for tag, flags in (("persist", 0x90), ("pp-v2", 0x20050), ("pp-persist", 0xA0)):
                 for _ in range(2):
                     ops.gemm_nt(A, B, C, bias, C if epi == 2 else None, epi=epi, group=group, flags=flags)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
