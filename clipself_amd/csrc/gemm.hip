@@ -18,8 +18,9 @@
 //     SOURCE address: two 128-byte tile rows share one 256-byte LDS row whose sixteen 16-byte slots are XOR-permuted
 //     by (lds_row & 15) -> every ds_read_b128 lane group hits 16 distinct slots (conflict free; SQ_LDS_BANK_CONFLICT
 //     < 2 % of wave cycles in profiles/).
-//   * two main-loop schedules:
-//       - "lockstep": one barrier per K tile, all 8 waves read fragments and issue MFMAs together (any tile shape);
+//   * main-loop schedules (the default for the tower shapes is the persistent split-ring loop, gemm_persist_kernel):
+//       - "lockstep": one barrier per K tile, all 8 waves read fragments and issue MFMAs together (any tile shape); with split
+//         operand rings (three A stages, two B stages, DMA pieces interleaved with the MFMAs) for the 256x256 tile;
 //       - "ping-pong" (256x256 only): the two 4-wave row groups run half a K tile out of phase, separated by raw
 //         s_barriers, so in every barrier interval one group issues 16 MFMAs per wave while the other reads its
 //         next fragments from LDS / issues the next tile's DMA -- each SIMD hosts one wave of either group, so its
