@@ -8,7 +8,6 @@ There is NO fallback: if the library is missing or a tensor is not on the GPU th
 from __future__ import annotations
 
 import ctypes
-import os
 import subprocess
 from pathlib import Path
 

@@ -91,7 +91,6 @@ def seeded_visual_state(cfg: TowerCfg, seed: int = 0, prefix: str = "visual.") -
     sd = {}
     for name, shape in visual_param_shapes(cfg, prefix).items():
         g = _rng(name, seed)
-        leaf = name.rsplit(".", 2)
         if name.endswith(".weight") and len(shape) == 1:          # LayerNorm gain
             t = 1.0 + 0.1 * g.standard_normal(shape)
         elif len(shape) == 1:                                      # biases
@@ -103,7 +102,6 @@ def seeded_visual_state(cfg: TowerCfg, seed: int = 0, prefix: str = "visual.") -
                 t = t / math.sqrt(2.0 * (layer + 1))
             elif name.endswith("visual.proj") or name.endswith("positional_embedding"):
                 t = t * (50.0 * cfg.width ** -0.5)          # scale * randn with scale = width^-0.5 (transformer.py:360-362,387)
-        del leaf
         sd[name] = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
     return sd
 

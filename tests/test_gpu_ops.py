@@ -1,7 +1,6 @@
 """`-m gpu`: every HIP kernel behind the C ABI, in isolation, against its CPU reference (oracle/ops_ref.py) on
 identical seeded inputs.  Tolerances: bf16 outputs <= 4e-3 relative L2 (1 bf16 ulp = 3.9e-3 element-wise; only
 rounding flips differ), fp32 outputs <= 2e-5.  Metrics are appended to gpurun_out/ops_metrics.txt."""
-import os
 from pathlib import Path
 
 import pytest

@@ -1,7 +1,6 @@
 """Pins the CPU oracle (oracle/eva_ref.py) against golden vectors captured from the real
 reference by oracle/gen_golden.py (fixtures: tests/golden/tiny_step.npz, b16_cfg1.npz)."""
 import json
-import math
 
 import numpy as np
 import pytest
