@@ -167,6 +167,38 @@ def gen_tiny(oc):
     print("tiny losses", out["losses"], "grad_none", none)
 
 
+CURVE = dict(TINY, seed_w=7, seed_b=300, steps=24, n_batches=4, warmup=4, total=24, lr=2e-3)
+
+
+def gen_curve(oc):
+    """Loss curve of the real reference over 24 optimiser steps on the tiny tower (4 distinct batches cycled, cosine schedule with warm-up,
+    lr high enough that the loss moves by ~40 %): the `loss curve matching reference` check of the north star at a size every test can run."""
+    from training.clipself import CLIPSelf
+    from training.scheduler import cosine_lr
+    cfg = _register_tiny(oc)
+    rec = CURVE
+    student, teacher = _build(oc, cfg, rec["seed_w"]), _build(oc, cfg, rec["seed_w"])
+    student.lock_image_tower(unlocked_groups=cfg.layers)
+    student.train()
+    teacher.eval()
+    opt, _ = _optimizer(student, rec["lr"], rec["wd"])
+    sched = cosine_lr(opt, rec["lr"], rec["warmup"], rec["total"])
+    method, args = CLIPSelf(), SimpleNamespace(multiscale=False, extract_type="v2", cosine_weight=1.0)
+    losses, lrs = [], []
+    for step in range(rec["steps"]):
+        batch = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"] + step % rec["n_batches"])
+        lrs.append(sched(step))
+        opt.zero_grad()
+        out, _, _ = method(batch, student, teacher, None, "cpu", None, False, args)
+        total = sum(out.values())
+        total.backward()
+        opt.step()
+        losses.append(float(total.detach()))
+    np.savez_compressed(GOLD / "tiny_curve.npz", losses=np.array(losses, np.float64), lrs=np.array(lrs, np.float64),
+                        recipe=np.array(json.dumps(rec)))
+    print("curve", [round(x, 4) for x in losses])
+
+
 def gen_tiny14(oc):
     """L/14-shaped miniature (patch 14, hidden 341): pins the zero-padded storage paths."""
     cfg = _register_tiny(oc, tiny14_cfg())
@@ -402,6 +434,9 @@ def main():
     if "--zeroshot-only" in sys.argv:
         gen_zeroshot(oc)
         return
+    if "--curve-only" in sys.argv:
+        gen_curve(oc)
+        return
     if "--openai-only" in sys.argv:
         gen_tiny_openai(oc)
         if "--tiny-only" not in sys.argv:
@@ -414,6 +449,7 @@ def main():
     gen_tiny(oc)
     gen_tiny14(oc)
     gen_regionclip(oc)
+    gen_curve(oc)
     gen_tiny_openai(oc)
     gen_zeroshot(oc)
     gen_params(oc)
