@@ -123,5 +123,11 @@ def tiny_openai_cfg(quick_gelu: bool = False) -> TowerCfg:
                     text_vocab=64, arch="openai", quick_gelu=quick_gelu)
 
 
+def tiny_openai14_cfg() -> TowerCfg:
+    """ViT-L/14-shaped miniature of the OpenAI family: patch 14 (3*14*14 = 588 -> conv1 stored with K padded to 640), 3x3 grid."""
+    return TowerCfg(name="ViT-tiny14-test", embed_dim=64, image_size=42, patch_size=14, width=128, layers=2, head_width=64, mlp_ratio=4.0,
+                    ln_eps=1e-5, text_width=32, text_heads=2, text_layers=1, text_context=8, text_vocab=64, arch="openai")
+
+
 def cfg_dict(cfg: TowerCfg) -> dict:
     return asdict(cfg)

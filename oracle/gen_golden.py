@@ -34,7 +34,7 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
-from clipself_amd.config import tiny_cfg, tiny14_cfg, tiny_openai_cfg, get_tower_cfg          # noqa: E402
+from clipself_amd.config import tiny_cfg, tiny14_cfg, tiny_openai_cfg, tiny_openai14_cfg, get_tower_cfg          # noqa: E402
 from clipself_amd.init import seeded_visual_state, synthetic_batch  # noqa: E402
 from oracle.ref_import import import_reference                   # noqa: E402
 
@@ -251,6 +251,14 @@ def gen_tiny_openai(oc):
                 blob["roi64"] = fresh.encode_pseudo_boxes(im, [b[:, :4] for b in bx], normalize=False, extract_type="v2").numpy()
             blob["recipe"] = np.array(json.dumps(rec))
         print("tiny openai", "quick" if quick else "gelu", "losses", out["losses"], "grad_none", none)
+    # ViT-L/14-shaped miniature (patch 14: zero-padded conv1 storage), one step: features, loss, three gradients
+    cfg = tiny_openai14_cfg()
+    rec = dict(TINY, seed_w=4, seed_b=31, steps=1, unlocked=cfg.layers)
+    student, teacher, out, first, groups = _run_steps(oc, cfg, rec, cfg.image_size, cfg.image_size, build=_build_openai)
+    blob.update({"p14/losses": np.array(out["losses"], np.float64), "p14/teacher": first["teacher"].numpy(), "p14/student_roi": first["student_roi"].numpy(),
+                 "p14/recipe": np.array(json.dumps(rec))})
+    for n in ("visual.transformer.resblocks.0.attn.in_proj_weight", "visual.transformer.resblocks.1.mlp.c_proj.weight", "visual.transformer.resblocks.0.ln_1.bias"):
+        blob["p14/grad/" + n] = first["grads"][n].numpy()
     np.savez_compressed(GOLD / "tiny_openai_step.npz", **blob)
 
 

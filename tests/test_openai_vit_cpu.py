@@ -274,3 +274,41 @@ def test_oracle_vitb16_cfg1_matches_reference(golden_dir):
     for n, v in grads.items():
         if v is not None:
             assert abs(float(v.double().norm()) - norms[n]) <= 2e-4 * norms[n] + 1e-12, n
+
+
+def test_patch14_miniature_padded_conv1_storage(gold):
+    """ViT-L/14-shaped miniature: conv1's contraction 3*14*14 = 588 is stored zero-padded to 640.  Oracle against the reference's vectors;
+    engine schedule (reference ops) against the same; the padding stays exactly zero through a training step."""
+    from clipself_amd.config import tiny_openai14_cfg
+    g, _ = gold
+    rec = json.loads(str(g["p14/recipe"]))
+    cfg = tiny_openai14_cfg()
+    sd = seeded_visual_state(cfg, rec["seed_w"])
+    batch = _batches(cfg, rec, 1)[0]
+    with torch.no_grad():
+        loss, student, teacher = eva_ref.clipself_loss(sd, sd, cfg, batch)
+    assert rel(teacher, g["p14/teacher"]) < 2e-6 and rel(student, g["p14/student_roi"]) < 2e-6 and abs(float(loss) - g["p14/losses"][0]) < 2e-6
+
+    eng, teacher_eng = _engine(cfg, rec["seed_w"], True), _engine(cfg, rec["seed_w"], False)
+    assert eng.Kpe == 640 and tuple(eng.storage_of(eng.master, "visual.conv1.weight").shape) == (cfg.width, 640)
+    assert tuple(eng.p["visual.conv1.weight"].shape) == (cfg.width, 3, 14, 14)
+    images, boxes, crops = batch
+    ops, rois = eng.ops, _rois(boxes)
+    t = teacher_eng.encode_image(crops.flatten(0, 1))
+    dense, grid = eng.encode_dense(images, need_grad=True)
+    pooled = eng.roi_pool(dense, rois, grid)
+    assert grid == 3 and rel(t, g["p14/teacher"]) < 2e-2 and one_minus_cos(t, g["p14/teacher"]) < 2e-4
+    assert rel(pooled, g["p14/student_roi"]) < 2e-2 and one_minus_cos(pooled, g["p14/student_roi"]) < 2e-4
+    K, E = pooled.shape
+    stats, loss_t, dpool = torch.empty(K, 3), torch.empty(1), torch.empty(K, E)
+    ops.cosine_loss_fwd(pooled, t, stats, loss_t, 1.0)
+    ops.cosine_loss_bwd(pooled, t, stats, dpool, 1.0, 1.0)
+    eng.zero_grad()
+    eng.backward_dense(eng.roi_pool_backward(dpool, rois, images.shape[0], dense.shape[1], grid))
+    assert abs(float(loss_t) - g["p14/losses"][0]) < 5e-3
+    for k in g.files:
+        if k.startswith("p14/grad/"):
+            assert rel(eng.g[k[9:]], g[k]) < 6e-2, k
+    eng.adamw_step(1, 1e-3, 0.1)
+    pad = eng.storage_of(eng.master, "visual.conv1.weight")[:, 588:]
+    assert float(pad.abs().max()) == 0.0
