@@ -312,3 +312,44 @@ def test_patch14_miniature_padded_conv1_storage(gold):
     eng.adamw_step(1, 1e-3, 0.1)
     pad = eng.storage_of(eng.master, "visual.conv1.weight")[:, 588:]
     assert float(pad.abs().max()) == 0.0
+
+
+def test_openai_release_state_dict_reader_and_factory_paths(tmp_path, gold):
+    """`--pretrained openai` reads the release file's state dict (shape scalars dropped, fp16 -> fp32: openai.py:44-76, model.py:417-474) and
+    switches the MLP activation to QuickGELU; a plain path loads an open_clip checkpoint; both through the tiny config registered on the fly."""
+    import json as _json
+    from clipself_amd import config as cfgmod
+    from clipself_amd.open_clip import CLIP, create_model
+    from clipself_amd.open_clip.factory import load_openai_state_dict
+    g, rec = gold
+    cfg = tiny_openai_cfg()
+    src = CLIP(cfg, ops=RefOps(), trainable=False)
+    src.visual.engine.load_state(seeded_visual_state(cfg, rec["seed_w"]))
+    sd = {k: v.detach().clone().half() for k, v in src.state_dict().items()}
+    sd.update(input_resolution=torch.tensor(32), context_length=torch.tensor(8), vocab_size=torch.tensor(64))
+    torch.save(sd, tmp_path / "ViT-tiny-test.pt")
+    back = load_openai_state_dict(str(tmp_path / "ViT-tiny-test.pt"))
+    assert not ({"input_resolution", "context_length", "vocab_size"} & set(back)) and all(v.dtype == torch.float32 for v in back.values())
+    assert set(back) == set(src.state_dict())
+
+    blob = {"embed_dim": cfg.embed_dim, "vision_cfg": {"image_size": cfg.image_size, "layers": cfg.layers, "width": cfg.width, "patch_size": cfg.patch_size},
+            "text_cfg": {"context_length": cfg.text_context, "vocab_size": cfg.text_vocab, "width": cfg.text_width, "heads": cfg.text_heads,
+                         "layers": cfg.text_layers}}
+    path = cfgmod._CFG_DIR / "ViT-tiny-test.json"
+    path.write_text(_json.dumps(blob))
+    try:
+        m = create_model("ViT-tiny-test", "openai", cache_dir=str(tmp_path), ops=RefOps(), trainable=False)
+        assert m.visual.cfg.quick_gelu and type(m).__name__ == "CLIP"
+        w = "visual.transformer.resblocks.1.mlp.c_fc.weight"
+        assert torch.equal(m.state_dict()[w], sd[w].float())                          # fp16 release weights, widened exactly
+        images, _, crops = _batches(cfg, rec, 1)[0]
+        with torch.no_grad():
+            t = m.encode_image(crops.flatten(0, 1))
+        assert rel(t, g["q/teacher"]) < 2e-2                                           # QuickGELU tower of the same (fp16-rounded) weights
+        torch.save({"state_dict": {"module." + k: v for k, v in src.state_dict().items()}}, tmp_path / "ckpt.pt")
+        m2 = create_model("ViT-tiny-test", str(tmp_path / "ckpt.pt"), ops=RefOps(), trainable=False)
+        assert not m2.visual.cfg.quick_gelu and torch.equal(m2.state_dict()[w], src.state_dict()[w])
+        with pytest.raises(RuntimeError):
+            create_model("ViT-tiny-test", "openai", cache_dir=str(tmp_path / "nowhere"), ops=RefOps(), require_pretrained=True)
+    finally:
+        path.unlink()
