@@ -56,3 +56,29 @@ def test_synthetic_panoptic_val_contract():
     images, bboxes, crops, masks, masked = val.batches[0]
     assert images.shape == (3, 3, 32, 32) and bboxes.shape == (3, 4, 8) and crops.shape == (3, 4, 3, 32, 32) and masks.shape == (3, 4, 4, 4)
     assert val.embeddings.shape == (5, 16) and masks.sum(dim=(-1, -2)).min() >= 1 and set(bboxes[..., 7].unique().tolist()) <= {0.0, 1.0}
+
+
+def test_numpy_restatement_of_the_resampling_is_pillow_exact():
+    """oracle/resample_ref.py (the arithmetic cs_crop_resize_u8 implements: rounded crop box, 22-bit fixed-point bicubic taps, horizontal then
+    vertical pass with uint8 rounding, pad, normalise) against Pillow on grid cells, free boxes (down- and up-sampling), boxes sticking out of
+    the image, .5 edges and the whole-image (det transform) case."""
+    from oracle.pil_crops_ref import OPENAI_MEAN, OPENAI_STD, pil_crops
+    from oracle.resample_ref import crop_resize
+    for (H, W, size, center) in ((213, 320, 96, True), (250, 167, 64, True), (96, 130, 224, True), (240, 320, 112, False)):
+        rng = np.random.default_rng(H * 7 + W)
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        img[: H // 2, : W // 3] = (rng.integers(0, 256, (H // 2, W // 3, 1)) // 3 + 90).astype(np.uint8)
+        boxes = []
+        for M, N in ((1, 1), (2, 3), (5, 3)):
+            xs, ys = np.linspace(0, 1, N + 1) * W, np.linspace(0, 1, M + 1) * H
+            boxes += [(xs[j], ys[i], xs[j + 1], ys[i + 1]) for i in range(M) for j in range(N)]
+        for _ in range(8):
+            x0, y0 = rng.uniform(0, W * 0.6), rng.uniform(0, H * 0.6)
+            boxes.append((x0, y0, min(x0 + rng.uniform(8, W * 0.4), W), min(y0 + rng.uniform(8, H * 0.4), H)))
+        boxes += [(10.5, 20.5, 41.5, 37.5), (-7.0, -3.0, 30.0, 25.0), (W - 20.0, H - 12.0, W + 9.0, H + 5.0)]
+        if not center:
+            boxes = [(0.0, 0.0, float(W), float(H))]
+        boxes = np.asarray(boxes, np.float32)
+        want = pil_crops(img, boxes, size, center)
+        got = crop_resize(img, boxes, size, center, OPENAI_MEAN, OPENAI_STD)
+        assert got.shape == want.shape and int((got != want).sum()) == 0, (H, W, size, int((got != want).sum()))
