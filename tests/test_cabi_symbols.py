@@ -47,3 +47,25 @@ def test_every_entry_point_has_a_tensor_level_wrapper_and_a_reference_op():
         name = renamed.get(sym, sym[len("cs_"):])
         assert callable(getattr(hip.HipOps, name, None)), f"HipOps.{name} missing for {sym}"
         assert callable(getattr(RefOps, name, None)), f"RefOps.{name} missing for {sym}"
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """include/clipself_hip.h is the binding contract for non-C++ hosts: it must compile as C99 on its own, and a C program that takes the
+    address of every declared entry point must link against libclipself_hip.so (no call is made -- there is no GPU here)."""
+    import shutil
+    import subprocess
+    from clipself_amd import hip
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    if not hip.library_path().exists():
+        hip.build_library()
+    names = _declared()
+    src = tmp_path / "bind.c"
+    src.write_text('#include "clipself_hip.h"\n#include <stdio.h>\nint main(void) {\n    const void* table[] = {\n'
+                   + "".join(f"        (const void*){n},\n" for n in names)
+                   + '    };\n    printf("%d\\n", (int)(sizeof table / sizeof table[0]));\n    return 0;\n}\n')
+    lib = hip.library_path()
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(tmp_path / "bind"),
+                        f"-L{lib.parent}", "-l:" + lib.name, f"-Wl,-rpath,{lib.parent}", "-Wl,--unresolved-symbols=ignore-in-shared-libs"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
