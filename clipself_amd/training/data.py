@@ -6,6 +6,7 @@ consumes is its *output contract* (data.py:247-281):
     images [B,3,S,S], normed_boxes [B,max_boxes,5] = (x0,y0,x1,y1 in [0,1], valid in {0,1}), image_crops [B,max_boxes,3,Sc,Sc]
 `SyntheticDistillData` emits exactly that (SURVEY.md §8 M2 recipe) straight into HBM, shaped like the reference's
 DataInfo/DataLoader pair (`.dataloader.num_batches`, `.num_samples`, `.set_epoch`)."""
+import os
 from dataclasses import dataclass
 
 import torch
@@ -49,6 +50,13 @@ class DataInfo:
 
     def set_epoch(self, epoch):
         self.dataloader.epoch = epoch
+
+
+def _read_ahead(images, order, num_batches, batch_size):
+    """Tell a lazily decoding image source (training/coco_source.py:DecodedImages) the order this epoch will ask in; plain lists ignore it."""
+    hint = getattr(images, "hint", None)
+    if hint is not None:
+        hint([order[(b * batch_size + j) % len(order)] for b in range(num_batches) for j in range(batch_size)])
 
 
 def grid_choices(max_split):
@@ -118,6 +126,7 @@ class GpuGridDistillLoader:
         order = list(range(len(self.images)))
         random_order = __import__("random").Random(1000 + self.epoch)
         random_order.shuffle(order)
+        _read_ahead(self.images, order, self.num_batches, self.batch_size)
         for b in range(self.num_batches):
             parts = [self.sample(self.images[order[(b * self.batch_size + j) % len(order)]])[:3] for j in range(self.batch_size)]
             yield tuple(torch.stack([p[i] for p in parts]) for i in range(3))
@@ -170,6 +179,7 @@ class GpuProposalDistillLoader:
     def __iter__(self):
         order = list(range(len(self.images)))
         __import__("random").Random(1000 + self.epoch).shuffle(order)
+        _read_ahead(self.images, order, self.num_batches, self.batch_size)
         for b in range(self.num_batches):
             ids = [order[(b * self.batch_size + j) % len(order)] for j in range(self.batch_size)]
             parts = [self.sample(self.images[i], self.anns[i])[:3] for i in ids]
@@ -210,6 +220,28 @@ class _ValLoader:
         return iter(self.dataset.batches)
 
 
+def coco_train_loader(args, ops=None):
+    """`--train-data <instances|proposals>.json --train-image-root <dir>` as in the reference's scripts: the annotation file is indexed and the
+    image files decoded on the host (training/coco_source.py), crops / det image / boxes are produced on the GPU by the loaders above."""
+    from .coco_source import AnnotationBoxes, CocoIndex, DecodedImages, subset_ids
+    if ops is None:
+        from ..hip import HipOps
+        ops = HipOps()
+    index = CocoIndex(args.train_data)
+    rank, world = getattr(args, "rank", 0), getattr(args, "world_size", 1)
+    ids = subset_ids(index, getattr(args, "train_ratio", 1.0) if args.dataset_type == "grid_distill" else 1.0, rank, world, seed=args.seed)
+    images = DecodedImages(index, args.train_image_root, args.device, image_ids=ids, workers=max(getattr(args, "workers", 1), 1) * 4,
+                           seed=args.seed + rank)
+    size, seed = args.det_image_size, 1234 + args.seed + 7919 * rank
+    if args.dataset_type == "proposals_distill":
+        return GpuProposalDistillLoader(images, AnnotationBoxes(images), ops, args.batch_size, size, args.input_size, min_size=args.min_size,
+                                        max_size=args.max_size, seed=seed)
+    if args.dataset_type == "grid_distill":
+        return GpuGridDistillLoader(images, ops, args.batch_size, args.max_boxes, size, args.input_size, max_split=args.max_split,
+                                    crop_scale=args.crop_scale, seed=seed)
+    raise NotImplementedError(f"--dataset-type {args.dataset_type} from annotation files (RegionCLIP needs the noun-label files the reference does not ship)")
+
+
 def get_data(args, preprocess_fns=None, epoch=0, tokenizer=None):
     if args.train_data == "synthetic-raw":
         # decoded images of assorted sizes (uint8, HWC, in HBM) through the GPU grid-distill pipeline
@@ -234,10 +266,12 @@ def get_data(args, preprocess_fns=None, epoch=0, tokenizer=None):
             loader = GpuGridDistillLoader(images, HipOps(), args.batch_size, args.max_boxes, size, args.input_size, max_split=args.max_split,
                                           crop_scale=args.crop_scale, steps=args.synthetic_steps, seed=seed)
         return {"train": DataInfo(loader)}
+    if args.train_data and args.train_data not in ("synthetic",) and os.path.isfile(args.train_data):
+        return {"train": DataInfo(coco_train_loader(args))}
     if args.train_data != "synthetic":
         raise NotImplementedError(
-            "only --train-data synthetic is wired in this build: the COCO/LVIS PIL pipeline is host-side and out of "
-            "scope of the MI355X hot path (SURVEY.md §8 N3); any iterable yielding the batch contract can be plugged in")
+            f"--train-data {args.train_data!r}: expected a COCO-style annotation file (decoded on the host, cropped / resized on the GPU: "
+            "training/coco_source.py), 'synthetic' or 'synthetic-raw'; the panoptic validation files are not read by this build")
     size = args.synthetic_image_size or args.det_image_size
     loader = _SyntheticLoader(args.synthetic_steps, args.batch_size, args.max_boxes, size, args.input_size,
                               args.device, args.rank, args.world_size, seed=1234 + args.seed,

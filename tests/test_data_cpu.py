@@ -82,3 +82,84 @@ def test_numpy_restatement_of_the_resampling_is_pillow_exact():
         want = pil_crops(img, boxes, size, center)
         got = crop_resize(img, boxes, size, center, OPENAI_MEAN, OPENAI_STD)
         assert got.shape == want.shape and int((got != want).sum()) == 0, (H, W, size, int((got != want).sum()))
+
+
+def _write_coco(tmp_path, with_anns=True):
+    """Six image files of assorted sizes and formats (one corrupt, one under 10 px) + a COCO-style json (one entry named by coco_url)."""
+    import json
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    root = tmp_path / "images"
+    (root / "val2017").mkdir(parents=True)
+    specs = [("a.png", 120, 200), ("b.jpg", 150, 90), ("val2017/c.png", 64, 64), ("d.png", 97, 131), ("tiny.png", 5, 5), ("broken.jpg", 0, 0)]
+    images, anns = [], []
+    for k, (name, h, w) in enumerate(specs):
+        if name == "broken.jpg":
+            (root / name).write_bytes(b"not an image")
+        else:
+            mode = "L" if name == "d.png" else "RGB"                       # a grey-scale file: the reference converts to RGB too
+            arr = rng.integers(0, 256, (h, w) if mode == "L" else (h, w, 3), dtype=np.uint8)
+            Image.fromarray(arr, mode=mode).save(root / name, quality=92)
+        info = {"id": 100 + k, "height": h, "width": w}
+        if name.startswith("val2017/"):
+            info["coco_url"] = "http://images.cocodataset.org/val2017/c.png"
+        else:
+            info["file_name"] = name
+        images.append(info)
+        if with_anns:
+            for j in range(k + 1):
+                anns.append({"id": 1000 + 10 * k + j, "image_id": 100 + k, "bbox": [3.0 * j, 2.0 * j, 20.0 + 5 * j, 12.0 + 7 * j], "category_id": 1})
+    path = tmp_path / "ann.json"
+    path.write_text(json.dumps({"images": images, "annotations": anns}))
+    return path, root
+
+
+def test_coco_files_feed_the_gpu_loaders_like_preloaded_images(tmp_path):
+    """training/coco_source.py: annotation json + image files -> lazily decoded images (read-ahead threads) -> the same batches as the
+    loaders produce from a preloaded list; unreadable and under-10-px files fall back to another sample, annotations follow the image."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from clipself_amd.training.coco_source import AnnotationBoxes, CocoIndex, DecodedImages, subset_ids
+    from clipself_amd.training.data import coco_train_loader
+    path, root = _write_coco(tmp_path)
+    index = CocoIndex(str(path))
+    assert index.image_ids == [100, 101, 102, 103, 104, 105] and len(index.imgToAnns[103]) == 4
+    assert CocoIndex.file_name(index.imgs[102]) == "val2017/c.png"
+    good = [0, 1, 2, 3]
+    lazy = DecodedImages(index, str(root), "cpu", image_ids=[100, 101, 102, 103], workers=3, depth=2)
+    pre = [torch.from_numpy(np.asarray(Image.open(lazy.path_of(i)).convert("RGB")).copy()) for i in good]
+    assert all(torch.equal(lazy[i], pre[i]) for i in good) and lazy[3].shape == (97, 131, 3)
+    anns = AnnotationBoxes(lazy)
+    assert anns[2] == [[0.0, 0.0, 20.0, 12.0], [3.0, 2.0, 25.0, 19.0], [6.0, 4.0, 30.0, 26.0]]
+    kw = dict(batch_size=2, det_size=64, crop_size=32, steps=3, seed=3)
+    a = list(GpuGridDistillLoader(lazy, RefOps(), max_boxes=5, max_split=4, crop_scale=1.5, **kw))
+    b = list(GpuGridDistillLoader(pre, RefOps(), max_boxes=5, max_split=4, crop_scale=1.5, **kw))
+    assert len(a) == 3 and all(torch.equal(x, y) for ba, bb in zip(a, b) for x, y in zip(ba, bb))
+    a = list(GpuProposalDistillLoader(lazy, anns, RefOps(), min_size=8, max_size=1024, **kw))
+    b = list(GpuProposalDistillLoader(pre, [anns[i] for i in good], RefOps(), min_size=8, max_size=1024, **kw))
+    assert all(torch.equal(x, y) for ba, bb in zip(a, b) for x, y in zip(ba, bb))
+
+    # fallback: positions 4 (5x5 px) and 5 (corrupt) are served by another sample, and the annotation view follows
+    every = DecodedImages(index, str(root), "cpu", workers=2, depth=4, seed=1)
+    every.hint([5, 4, 0])
+    j, img = every.resolve(5)
+    assert j in good and torch.equal(img, pre[j]) and AnnotationBoxes(every)[5] == anns[j]
+    j4, _ = every.resolve(4)
+    assert j4 in good
+
+    # sharding and the train_ratio subset are the same on every rank
+    assert subset_ids(index, 1.0, 0, 2) == [100, 102, 104] and subset_ids(index, 1.0, 1, 2) == [101, 103, 105]
+    half = [subset_ids(index, 0.5, r, 1, seed=9) for r in range(2)]
+    assert half[0] == half[1] and len(half[0]) == 3
+
+    # the entrypoint's data hook: --train-data <json> --train-image-root <dir>
+    args = SimpleNamespace(train_data=str(path), train_image_root=str(root), dataset_type="grid_distill", device="cpu", rank=0, world_size=1, seed=0,
+                           train_ratio=1.0, workers=1, det_image_size=64, input_size=32, batch_size=2, max_boxes=4, max_split=3, crop_scale=1.0,
+                           min_size=8, max_size=1024)
+    loader = coco_train_loader(args, ops=RefOps())
+    assert loader.num_batches == 3
+    images, boxes, crops = next(iter(loader))
+    assert images.shape == (2, 3, 64, 64) and boxes.shape == (2, 4, 5) and crops.shape == (2, 4, 3, 32, 32) and float(boxes[..., 4].sum()) >= 2
+    args.dataset_type = "proposals_distill"
+    images, boxes, crops = next(iter(coco_train_loader(args, ops=RefOps())))
+    assert boxes.shape == (2, 20, 5) and crops.shape == (2, 20, 3, 32, 32)

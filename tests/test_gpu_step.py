@@ -609,3 +609,23 @@ def test_loss_curve_follows_the_reference_over_24_steps(golden_dir):
     from test_loss_curve_cpu import run_curve
     worst, losses = run_curve(golden_dir, HipOps(), "cuda")
     _log(f"24-step loss curve: worst |loss - reference| = {worst:.3e}; last {losses[-1]:.4f}")
+
+
+def test_training_main_reads_coco_files(tmp_path):
+    """`--train-data <annotation json> --train-image-root <dir>` as in the reference's scripts: files decoded on the host (read-ahead threads),
+    crops / det images produced by cs_crop_resize_u8, CLIPSelf steps through training.main."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    from test_data_cpu import _write_coco
+    root = Path(__file__).resolve().parent.parent
+    ann, images = _write_coco(tmp_path)
+    cmd = [sys.executable, "-m", "clipself_amd.training.main", "--model", "EVA02-CLIP-B-16", "--pretrained", "eva", "--train-data", str(ann),
+           "--train-image-root", str(images), "--dataset-type", "grid_distill", "--batch-size", "2", "--max-boxes", "4", "--max-split", "3",
+           "--det-image-size", "224", "--epochs", "1", "--lock-image", "--lock-image-unlocked-groups", "2", "--lr", "1e-5", "--wd", "0.1",
+           "--warmup", "10", "--log-every-n-steps", "1", "--logs", str(tmp_path / "logs"), "--cache-dir", "none.pt", "--name", "coco",
+           "--zeroshot-frequency", "0", "--val-data", ""]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("Train Epoch: 0") == 3 and "Loss_cosine" in r.stderr           # 6 files -> 3 batches of 2
+    assert "Cannot load" in r.stdout and "Invalid image" in r.stdout                       # the corrupt and the 5x5 file fell back
