@@ -143,3 +143,108 @@ def subset_ids(index: CocoIndex, train_ratio: float, rank: int = 0, world: int =
         ids = ids[:usable][rank::world] if usable else ids
     logging.info(f"coco source: {len(ids)} images on rank {rank} of {world}")
     return ids
+
+
+# ------------------------------------------------------------------------------------------------------------------ panoptic validation set
+def rgb2id(color: np.ndarray) -> np.ndarray:
+    """Segment ids of a COCO-panoptic PNG (panopticapi convention: R + 256 G + 256^2 B)."""
+    c = color.astype(np.int64)
+    return c[..., 0] + 256 * c[..., 1] + 256 * 256 * c[..., 2]
+
+
+class CocoPanopticVal:
+    """The reference's validation set (COCOPanopticDataset, src/training/data.py:283-387; index as COCOPanoptic, src/training/coco_api.py:52-112)
+    with the pixel work on the GPU: per image one batch (the reference evaluates with batch size 1, data.py:484-487) of
+        images [1,3,S,S], bboxes [1,K,8] = (x0,y0,x1,y1 in [0,1] of the padded square, class, valid, area, is_thing),
+        image_crops [1,K,3,Sc,Sc], gt_masks [1,K,S/f,S/f], masked_image_crops [1,K,3,Sc,Sc]
+    K = min(max segments per image, 100).  Things use their box enlarged 1.5x (clipped) as the crop, stuff the bounding box of its segment
+    (`mask2box`: inclusive max coordinates, training/utils.py:25-30); areas outside [8^2, 1024^2] px are skipped; masks are the segment
+    resized like `ResizeLongest(S / f)` does for tensors (bicubic, then > 0) -- torchvision's tensor resize is not pinned by the reference,
+    the anti-aliased form of current releases is used.  `masked_image_crops` (crops of the image with everything outside the segment set to
+    114) are produced only with masked_crops=True: zero_shot.run never reads them (zero_shot.py:30-75)."""
+
+    def __init__(self, annotation_file, image_root, segm_root, embed_path, ops, device, det_size, crop_size, downsample_factor=16, rank=0,
+                 world=1, masked_crops=False):
+        with open(annotation_file) as f:
+            blob = json.load(f)
+        self.imgs = OrderedDict()
+        for info in blob.get("images", []):
+            info = dict(info, segm_file=info["file_name"].replace("jpg", "png"))
+            self.imgs[info["id"]] = info
+        self.img_to_anns = defaultdict(list)
+        for ann in blob.get("annotations", []):
+            for seg in ann["segments_info"]:
+                self.img_to_anns[ann["image_id"]].append(dict(seg, image_id=ann["image_id"]))
+        self.cats = {c["id"]: c for c in blob.get("categories", [])}
+        self.cat_id2label = {cid: i for i, cid in enumerate(sorted(self.cats))}
+        self.embeddings = np.load(embed_path)
+        self.image_ids = list(self.imgs.keys())[rank::world] if world > 1 else list(self.imgs.keys())
+        self.max_anns = min(max((len(v) for v in self.img_to_anns.values()), default=1), 100)
+        self.image_root, self.segm_root, self.ops, self.device = image_root, segm_root, ops, torch.device(device)
+        self.det_size, self.crop_size, self.mask_size = det_size, crop_size, det_size // downsample_factor
+        self.min_size, self.max_size, self.masked_crops = 8, 1024, masked_crops
+        self.batches = self                      # `_ValLoader`-style consumers iterate `dataset.batches`
+
+    def __len__(self):
+        return len(self.image_ids)
+
+    def _mask(self, segment: np.ndarray) -> torch.Tensor:
+        H, W = segment.shape
+        scale = self.mask_size / float(max(H, W))
+        nh, nw = round(H * scale), round(W * scale)
+        m = torch.from_numpy(segment).float()[None, None]
+        m = torch.nn.functional.interpolate(m, size=(nh, nw), mode="bicubic", align_corners=False, antialias=True)[0, 0]
+        out = torch.zeros(self.mask_size, self.mask_size)
+        out[:nh, :nw] = (m > 0.0).float()
+        return out
+
+    def item(self, idx: int):
+        from PIL import Image
+        info = self.imgs[self.image_ids[idx]]
+        image = decode_rgb(os.path.join(self.image_root, info["file_name"]))
+        if image is None:
+            raise RuntimeError(f"validation image {info['file_name']} cannot be read")
+        with Image.open(os.path.join(self.segm_root, info["segm_file"])) as im:
+            segm = rgb2id(np.array(im.convert("RGB"), dtype=np.uint8))
+        H, W = image.shape[:2]
+        dev, K = self.device, self.max_anns
+        img = torch.from_numpy(image).to(dev)
+        boxes, masks = torch.zeros(K, 8), torch.zeros(K, self.mask_size, self.mask_size)
+        slots, crop_px, segments = [], [], []
+        for i, ann in enumerate(self.img_to_anns[info["id"]][:K]):
+            is_thing = self.cats[ann["category_id"]]["isthing"]
+            segment = segm == ann["id"]
+            if is_thing > 0:
+                x, y, w, h = ann["bbox"]
+                cx, cy = x + w * 0.5, y + h * 0.5
+                crop = [max(cx - w * 0.75, 0), max(cy - h * 0.75, 0), min(cx + w * 0.75, W), min(cy + h * 0.75, H)]
+            else:
+                if not segment.any():
+                    continue
+                ys, xs = np.where(segment)
+                crop = [float(xs.min()), float(ys.min()), float(xs.max()), float(ys.max())]
+                x, y, w, h = crop[0], crop[1], crop[2] - crop[0], crop[3] - crop[1]
+            if w * h < self.min_size ** 2 or w * h > self.max_size ** 2:
+                continue
+            boxes[i] = torch.tensor([x, y, x + w, y + h, self.cat_id2label[ann["category_id"]], 1.0, w * h, is_thing], dtype=torch.float32)
+            masks[i] = self._mask(segment)
+            slots.append(i)
+            crop_px.append(crop)
+            segments.append(segment)
+        crops = torch.zeros(K, 3, self.crop_size, self.crop_size, device=dev)
+        masked = torch.zeros(K, 3, self.crop_size, self.crop_size, device=dev)
+        if slots:
+            px = torch.tensor(crop_px, dtype=torch.float32, device=dev)
+            crops[slots] = self.ops.crop_resize(img, px, self.crop_size, pad_center=True)
+            if self.masked_crops:
+                for s, segment, box in zip(slots, segments, crop_px):
+                    grey = image.copy()
+                    grey[~segment] = 114
+                    masked[s] = self.ops.crop_resize(torch.from_numpy(grey).to(dev), px.new_tensor([box]), self.crop_size, pad_center=True)[0]
+        det = self.ops.crop_resize(img, torch.tensor([[0.0, 0.0, float(W), float(H)]], device=dev), self.det_size, pad_center=False)[0]
+        boxes[:, :4] *= min(self.det_size / H, self.det_size / W) / self.det_size
+        return det[None], boxes[None].to(dev), crops[None], masks[None].to(dev), masked[None]
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self.item(i)

@@ -214,7 +214,8 @@ class SyntheticPanopticVal:
 class _ValLoader:
     def __init__(self, dataset):
         self.dataset = dataset
-        self.num_batches, self.num_samples = len(dataset), sum(len(b[0]) for b in dataset.batches)
+        streaming = dataset.batches is dataset                  # CocoPanopticVal: one image per batch, produced on the fly
+        self.num_batches, self.num_samples = len(dataset), len(dataset) if streaming else sum(len(b[0]) for b in dataset.batches)
 
     def __iter__(self):
         return iter(self.dataset.batches)
@@ -242,6 +243,32 @@ def coco_train_loader(args, ops=None):
     raise NotImplementedError(f"--dataset-type {args.dataset_type} from annotation files (RegionCLIP needs the noun-label files the reference does not ship)")
 
 
+def coco_panoptic_val(args, ops=None):
+    """`--val-data <panoptic json> --val-image-root <dir> --val-segm-root <dir> --embed-path <npy>` (get_coco_panoptic_dataset, data.py:457-497)."""
+    from .coco_source import CocoPanopticVal
+    if ops is None:
+        from ..hip import HipOps
+        ops = HipOps()
+    return CocoPanopticVal(args.val_data, args.val_image_root, args.val_segm_root, args.embed_path, ops, args.device, args.det_image_size,
+                           args.input_size, downsample_factor=args.downsample_factor, rank=getattr(args, "rank", 0) if args.distributed else 0,
+                           world=getattr(args, "world_size", 1) if args.distributed else 1)
+
+
+def _with_val(data, args):
+    """Adds data['val']: `--val-data synthetic` (seeded panoptic-style batches) or a COCO-panoptic annotation file; anything else (e.g. the
+    reference's default path when that file does not exist) means no evaluation."""
+    val = getattr(args, "val_data", None)
+    if val == "synthetic":
+        cfg = args.tower_cfg
+        size = getattr(args, "synthetic_image_size", None) or args.det_image_size
+        ds = SyntheticPanopticVal(2, min(args.batch_size, 4), min(args.max_boxes, 6), size, args.input_size, size // cfg.patch_size,
+                                  cfg.embed_dim, seed=4321 + args.seed)
+        data["val"] = DataInfo(_ValLoader(ds))
+    elif val and os.path.isfile(val):
+        data["val"] = DataInfo(_ValLoader(coco_panoptic_val(args)))
+    return data
+
+
 def get_data(args, preprocess_fns=None, epoch=0, tokenizer=None):
     if args.train_data == "synthetic-raw":
         # decoded images of assorted sizes (uint8, HWC, in HBM) through the GPU grid-distill pipeline
@@ -265,22 +292,20 @@ def get_data(args, preprocess_fns=None, epoch=0, tokenizer=None):
         else:
             loader = GpuGridDistillLoader(images, HipOps(), args.batch_size, args.max_boxes, size, args.input_size, max_split=args.max_split,
                                           crop_scale=args.crop_scale, steps=args.synthetic_steps, seed=seed)
-        return {"train": DataInfo(loader)}
-    if args.train_data and args.train_data not in ("synthetic",) and os.path.isfile(args.train_data):
-        return {"train": DataInfo(coco_train_loader(args))}
+        return _with_val({"train": DataInfo(loader)}, args)
+    if args.train_data and args.train_data != "synthetic" and os.path.isfile(args.train_data):
+        return _with_val({"train": DataInfo(coco_train_loader(args))}, args)
+    if not args.train_data:                                             # evaluation-only runs (scripts/test_*.sh: --train-data "")
+        data = _with_val({}, args)
+        if data:
+            return data
     if args.train_data != "synthetic":
         raise NotImplementedError(
             f"--train-data {args.train_data!r}: expected a COCO-style annotation file (decoded on the host, cropped / resized on the GPU: "
-            "training/coco_source.py), 'synthetic' or 'synthetic-raw'; the panoptic validation files are not read by this build")
+            "training/coco_source.py), 'synthetic' or 'synthetic-raw'")
     size = args.synthetic_image_size or args.det_image_size
     loader = _SyntheticLoader(args.synthetic_steps, args.batch_size, args.max_boxes, size, args.input_size,
                               args.device, args.rank, args.world_size, seed=1234 + args.seed,
                               valid_prob=0.7 if args.dataset_type == "proposals_distill" else 1.0, resident=False)
     loader.region_clip = args.dataset_type == "region_clip"
-    data = {"train": DataInfo(loader)}
-    if getattr(args, "val_data", None) == "synthetic":
-        cfg = args.tower_cfg
-        val = SyntheticPanopticVal(2, min(args.batch_size, 4), min(args.max_boxes, 6), size, args.input_size, size // cfg.patch_size,
-                                   cfg.embed_dim, seed=4321 + args.seed)
-        data["val"] = DataInfo(_ValLoader(val))
-    return data
+    return _with_val({"train": DataInfo(loader)}, args)

@@ -131,6 +131,8 @@ def main(argv):
     args.save_logs = args.logs and args.logs.lower() != "none" and is_master(args)
     os.makedirs(args.checkpoint_path, exist_ok=True)
     evaluate(model, data, start_epoch, args)
+    if "train" not in data:                                     # main.py:258-263: evaluation-only run (scripts/test_*.sh: --train-data "")
+        return 0
 
     for epoch in range(start_epoch, args.epochs):
         if is_master(args):

@@ -163,3 +163,82 @@ def test_coco_files_feed_the_gpu_loaders_like_preloaded_images(tmp_path):
     args.dataset_type = "proposals_distill"
     images, boxes, crops = next(iter(coco_train_loader(args, ops=RefOps())))
     assert boxes.shape == (2, 20, 5) and crops.shape == (2, 20, 3, 32, 32)
+
+
+def _write_panoptic(tmp_path):
+    """Two images + COCO-panoptic style files: <segm_root>/<name>.png with segment ids encoded as R + 256 G + 256^2 B, a json with
+    segments_info (things carry a bbox, stuff is located through its mask) and categories with `isthing`, class embeddings as .npy."""
+    import json
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    img_root, seg_root = tmp_path / "val", tmp_path / "panoptic"
+    img_root.mkdir(), seg_root.mkdir()
+    cats = [{"id": 7, "name": "thing-a", "isthing": 1}, {"id": 3, "name": "stuff-b", "isthing": 0}, {"id": 21, "name": "thing-c", "isthing": 1}] + \
+           [{"id": 40 + i, "name": f"unused-{i}", "isthing": i % 2} for i in range(3)]          # top-5 needs more than five classes
+    images, annotations = [], []
+    layouts = {"p.jpg": (96, 128, [(300, 7, (10, 20, 50, 40)), (70000, 3, (64, 8, 60, 80)), (5, 21, (0, 70, 6, 5))]),      # last: 30 px^2 -> skipped
+               "q.jpg": (80, 80, [(9, 3, (0, 0, 80, 30)), (1234567, 21, (20, 40, 40, 30))])}
+    for k, (name, (H, W, segs)) in enumerate(layouts.items()):
+        Image.fromarray(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).save(img_root / name, quality=95)
+        ids = np.zeros((H, W), np.int64)
+        info = []
+        for sid, cat, (x, y, w, h) in segs:
+            ids[y:y + h, x:x + w] = sid
+            info.append({"id": sid, "category_id": cat, "bbox": [x, y, w, h], "area": w * h, "iscrowd": 0})
+        png = np.stack([ids % 256, (ids // 256) % 256, ids // 65536], -1).astype(np.uint8)
+        Image.fromarray(png).save(seg_root / name.replace("jpg", "png"))
+        images.append({"id": 50 + k, "file_name": name, "height": H, "width": W})
+        annotations.append({"image_id": 50 + k, "file_name": name.replace("jpg", "png"), "segments_info": info})
+    ann = tmp_path / "panoptic.json"
+    ann.write_text(json.dumps({"images": images, "annotations": annotations, "categories": cats}))
+    emb = tmp_path / "emb.npy"
+    np.save(emb, rng.standard_normal((6, 64)).astype(np.float32))
+    return ann, img_root, seg_root, emb
+
+
+def test_panoptic_validation_files_feed_the_zero_shot_evaluation(tmp_path):
+    """training/coco_source.py:CocoPanopticVal -- the reference's COCOPanopticDataset contract (data.py:283-387) from real files -- and
+    zero_shot.run / macc_with_is_thing on top of it with the tiny tower on the reference ops."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from clipself_amd.config import tiny_cfg
+    from clipself_amd.init import seeded_visual_state
+    from clipself_amd.open_clip.model import CustomCLIP
+    from clipself_amd.training.coco_source import CocoPanopticVal, rgb2id
+    from clipself_amd.training.zero_shot import zero_shot_eval
+    from oracle.pil_crops_ref import pil_crops
+    ann, img_root, seg_root, emb = _write_panoptic(tmp_path)
+    ds = CocoPanopticVal(str(ann), str(img_root), str(seg_root), str(emb), RefOps(), "cpu", det_size=32, crop_size=32, downsample_factor=8)
+    assert len(ds) == 2 and ds.max_anns == 3 and ds.mask_size == 4 and ds.cat_id2label == {3: 0, 7: 1, 21: 2, 40: 3, 41: 4, 42: 5} and ds.embeddings.shape == (6, 64)
+    assert int(rgb2id(np.array([[[7, 1, 2]]], np.uint8))[0, 0]) == 7 + 256 + 2 * 65536
+    images, boxes, crops, masks, masked = ds.item(0)
+    assert images.shape == (1, 3, 32, 32) and boxes.shape == (1, 3, 8) and crops.shape == (1, 3, 3, 32, 32) and masks.shape == (1, 3, 4, 4)
+    b = boxes[0]
+    s = min(32 / 96, 32 / 128) / 32                                   # pixels -> fraction of the padded square
+    assert torch.allclose(b[0], torch.tensor([10 * s, 20 * s, 60 * s, 60 * s, 1.0, 1.0, 2000.0, 1.0]))            # thing: its bbox
+    assert torch.allclose(b[1], torch.tensor([64 * s, 8 * s, 123 * s, 87 * s, 0.0, 1.0, 59.0 * 79.0, 0.0]))       # stuff: mask2box (inclusive max)
+    assert float(b[2].abs().sum()) == 0.0 and float(crops[0, 2].abs().sum()) == 0.0                                # 30 px^2 < 8^2: empty slot
+    img = np.asarray(Image.open(img_root / "p.jpg").convert("RGB"))
+    want = pil_crops(img, np.array([[0.0, 10.0, 72.5, 70.0], [64.0, 8.0, 123.0, 87.0]], np.float32), 32, True)      # thing: 1.5x box, clipped
+    assert torch.equal(crops[0, :2], torch.from_numpy(want))
+    assert torch.equal(images[0], torch.from_numpy(pil_crops(img, np.array([[0, 0, 128, 96]], np.float32), 32, False))[0])
+    m = masks[0]
+    # a 4x4 map of the 96x128 image (last row = padding): the bicubic resize + '> 0' dilates by the kernel's positive lobe, not further
+    assert m[0].sum() > 0 and m[1].sum() > 0 and m[2].sum() == 0 and m[1][:, 0].sum() == 0 and m[0][:, 3].sum() == 0 and m[:, 3].sum() == 0
+    assert float(masked.abs().sum()) == 0.0
+    _, _, _, _, masked = CocoPanopticVal(str(ann), str(img_root), str(seg_root), str(emb), RefOps(), "cpu", 32, 32, 8, masked_crops=True).item(0)
+    assert float(masked[0, 0].abs().sum()) > 0 and not torch.equal(masked[0, 0], crops[0, 0])
+
+    cfg = tiny_cfg()
+    model = CustomCLIP(cfg, ops=RefOps(), trainable=False)
+    model.visual.engine.load_state(seeded_visual_state(cfg, 3))
+    args = SimpleNamespace(device="cpu", precision="fp32", distributed=False, horovod=False, extract_type="v2", image_ave_pool=False, rank=0,
+                           local_rank=0, world_size=1, zeroshot_frequency=1, epochs=1, val_data=str(ann), val_image_root=str(img_root),
+                           val_segm_root=str(seg_root), embed_path=str(emb), det_image_size=32, input_size=32, downsample_factor=8,
+                           train_data="", batch_size=1, max_boxes=4, seed=0)
+    from clipself_amd.training.data import DataInfo, _ValLoader, coco_panoptic_val
+    data = {"val": DataInfo(_ValLoader(coco_panoptic_val(args, ops=RefOps())))}       # what get_data() builds with the HIP ops
+    assert data["val"].dataloader.num_batches == 2 and data["val"].dataloader.num_samples == 2
+    metrics = zero_shot_eval(model, data, 1, args)
+    assert {"rois.thing.macc1", "crops.thing.macc5", "maskpool.stuff.macc1"} <= set(metrics), sorted(metrics)
+    assert all(0.0 <= v <= 1.0 for v in metrics.values())
