@@ -7,6 +7,7 @@ consumes is its *output contract* (data.py:247-281):
 `SyntheticDistillData` emits exactly that (SURVEY.md §8 M2 recipe) straight into HBM, shaped like the reference's
 DataInfo/DataLoader pair (`.dataloader.num_batches`, `.num_samples`, `.set_epoch`)."""
 import os
+import random
 from dataclasses import dataclass
 
 import torch
@@ -80,7 +81,6 @@ class GpuGridDistillLoader:
     random draws use Python's `random` exactly where the reference does."""
 
     def __init__(self, images_u8, ops, batch_size, max_boxes, det_size, crop_size, max_split=6, crop_scale=1.0, steps=None, seed=0):
-        import random
         self.images, self.ops = images_u8, ops
         self.batch_size, self.max_boxes, self.det_size, self.crop_size = batch_size, max_boxes, det_size, crop_size
         self.crop_scale = crop_scale
@@ -124,8 +124,7 @@ class GpuGridDistillLoader:
 
     def __iter__(self):
         order = list(range(len(self.images)))
-        random_order = __import__("random").Random(1000 + self.epoch)
-        random_order.shuffle(order)
+        random.Random(1000 + self.epoch).shuffle(order)
         _read_ahead(self.images, order, self.num_batches, self.batch_size)
         for b in range(self.num_batches):
             parts = [self.sample(self.images[order[(b * self.batch_size + j) % len(order)]])[:3] for j in range(self.batch_size)]
@@ -139,7 +138,6 @@ class GpuProposalDistillLoader:
     (data.py:111-118), fallback to the top-left quarter image when nothing is valid (:122-124), boxes rescaled to the padded square."""
 
     def __init__(self, images_u8, annotations, ops, batch_size, det_size, crop_size, min_size=8, max_size=1024, max_anns=20, steps=None, seed=0):
-        import random
         self.images, self.anns, self.ops = images_u8, annotations, ops
         self.batch_size, self.det_size, self.crop_size = batch_size, det_size, crop_size
         self.min_size, self.max_size, self.max_anns = min_size, max_size, max_anns
@@ -178,7 +176,7 @@ class GpuProposalDistillLoader:
 
     def __iter__(self):
         order = list(range(len(self.images)))
-        __import__("random").Random(1000 + self.epoch).shuffle(order)
+        random.Random(1000 + self.epoch).shuffle(order)
         _read_ahead(self.images, order, self.num_batches, self.batch_size)
         for b in range(self.num_batches):
             ids = [order[(b * self.batch_size + j) % len(order)] for j in range(self.batch_size)]
