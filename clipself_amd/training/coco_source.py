@@ -31,6 +31,8 @@ class CocoIndex:
         for ann in blob.get("annotations", []):
             self.imgToAnns[ann["image_id"]].append(ann)
         self.image_ids = list(self.imgs.keys())
+        self.cats = {c["id"]: c for c in blob.get("categories", [])}
+        self.cat_id2label = {cid: i for i, cid in enumerate(sorted(self.cats))}        # data.py:312-314,414-416
 
     @staticmethod
     def file_name(info: dict) -> str:
@@ -77,6 +79,18 @@ class DecodedImages:
 
     def annotations_of(self, i: int):
         return self.index.imgToAnns[self.image_ids[i]]
+
+    def annotation_view(self):
+        """List-like view of the raw annotation dicts aligned with this image list (follows fallbacks like AnnotationBoxes)."""
+        images = self
+
+        class _View:
+            def __len__(self):
+                return len(images)
+
+            def __getitem__(self, i):
+                return images.annotations_of(images.resolved.get(i, i))
+        return _View()
 
     def hint(self, order):
         self._order, self._cursor = list(order), 0
@@ -130,11 +144,11 @@ class AnnotationBoxes:
         return [list(a["bbox"]) for a in self.images.annotations_of(i)]
 
 
-def subset_ids(index: CocoIndex, train_ratio: float, rank: int = 0, world: int = 1, seed: int = 0):
+def subset_ids(index: CocoIndex, train_ratio: float, rank: int = 0, world: int = 1, seed: int = 0, annotated_only: bool = False):
     """image ids of this rank: the `train_ratio` random subset of GridDistillDataset (data.py:150-155), then every world-th id starting at
     `rank` (what DistributedSampler hands each process, data.py:548).  The subset is drawn from a generator seeded identically on every
     rank (the reference shuffles with each process's own global `random` state, so its ranks disagree about the subset)."""
-    ids = list(index.image_ids)
+    ids = [i for i in index.image_ids if index.imgToAnns.get(i)] if annotated_only else list(index.image_ids)   # data.py:397: RegionCLIP
     if train_ratio < 1.0:
         random.Random(seed).shuffle(ids)
         ids = ids[:int(len(ids) * train_ratio)]

@@ -184,6 +184,42 @@ class GpuProposalDistillLoader:
             yield tuple(torch.stack([p[i] for p in parts]) for i in range(3))
 
 
+class GpuRegionClipLoader:
+    """COCORegionCLIPDataset (src/training/data.py:390-459) with the pixel work on the GPU: only images that have annotations, per image the
+    det transform (ResizeLongest, right/bottom padding) and up to max_anns = min(max annotations per image, 20) boxes as
+    (x0, y0, x1, y1 in [0,1] of the padded square, class label = rank of the category id, valid) -- no crops, no teacher."""
+
+    def __init__(self, images_u8, annotations, cat_id2label, ops, batch_size, det_size, max_anns=20, steps=None, seed=0):
+        self.images, self.anns, self.cat_id2label, self.ops = images_u8, annotations, cat_id2label, ops
+        self.batch_size, self.det_size, self.max_anns = batch_size, det_size, max_anns
+        self.num_batches = steps if steps is not None else len(images_u8) // batch_size
+        self.num_samples = self.num_batches * batch_size
+        self.epoch = 0
+
+    def __len__(self):
+        return self.num_batches
+
+    def sample(self, img, anns):
+        H, W = img.shape[0], img.shape[1]
+        dev = img.device
+        boxes = torch.zeros(self.max_anns, 6)
+        for i, a in enumerate(anns[:self.max_anns]):
+            x, y, w, h = a["bbox"]
+            boxes[i] = torch.tensor([x, y, x + w, y + h, float(self.cat_id2label[a["category_id"]]), 1.0])
+        det = self.ops.crop_resize(img, torch.tensor([[0.0, 0.0, float(W), float(H)]], device=dev), self.det_size, pad_center=False)[0]
+        boxes[:, :4] *= min(self.det_size / H, self.det_size / W) / self.det_size
+        return det, boxes.to(dev)
+
+    def __iter__(self):
+        order = list(range(len(self.images)))
+        random.Random(1000 + self.epoch).shuffle(order)
+        _read_ahead(self.images, order, self.num_batches, self.batch_size)
+        for b in range(self.num_batches):
+            ids = [order[(b * self.batch_size + j) % len(order)] for j in range(self.batch_size)]
+            parts = [self.sample(self.images[i], self.anns[i]) for i in ids]
+            yield torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts])
+
+
 class SyntheticPanopticVal:
     """Batches shaped like the panoptic validation set (src/training/data.py:331-387) plus `.embeddings`: boxes from the synthetic
     recipe, a rectangular mask per box at feature-map resolution, a class per box and a things/stuff flag per class."""
@@ -228,7 +264,8 @@ def coco_train_loader(args, ops=None):
         ops = HipOps()
     index = CocoIndex(args.train_data)
     rank, world = getattr(args, "rank", 0), getattr(args, "world_size", 1)
-    ids = subset_ids(index, getattr(args, "train_ratio", 1.0) if args.dataset_type == "grid_distill" else 1.0, rank, world, seed=args.seed)
+    ratio = getattr(args, "train_ratio", 1.0) if args.dataset_type in ("grid_distill", "region_clip") else 1.0
+    ids = subset_ids(index, ratio, rank, world, seed=args.seed, annotated_only=args.dataset_type == "region_clip")
     images = DecodedImages(index, args.train_image_root, args.device, image_ids=ids, workers=max(getattr(args, "workers", 1), 1) * 4,
                            seed=args.seed + rank)
     size, seed = args.det_image_size, 1234 + args.seed + 7919 * rank
@@ -238,7 +275,10 @@ def coco_train_loader(args, ops=None):
     if args.dataset_type == "grid_distill":
         return GpuGridDistillLoader(images, ops, args.batch_size, args.max_boxes, size, args.input_size, max_split=args.max_split,
                                     crop_scale=args.crop_scale, seed=seed)
-    raise NotImplementedError(f"--dataset-type {args.dataset_type} from annotation files (RegionCLIP needs the noun-label files the reference does not ship)")
+    if args.dataset_type == "region_clip":
+        return GpuRegionClipLoader(images, images.annotation_view(), index.cat_id2label, ops, args.batch_size, size,
+                                   max_anns=min(max((len(v) for v in index.imgToAnns.values()), default=1), 20))
+    raise NotImplementedError(f"--dataset-type {args.dataset_type}")
 
 
 def coco_panoptic_val(args, ops=None):

@@ -242,3 +242,28 @@ def test_panoptic_validation_files_feed_the_zero_shot_evaluation(tmp_path):
     metrics = zero_shot_eval(model, data, 1, args)
     assert {"rois.thing.macc1", "crops.thing.macc5", "maskpool.stuff.macc1"} <= set(metrics), sorted(metrics)
     assert all(0.0 <= v <= 1.0 for v in metrics.values())
+
+
+def test_region_clip_batches_from_coco_files(tmp_path):
+    """COCORegionCLIPDataset's contract (data.py:390-459) from files: annotated images only, boxes (xyxy in the padded square, label, valid)."""
+    import json
+    from types import SimpleNamespace
+    from clipself_amd.training.data import coco_train_loader
+    path, root = _write_coco(tmp_path)
+    blob = json.loads(path.read_text())
+    blob["categories"] = [{"id": 5, "name": "b"}, {"id": 1, "name": "a"}]
+    blob["annotations"] = [a for a in blob["annotations"] if a["image_id"] != 101]             # image 101 loses its annotations -> dropped
+    for k, a in enumerate(blob["annotations"]):
+        a["category_id"] = 5 if k % 2 else 1
+    path.write_text(json.dumps(blob))
+    args = SimpleNamespace(train_data=str(path), train_image_root=str(root), dataset_type="region_clip", device="cpu", rank=0, world_size=1, seed=0,
+                           train_ratio=1.0, workers=1, det_image_size=64, input_size=32, batch_size=2, max_boxes=4, max_split=3, crop_scale=1.0,
+                           min_size=8, max_size=1024)
+    loader = coco_train_loader(args, ops=RefOps())
+    assert len(loader.images) == 5 and loader.max_anns == 6 and loader.num_batches == 2 and loader.cat_id2label == {1: 0, 5: 1}
+    images, boxes = next(iter(loader))
+    assert images.shape == (2, 3, 64, 64) and boxes.shape == (2, 6, 6)
+    det, b = loader.sample(loader.images[3], loader.anns[3])                                    # d.png: 97 x 131, four annotations
+    s = min(64 / 97, 64 / 131) / 64
+    assert torch.allclose(b[1, :4], torch.tensor([3.0, 2.0, 28.0, 21.0]) * s) and b[:, 5].tolist() == [1, 1, 1, 1, 0, 0]
+    assert set(b[:4, 4].tolist()) <= {0.0, 1.0} and det.shape == (3, 64, 64)

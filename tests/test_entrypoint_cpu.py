@@ -89,4 +89,13 @@ def test_evaluation_only_and_training_from_files(tiny_model_config, tmp_path):
     assert _run(argv) == 0
     assert (tmp_path / "tr" / "checkpoints" / "epoch_1.pt").exists()
     assert len((tmp_path / "tr" / "checkpoints" / "results.json").read_text().strip().splitlines()) == 2
+    # scripts/train_regionclip_coco_*.sh shape: the same files with category labels, RegionCLIP method, no teacher
+    blob = json.loads(tr_ann.read_text())
+    blob["categories"] = [{"id": 1, "name": "a"}]
+    tr_ann.write_text(json.dumps(blob))
+    argv = ["--model", tiny_model_config, "--pretrained", "eva", "--train-data", tr_ann, "--train-image-root", tr_root, "--dataset-type", "region_clip",
+            "--val-data", "", "--batch-size", 2, "--det-image-size", 32, "--epochs", 1, "--lock-image", "--lock-image-unlocked-groups", 1, "--lr", 1e-3,
+            "--warmup", 1, "--logs", tmp_path, "--name", "rc", "--cache-dir", "none.pt", "--zeroshot-frequency", 0, "--alpha", 0.5]
+    assert _run(argv) == 0
+    assert (tmp_path / "rc" / "checkpoints" / "epoch_1.pt").exists()
     assert cfg_dict(tiny_cfg())["width"] == 128
