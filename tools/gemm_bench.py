@@ -154,6 +154,36 @@ def square():
         print(line, flush=True)
 
 
+def student_shapes():
+    """The student's GEMM shapes (M = images * 197 rows: forward, dgrad and the v-only last block) across tile configurations -- 50 M panels of
+    256 rows leave the N = 768 products at 150 tiles (usage: python tools/gemm_bench.py 64 student)."""
+    ops = HipOps()
+    M = int(sys.argv[1]) * 197
+    shapes = [("qkv fwd   N=2304 K=768  epi0", 2304, 768, 0), ("proj fwd  N=768  K=768  epi2", 768, 768, 2), ("w12 fwd   N=4096 K=768  epi0", 4096, 768, 0),
+              ("w3 fwd    N=768  K=2048 epi2", 768, 2048, 2), ("dgrad w3  N=2048 K=768  epi0", 2048, 768, 0), ("dgrad w12 N=768  K=4096 epi0", 768, 4096, 0),
+              ("dgrad qkv N=768  K=2304 epi0", 768, 2304, 0), ("head      N=512  K=768  epi1", 512, 768, 1)]
+    for name, N, K, epi in shapes:
+        A = torch.randn(M, K, device="cuda").to(BF)
+        B = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
+        bias = torch.randn(N, device="cuda")
+        C = torch.randn(M, N, device="cuda") if epi in (1, 2) else torch.empty(M, N, dtype=BF, device="cuda")
+        extra = C if epi == 2 else None
+        line = f"{name} M={M}: "
+        for cfg in (0, 1, 2, 4, 3, 7, 9, 8):
+            flags = cfg << 4
+            for _ in range(3):
+                ops.gemm_nt(A, B, C, bias, extra, epi=epi, flags=flags)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.gemm_nt(A, B, C, bias, extra, epi=epi, flags=flags)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 20
+            line += f"cfg{cfg} {us:6.1f} us ({2.0 * M * N * K / us / 1e6:4.0f} TF/s) | "
+        print(line, flush=True)
+
+
 def fold_ab():
     """A/B of the folded-LayerNorm operands: SwiGLU GEMM with / without the statistics output, residual GEMM with / without the
     folded epilogue, and the finalize kernel (usage: python tools/gemm_bench.py 512 fold)."""
@@ -236,4 +266,4 @@ def wgrad_ab():
 
 if __name__ == "__main__":
     mode = sys.argv[2] if len(sys.argv) > 2 else ""
-    {"fold": fold_ab, "wgrad": wgrad_ab, "raster": raster_ab, "square": square}.get(mode, main)()
+    {"fold": fold_ab, "wgrad": wgrad_ab, "raster": raster_ab, "square": square, "student": student_shapes}.get(mode, main)()
