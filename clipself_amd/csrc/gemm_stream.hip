@@ -1,0 +1,574 @@
+// Streaming persistent bf16 MFMA GEMM with register-level epilogues (gfx950) -- the default schedule of the frozen tower's GEMMs.
+//
+//   C[M,N] (+epilogue) = A[M,K] . B[N,K]^T      same operands, LDS image and 256x256x64 tile / 8 waves of 128x64 as gemm_persist_kernel
+//                                               (gemm.hip); what changes is everything around the MFMA loop:
+//
+//   * The MFMA operands are swapped: acc = mfma(B fragment, A fragment), i.e. every wave accumulates its tile TRANSPOSED.  A lane then
+//     owns one output ROW (row = lane & 31 of the 32x32 block) and its 16 accumulator registers are four groups of four CONSECUTIVE
+//     columns (col = 8*(e>>2) + 4*(lane>>5) + (e&3)).  Per-row LayerNorm statistics become per-lane scalars, four results pack into
+//     8 bytes of bf16 in registers, one v_permlane32_swap per dword pairs the two half-waves' groups into 16 contiguous bytes, and
+//     the output leaves as 16-byte row-segment stores straight from registers: no LDS slab, no ds_write/ds_read transposition, no
+//     lgkmcnt round trips in the epilogue.  Per-column constants (bias, folded-LN column sums) are fetched with ONE coalesced dword
+//     per lane and broadcast with ds_bpermute (the LDS crossbar, no LDS memory).
+//   * The operand ring runs CONTINUOUSLY across output tiles: K tile g of the workgroup's tile sequence lives in A slot g % 3 /
+//     B slot g & 1, and iteration g issues B(g+1) and A(g+2) whatever tile they belong to, so the first operands of the next output
+//     tile are in flight two K tiles before the current tile's epilogue and there is no per-tile prologue, no extra barrier.
+//   * The epilogue's stores are never waited for: vmcnt retires in order on gfx9, so the first K tile after an epilogue waits
+//     vmcnt(4 + S) with S = the fixed number of store instructions an epilogue issues (buffer stores with out-of-range offsets for
+//     masked rows / columns keep that count exact).
+//   * EARLY variant: the few per-row / per-column operands of the epilogue are loaded (inline asm, counted by hand) at the top of the
+//     tile's LAST K iteration, ahead of that iteration's operand DMA, so that consuming them does not drain the DMA queue
+//     (hipcc waits vmcnt(0) for any ordinary load while an LDS-DMA is pending).
+//
+// Epilogues: bf16 (+bias, optional GELU / QuickGELU, optional folded LayerNorm), fused SwiGLU (+folded LayerNorm, +row statistics of the
+// hidden matrix), fp32 residual (+folded LayerNorm, + bf16 copy and row statistics of the new stream).  Reference call sites:
+// eva_vit_model.py:99-103 (SwiGLU), :177-179 (q|k|v), :218-219 (proj), :306-307 (residual adds); open_clip/transformer.py:195-211.
+#include "gemm_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr unsigned OOB = 0xfffffff0u;          // voffset of a masked lane: beyond num_records of every descriptor below -> the store is dropped
+
+__device__ __forceinline__ float lane_bcast(int src_lane_x4, float v) {      // v of lane (src_lane_x4 / 4)
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane_x4, __float_as_int(v)));
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    union { bf16x2 v; unsigned u; } pk;
+    pk.v[0] = f2bf(a);
+    pk.v[1] = f2bf(b);
+    return pk.u;
+}
+// half exchange: lanes 32-63 of x <-> lanes 0-31 of y (v_permlane32_swap)
+__device__ __forceinline__ void swap32(unsigned& x, unsigned& y) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+__device__ __forceinline__ float both_halves(float v) {                     // v(lane) + v(lane ^ 32)
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void store16(const u32x4& v, __amdgpu_buffer_rsrc_t rs, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+}
+__device__ __forceinline__ float silu_mul(float u, float v) {               // hardware exp2 / rcp (1 ulp each; the result is rounded to bf16)
+    return u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u)) * v;
+}
+template <int ACT>
+__device__ __forceinline__ float activate_s(float v) {
+    if (ACT == 1) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));                                            // nn.GELU
+    if (ACT == 2) return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v));   // QuickGELU
+    return v;
+}
+
+// Epilogue operands that do not depend on the accumulators: per-row LayerNorm statistics of the wave's four 32-row blocks (lane = row)
+// and the per-column constants of its 64 columns (lane = column).
+struct EpiOps {
+    float mean[4], rstd[4];
+    float cb, cc;            // bias / folded-LN column sum of column (lane) -- SwiGLU: lanes 0-31 = x1 columns, 32-63 = x2 columns
+};
+
+// ---------------------------------------------------------------------------------------------------------------- SwiGLU
+// acc[i][0] = x1, acc[i][1] = x2 of hidden units hbase + col(e, lane>>5); out[row][hidden] = silu(x1) * x2 in bf16.
+template <bool LN, bool AUX>
+__device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int tn, int wn, const EpiOps& eo) {
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int hbase = tn * 128 + wn * 32;
+    const bool colok = hbase < p.group;                                 // wave-uniform: group % 32 == 0 (checked by the launcher)
+    float nm[4], rs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rs[i] = LN ? eo.rstd[i] : 1.f;
+        nm[i] = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
+    }
+    unsigned pk[4][4][2];
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    const int sl0 = hf << 4;                                            // byte address of source lane 4*hf
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float hv[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = q * 4 + r;
+            const int sl = sl0 + ((8 * q + r) << 2);
+            const float b1 = lane_bcast(sl, eo.cb), b2 = lane_bcast(sl + 128, eo.cb);
+            float c1 = 0.f, c2 = 0.f;
+            if (LN) { c1 = lane_bcast(sl, eo.cc); c2 = lane_bcast(sl + 128, eo.cc); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float u = acc[i][0][e], v = acc[i][1][e];
+                if (LN) {                                               // value = rstd * acc - rstd * mean * colsum + bias: two FMAs
+                    u = fmaf(rs[i], u, fmaf(nm[i], c1, b1));
+                    v = fmaf(rs[i], v, fmaf(nm[i], c2, b2));
+                } else {
+                    u += b1;
+                    v += b2;
+                }
+                hv[i][r] = silu_mul(u, v);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pk[i][q][0] = pack2(hv[i][0], hv[i][1]);
+            pk[i][q][1] = pack2(hv[i][2], hv[i][3]);
+            if (AUX) {                                                  // statistics of the ROUNDED outputs (what the next GEMM reads)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const float a = __uint_as_float(pk[i][q][d] << 16), b = __uint_as_float(pk[i][q][d] & 0xffff0000u);
+                    ssum[i] += a + b;
+                    ssq[i] = fmaf(a, a, fmaf(b, b, ssq[i]));
+                }
+            }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc((const __bf16*)p.C + (size_t)row0 * p.ldc + hbase);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool ok = colok && row0 + i * 32 + l31 < p.M;
+        const unsigned rowoff = (unsigned)((i * 32 + l31) * p.ldc + 8 * hf) * 2u;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            unsigned x0 = pk[i][2 * pr][0], x1 = pk[i][2 * pr][1], y0 = pk[i][2 * pr + 1][0], y1 = pk[i][2 * pr + 1][1];
+            swap32(x0, y0);              // lower half: own group 2pr | upper's group 2pr  = columns 16pr .. 16pr+7
+            swap32(x1, y1);              // upper half: lower's group 2pr+1 | own group 2pr+1 = columns 16pr+8 .. 16pr+15
+            store16(u32x4{x0, x1, y0, y1}, rc, ok ? rowoff + 32u * pr : OOB);
+        }
+    }
+    if (AUX) {
+        // per-(32-hidden slice, row) partial (sum, sum of squares): slice = tn * 4 + wn; cs_ln_stats_finalize() pools the slices
+        const size_t slice = (size_t)tn * 4 + wn;
+        const __amdgpu_buffer_rsrc_t rst = make_rsrc(p.stats_part + (slice * p.M + row0) * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float s = both_halves(ssum[i]), q2 = both_halves(ssq[i]);
+            const bool ok = colok && hf == 0 && row0 + i * 32 + l31 < p.M;
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(s), __float_as_uint(q2)}, rst, ok ? (unsigned)(i * 32 + l31) * 8u : OOB, 0, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- bf16 (+activation)
+template <int ACT, bool LN>
+__device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, const EpiOps& eo) {
+    const int l31 = lane & 31, hf = lane >> 5;
+    float nm[4], rs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rs[i] = LN ? eo.rstd[i] : 1.f;
+        nm[i] = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc((const __bf16*)p.C + (size_t)row0 * p.ldc + colw);
+    const int sl0 = hf << 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const bool colok = colw + j * 32 < p.N;                         // wave-uniform: N % 32 == 0
+        unsigned pk[4][4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float ov[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sl = sl0 + ((j * 32 + 8 * q + r) << 2);
+                const float b = lane_bcast(sl, eo.cb);
+                const float c = LN ? lane_bcast(sl, eo.cc) : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float a = acc[i][j][q * 4 + r];
+                    ov[i][r] = activate_s<ACT>(LN ? fmaf(rs[i], a, fmaf(nm[i], c, b)) : a + b);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pk[i][q][0] = pack2(ov[i][0], ov[i][1]);
+                pk[i][q][1] = pack2(ov[i][2], ov[i][3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = colok && row0 + i * 32 + l31 < p.M;
+            const unsigned rowoff = (unsigned)((i * 32 + l31) * p.ldc + j * 32 + 8 * hf) * 2u;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                unsigned x0 = pk[i][2 * pr][0], x1 = pk[i][2 * pr][1], y0 = pk[i][2 * pr + 1][0], y1 = pk[i][2 * pr + 1][1];
+                swap32(x0, y0);
+                swap32(x1, y1);
+                store16(u32x4{x0, x1, y0, y1}, rc, ok ? rowoff + 32u * pr : OOB);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- fp32 residual
+// out = extra + (LN ? rstd*(acc - mean*colsum) : acc) + bias; AUX: also a bf16 copy of out (xb_out) and per-(64-column slice, row)
+// partial (sum, sum of squares) of the fp32 outputs.  In place (C == extra) is the normal use: every element is read and written by
+// the same lane.
+template <bool LN, bool AUX>
+__device__ __forceinline__ void epi_resid(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, int tn, int wn,
+                                          const EpiOps& eo) {
+    const int l31 = lane & 31, hf = lane >> 5;
+    float nm[4], rs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rs[i] = LN ? eo.rstd[i] : 1.f;
+        nm[i] = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc((const float*)p.C + (size_t)row0 * p.ldc + colw);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.extra + (size_t)row0 * p.ldc + colw);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(AUX ? (const void*)(p.xb_out + (size_t)row0 * p.ldxb + colw) : (const void*)p.C);
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    const int sl0 = hf << 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const bool colok = colw + j * 32 < p.N;
+        float bq[16], cq[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int sl = sl0 + ((j * 32 + 8 * (e >> 2) + (e & 3)) << 2);
+            bq[e] = lane_bcast(sl, eo.cb);
+            cq[e] = LN ? lane_bcast(sl, eo.cc) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = colok && row0 + i * 32 + l31 < p.M;
+            const unsigned rowoff = (unsigned)((i * 32 + l31) * p.ldc + j * 32 + 4 * hf) * 4u;
+            f32x4 x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)                                  // masked lanes read zeros (out-of-range buffer load)
+                x[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? rowoff + 32u * q : OOB, 0, 0));
+            unsigned pk[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = q * 4 + r;
+                    const float a = acc[i][j][e];
+                    o[r] = x[q][r] + (LN ? fmaf(rs[i], a, fmaf(nm[i], cq[e], bq[e])) : a + bq[e]);
+                    if (AUX) {
+                        ssum[i] += o[r];
+                        ssq[i] = fmaf(o[r], o[r], ssq[i]);
+                    }
+                }
+                store16(__builtin_bit_cast(u32x4, o), rc, ok ? rowoff + 32u * q : OOB);
+                if (AUX) {
+                    pk[q][0] = pack2(o[0], o[1]);
+                    pk[q][1] = pack2(o[2], o[3]);
+                }
+            }
+            if (AUX) {
+                const unsigned boff = (unsigned)((i * 32 + l31) * p.ldxb + j * 32 + 8 * hf) * 2u;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    unsigned x0 = pk[2 * pr][0], x1 = pk[2 * pr][1], y0 = pk[2 * pr + 1][0], y1 = pk[2 * pr + 1][1];
+                    swap32(x0, y0);
+                    swap32(x1, y1);
+                    store16(u32x4{x0, x1, y0, y1}, rb, ok ? boff + 32u * pr : OOB);
+                }
+            }
+        }
+    }
+    if (AUX) {
+        const size_t slice = (size_t)tn * 4 + wn;                       // 64-column slices: tile column tn has four
+        const __amdgpu_buffer_rsrc_t rst = make_rsrc(p.stats_part + (slice * p.M + row0) * 2);
+        const bool sliceok = colw < p.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float s = both_halves(ssum[i]), q2 = both_halves(ssq[i]);
+            const bool ok = sliceok && hf == 0 && row0 + i * 32 + l31 < p.M;
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(s), __float_as_uint(q2)}, rst, ok ? (unsigned)(i * 32 + l31) * 8u : OOB, 0, 0);
+        }
+    }
+}
+
+// store instructions one epilogue issues per wave (exact: masked lanes keep their instruction, see OOB)
+template <int EPI, bool AUX>
+constexpr int epi_stores() {
+    if (EPI == EPI_SWIGLU_BF16) return 8 + (AUX ? 4 : 0);
+    if (EPI == EPI_RESID_F32) return 32 + (AUX ? 16 + 4 : 0);
+    return 16;
+}
+
+// dword load the compiler does not see (no vmcnt(0) drain of the pending LDS-DMA at its use): counted by hand, see EARLY below
+__device__ __forceinline__ float asm_load_f32(const float* base /* wave-uniform */, unsigned byte_off) {
+    float v;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
+    return v;
+}
+
+#define CS_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+// EPI: EPI_BF16 / EPI_GELU_BF16 / EPI_QGELU_BF16 / EPI_SWIGLU_BF16 / EPI_RESID_F32 (the latter with LN = folded LayerNorm, i.e. epilogue 6)
+template <int EPI, bool LN, bool AUX, bool EARLY>
+__global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
+    constexpr bool SWI = EPI == EPI_SWIGLU_BF16, RES = EPI == EPI_RESID_F32;
+    static_assert(SWI || RES || epi_is_bf16(EPI), "register epilogues");
+    constexpr int BM = 256, BN = 256, WN = 4, TM = 128, TN = 64, FM = 4, FN = 2;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int S = epi_stores<EPI, AUX>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int hf = lane >> 5, l31 = lane & 31;
+    char* const b_ring = smem + 3 * A_BYTES;
+    const int ntiles = p.tiles_m * p.tiles_n, ktiles = p.K / BK;
+    const int a_base = ((wm * TM + l31) >> 1) << 8, b_base = ((wn * TN + l31) >> 1) << 8;
+    const int par8 = (l31 & 1) << 3, sw = l31 >> 1;
+    const int G = gridDim.x;
+
+    // DMA cursors: position (tile, K tile) of the next A / B operand tile to put in flight.  A piece's source address is
+    // wave-uniform base (operand + first row of the tile, advanced by 128 bytes per K tile: SGPRs) + a per-lane 32-bit byte offset
+    // that is constant for the whole tile -> no vector address arithmetic in the K loop.
+    unsigned avoff[4], bvoff[4];
+    const char *a_src = nullptr, *b_src = nullptr;
+    int a_tile = blockIdx.x, a_kt = 0, b_tile = blockIdx.x, b_kt = 0;
+    bool a_ok = true, b_ok = true;
+    auto set_a = [&](int tile) {
+        int tm, tn;
+        tile_of_id(p, tile, ntiles, tm, tn);
+        a_src = (const char*)(p.A + (size_t)tm * BM * p.lda);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int tr, chk;
+            lane_source(wave * 4 + i, lane, tr, chk);
+            avoff[i] = (unsigned)(min(tr, p.M - 1 - tm * BM) * p.lda + chk * 8) * 2u;
+        }
+    };
+    auto set_b = [&](int tile) {
+        int tm, tn;
+        tile_of_id(p, tile, ntiles, tm, tn);
+        if (SWI) {         // tile rows [w*64 + jj*32 + t] <- weight row jj*Hd + (tn*128 + w*32 + t): x1 | x2 of one hidden unit share lane and register
+            b_src = (const char*)(p.B + (size_t)tn * (BN / 2) * p.ldb);
+        } else {
+            b_src = (const char*)(p.B + (size_t)tn * BN * p.ldb);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int tr, chk;
+            lane_source(wave * 4 + i, lane, tr, chk);
+            int rel;
+            if (SWI) {
+                const int hrel = (tr >> 6) * 32 + (tr & 31);                                  // hidden unit relative to tn*128
+                rel = ((tr >> 5) & 1) * p.group + min(hrel, p.group - 1 - tn * (BN / 2));
+            } else {
+                rel = min(tr, p.N - 1 - tn * BN);
+            }
+            bvoff[i] = (unsigned)(rel * p.ldb + chk * 8) * 2u;
+        }
+    };
+    auto adv_a = [&]() {
+        if (++a_kt == ktiles) {
+            a_kt = 0;
+            a_tile += G;
+            a_ok = a_tile < ntiles;
+            if (a_ok) set_a(a_tile);
+        }
+    };
+    auto adv_b = [&]() {
+        if (++b_kt == ktiles) {
+            b_kt = 0;
+            b_tile += G;
+            b_ok = b_tile < ntiles;
+            if (b_ok) set_b(b_tile);
+        }
+    };
+#define ISSUE_A(X, SLOT)                                                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + (size_t)a_kt * (BK * 2) + avoff[X]), \
+                                     (__attribute__((address_space(3))) void*)(smem + (SLOT) * A_BYTES + (wave * 4 + (X)) * 1024), 16, 0, 0)
+#define ISSUE_B(X, SLOT)                                                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + (size_t)b_kt * (BK * 2) + bvoff[X]), \
+                                     (__attribute__((address_space(3))) void*)(b_ring + (SLOT) * B_BYTES + (wave * 4 + (X)) * 1024), 16, 0, 0)
+
+    set_a(a_tile);
+    set_b(b_tile);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) ISSUE_A(x, 0);
+    adv_a();
+#pragma unroll
+    for (int x = 0; x < 4; ++x) ISSUE_B(x, 0);
+    adv_b();
+    bool pendA = a_ok;                       // is A(g+1) in flight at the top of iteration g
+    if (a_ok) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ISSUE_A(x, 1);
+        adv_a();
+    }
+
+    int curA = 0, gpar = 0;                  // A slot of K tile g, parity of g
+    bool after_epi = false;
+    for (int tile = blockIdx.x; tile < ntiles; tile += G) {
+        int tm, tn;
+        tile_of_id(p, tile, ntiles, tm, tn);
+        const int row0 = tm * BM + wm * TM, colw = tn * BN + wn * TN;
+        f32x16 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        EpiOps eo;
+        // operand addresses of the epilogue loads: rows of the wave's four blocks, columns of its 64-column slice
+        auto load_epi_ops = [&](auto asm_c) {
+            constexpr bool ASM = decltype(asm_c)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) eo.mean[i] = eo.rstd[i] = 0.f;
+            eo.cb = eo.cc = 0.f;
+            if (LN) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned ro = (unsigned)min(row0 + i * 32 + l31, p.M - 1) * 4u;
+                    if (ASM) {
+                        eo.mean[i] = asm_load_f32(p.ln_mean, ro);
+                        eo.rstd[i] = asm_load_f32(p.ln_rstd, ro);
+                    } else {
+                        eo.mean[i] = p.ln_mean[ro >> 2];
+                        eo.rstd[i] = p.ln_rstd[ro >> 2];
+                    }
+                }
+            }
+            unsigned co;
+            if (SWI) co = (unsigned)(hf * p.group + min(tn * 128 + wn * 32 + l31, p.group - 1)) * 4u;
+            else co = (unsigned)min(colw + lane, p.N - 1) * 4u;
+            if (p.bias) eo.cb = ASM ? asm_load_f32(p.bias, co) : p.bias[co >> 2];
+            if (LN) eo.cc = ASM ? asm_load_f32(p.ln_colsum, co) : p.ln_colsum[co >> 2];
+        };
+
+        auto ktile = [&](auto last_c) {
+            constexpr bool LAST = decltype(last_c)::value;
+            // In issue order this wave's pending ops are ... A(g), B(g), A(g+1) [, the previous epilogue's S stores]: everything older
+            // than A(g+1) must have landed; vmcnt retires in order, so the stores (newest) may stay in flight as well.
+            if (after_epi) {
+                if (pendA) CS_VMCNT(4 + S); else CS_VMCNT(S);
+            } else {
+                if (pendA) CS_VMCNT(4); else CS_VMCNT(0);
+            }
+            after_epi = false;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();     // K tile g landed everywhere; A slot (g+2)%3 and B slot (g+1)&1 are free
+            if constexpr (LAST && EARLY) load_epi_ops(std::true_type{});
+            const char* la = smem + curA * A_BYTES + a_base;
+            const char* lb = b_ring + gpar * B_BYTES + b_base;
+            const int slot_a2 = curA == 0 ? 2 : curA - 1, slot_b1 = gpar ^ 1;
+            bool a_iss = false, b_iss = false;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = ((par8 | (ks * 2 + hf)) ^ sw) << 4;
+                bf16x8 a[FM], b[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(la + i * (16 * 256) + off);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(lb + j * (16 * 256) + off);
+                if (ks < 2) {                  // two DMA pieces per k-step: B(g+1) first, then A(g+2)
+                    if (b_ok) {
+                        if ((ks & 1) == 0) { ISSUE_B(0, slot_b1); ISSUE_B(1, slot_b1); } else { ISSUE_B(2, slot_b1); ISSUE_B(3, slot_b1); }
+                    }
+                } else if (a_ok) {
+                    if ((ks & 1) == 0) { ISSUE_A(0, slot_a2); ISSUE_A(1, slot_a2); } else { ISSUE_A(2, slot_a2); ISSUE_A(3, slot_a2); }
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                if (ks == 1) {
+                    b_iss = b_ok;
+                    if (b_ok) adv_b();
+                }
+                if (ks == 3) {
+                    a_iss = a_ok;
+                    if (a_ok) adv_a();
+                }
+            }
+            pendA = a_iss;
+            curA = curA == 2 ? 0 : curA + 1;
+            gpar ^= 1;
+            if constexpr (LAST && EARLY) {
+                // the epilogue operands were issued ahead of this iteration's DMA pieces: wait for them, not for the DMA
+#define CS_EARLY_WAIT(N)                                                                                                             \
+    asm volatile("s_waitcnt vmcnt(%10)"                                                                                              \
+                 : "+v"(eo.mean[0]), "+v"(eo.mean[1]), "+v"(eo.mean[2]), "+v"(eo.mean[3]), "+v"(eo.rstd[0]), "+v"(eo.rstd[1]),       \
+                   "+v"(eo.rstd[2]), "+v"(eo.rstd[3]), "+v"(eo.cb), "+v"(eo.cc)                                                      \
+                 : "n"(N)                                                                                                            \
+                 : "memory")
+                if (a_iss && b_iss) CS_EARLY_WAIT(8);
+                else if (a_iss || b_iss) CS_EARLY_WAIT(4);
+                else CS_EARLY_WAIT(0);
+#undef CS_EARLY_WAIT
+            }
+        };
+        for (int kt = 0; kt + 1 < ktiles; ++kt) ktile(std::false_type{});
+        ktile(std::true_type{});
+        if constexpr (!EARLY) load_epi_ops(std::false_type{});
+
+        if constexpr (SWI) epi_swiglu<LN, AUX>(p, acc, lane, row0, tn, wn, eo);
+        else if constexpr (RES) epi_resid<LN, AUX>(p, acc, lane, row0, colw, tn, wn, eo);
+        else epi_bf16<epi_act(EPI), LN>(p, acc, lane, row0, colw, eo);
+        after_epi = true;
+    }
+#undef ISSUE_A
+#undef ISSUE_B
+}
+
+template <int EPI, bool LN, bool AUX>
+int launch_stream_t(const GemmArgs& a, unsigned grid, bool early, hipStream_t stream) {
+    constexpr size_t lds = 160 * 1024;
+    if (early) {
+        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, LN, AUX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once;
+        hipLaunchKernelGGL((gemm_stream_kernel<EPI, LN, AUX, true>), dim3(grid), dim3(512), lds, stream, a);
+    } else {
+        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, LN, AUX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once;
+        hipLaunchKernelGGL((gemm_stream_kernel<EPI, LN, AUX, false>), dim3(grid), dim3(512), lds, stream, a);
+    }
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int EPI>
+int launch_stream_bf16(const GemmArgs& a, unsigned grid, bool early, hipStream_t stream) {
+    return a.ln_mean ? launch_stream_t<EPI, true, false>(a, grid, early, stream) : launch_stream_t<EPI, false, false>(a, grid, early, stream);
+}
+
+}  // namespace
+
+// Returns 1 when the problem is outside what the register epilogues cover (the caller falls back to gemm_persist_kernel), 0 on launch,
+// < 0 on error.  `a` arrives with M/N/K, leading dimensions, operands and epilogue operands set (gemm_nt_impl); reserve = CUs to leave free.
+int cs_gemm_stream_launch(GemmArgs a, int epi, int early, int reserve, hipStream_t stream) {
+    const bool swi = epi == EPI_SWIGLU_BF16, res = epi == EPI_RESID_F32 || epi == EPI_RESID_LN_F32;
+    if (!(swi || res || epi == EPI_BF16 || epi == EPI_QGELU_BF16)) return 1;      // exact GELU (erf) keeps the slab epilogue: register pressure
+    if (a.M < 1 || a.K % BK != 0) return 1;
+    if (swi ? (a.group % 32 != 0) : (a.N % 32 != 0)) return 1;
+    if ((long)a.ldc * 128 * 4 >= 0x70000000L || (long)a.ldxb * 128 * 2 >= 0x70000000L) return 1;      // 32-bit offsets inside a wave tile
+    const bool ln = a.ln_mean != nullptr;
+    if ((epi == EPI_RESID_LN_F32) != (res && ln)) return 1;
+    bool aux = false;
+    if (swi) aux = a.stats_part != nullptr;
+    else if (res) {
+        if ((a.stats_part != nullptr) != (a.xb_out != nullptr)) return 1;
+        aux = a.stats_part != nullptr;
+    } else if (a.stats_part || a.xb_out) return 1;
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = swi ? (a.group + 127) / 128 : (a.N + 255) / 256;
+    const long ntiles = (long)a.tiles_m * a.tiles_n;
+    const long cap = 256 - (reserve > 0 && reserve < 200 ? reserve : 0);
+    const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
+    const bool e = early != 0;
+    if (swi) {
+        if (ln) return aux ? launch_stream_t<EPI_SWIGLU_BF16, true, true>(a, grid, e, stream) : launch_stream_t<EPI_SWIGLU_BF16, true, false>(a, grid, e, stream);
+        return aux ? launch_stream_t<EPI_SWIGLU_BF16, false, true>(a, grid, e, stream) : launch_stream_t<EPI_SWIGLU_BF16, false, false>(a, grid, e, stream);
+    }
+    if (res) {
+        if (ln) return aux ? launch_stream_t<EPI_RESID_F32, true, true>(a, grid, e, stream) : launch_stream_t<EPI_RESID_F32, true, false>(a, grid, e, stream);
+        if (aux) return 1;
+        return launch_stream_t<EPI_RESID_F32, false, false>(a, grid, e, stream);
+    }
+    if (epi == EPI_BF16) return launch_stream_bf16<EPI_BF16>(a, grid, e, stream);
+    return launch_stream_bf16<EPI_QGELU_BF16>(a, grid, e, stream);
+}

@@ -264,6 +264,62 @@ def wgrad_ab():
         print(line, flush=True)
 
 
+def stream_ab():
+    """Streaming kernel with register epilogues (cfg 11; cfg 12 = early epilogue operand loads) against the persistent slab-epilogue
+    kernel (cfg 9) on the teacher's four GEMMs exactly as `_teacher_block_folded` calls them (folded LayerNorms, statistics / bf16 copy
+    outputs), two interleaved passes + a bitwise race screen (usage: python tools/gemm_bench.py 2048 stream)."""
+    ops = HipOps()
+    M = int(sys.argv[1]) * 197
+    C, Hd = 768, 2048
+    xb = torch.randn(M, C, device="cuda").to(BF)
+    mean, rstd = torch.randn(M, device="cuda") * 0.1, torch.rand(M, device="cuda") + 0.5
+    cases = []
+    Wq, cq, dq = (torch.randn(3 * C, C, device="cuda") * 0.05).to(BF), torch.randn(3 * C, device="cuda"), torch.randn(3 * C, device="cuda")
+    qkv = torch.empty(M, 3 * C, dtype=BF, device="cuda")
+    cases.append(("qkv  N=2304 K=768  bf16+LN", 2.0 * M * 3 * C * C, qkv,
+                  lambda f: ops.gemm_nt_ln(xb, Wq, qkv, bias=dq, ln_mean=mean, ln_rstd=rstd, ln_colsum=cq, epi=0, flags=f)))
+    Wp, cp, dp = (torch.randn(C, C, device="cuda") * 0.05).to(BF), torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+    x = torch.randn(M, C, device="cuda")
+    part_x, xb2 = torch.empty(C // 64, M, 2, device="cuda"), torch.empty(M, C, dtype=BF, device="cuda")
+    cases.append(("proj N=768  K=768  resid+LN+copy+stats", 2.0 * M * C * C, xb2,
+                  lambda f: ops.gemm_nt_ln(xb, Wp, x, bias=dp, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=cp, stats_part=part_x, xb_out=xb2, epi=6, flags=f)))
+    W12, c12, d12 = (torch.randn(2 * Hd, C, device="cuda") * 0.05).to(BF), torch.randn(2 * Hd, device="cuda"), torch.randn(2 * Hd, device="cuda")
+    hid, part_h = torch.empty(M, Hd, dtype=BF, device="cuda"), torch.empty(4 * (Hd // 128), M, 2, device="cuda")
+    cases.append(("w12  N=4096 K=768  swiglu+LN+stats", 2.0 * M * 2 * Hd * C, hid,
+                  lambda f: ops.gemm_nt_ln(xb, W12, hid, bias=d12, ln_mean=mean, ln_rstd=rstd, ln_colsum=c12, stats_part=part_h, epi=3, group=Hd, flags=f)))
+    W3, c3, d3 = (torch.randn(C, Hd, device="cuda") * 0.05).to(BF), torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+    hin = torch.randn(M, Hd, device="cuda").to(BF)
+    cases.append(("w3   N=768  K=2048 resid+LN+copy+stats", 2.0 * M * C * Hd, xb2,
+                  lambda f: ops.gemm_nt_ln(hin, W3, x, bias=d3, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=c3, stats_part=part_x, xb_out=xb2, epi=6, flags=f)))
+    for name, flops, out, run in cases:
+        line = f"{name} M={M}: "
+        for rep in range(2):
+            for tag, f in (("cfg9", 0x90), ("cfg11", 0xB0), ("cfg12", 0xC0)):
+                for _ in range(2):
+                    run(f)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    run(f)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 10
+                line += f"{tag} {us:7.1f} us ({flops / us / 1e6:4.0f} TF/s) | "
+        print(line, flush=True)
+        if "resid" not in name:            # race screen: every run of the streaming kernel must reproduce its own first result bit for bit
+            for f in (0xB0, 0xC0):
+                run(f)
+                ref = out.clone()
+                bad = 0
+                for _ in range(10):
+                    out.fill_(float("nan"))
+                    run(f)
+                    bad += int(not torch.equal(out, ref))
+                run(0x90)
+                d = (out.float() - ref.float()).abs().max().item()
+                print(f"   flags {f:#x}: {bad}/10 runs differ from the first; max |diff| to cfg 9 = {d:.3e}", flush=True)
+
+
 if __name__ == "__main__":
     mode = sys.argv[2] if len(sys.argv) > 2 else ""
-    {"fold": fold_ab, "wgrad": wgrad_ab, "raster": raster_ab, "square": square, "student": student_shapes}.get(mode, main)()
+    {"fold": fold_ab, "wgrad": wgrad_ab, "raster": raster_ab, "square": square, "student": student_shapes, "stream": stream_ab}.get(mode, main)()
