@@ -31,6 +31,8 @@ sys.path.insert(0, str(ROOT))
 MODEL = "EVA02-CLIP-B-16"
 BATCH, CROPS, SIZE = 64, 32, 224
 PEAK_BF16_TFLOPS = 2500.0
+DOMINANT_KERNEL = ("gemm_stream_kernel<EPI_SWIGLU_BF16, LN, stats> (teacher W1|W2 GEMM with norm2 folded in + SiLU*mul + ffn_ln partial "
+                   "statistics, M=chunk*197,N=4096,K=768)")
 
 
 def flops_per_image(cfg, k, cls_only=True):
@@ -101,10 +103,20 @@ def isolated_swiglu_gemm(ops, M, cfg, launches=5):
     return 1e3 * e0.elapsed_time(e1) / launches
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline_worker():
-    """fp32 CPU oracle (oracle/eva_ref.py) on the host cores, bounded sample: one full step on 1 image x 8 crops
-    (teacher + student fwd/bwd + AdamW) plus the teacher's per-crop cost on 16 more crops; the 32-crop step time is
-    t_step(8 crops) + 24 * t_teacher_per_crop (the teacher is linear in crops).  Prints a JSON object."""
+    """fp32 CPU oracle (oracle/eva_ref.py) on the host cores, protocol of SURVEY.md section 8 M5: BASELINE configs[0] exactly (2 images x 8
+    boxes, 224^2; 1 warm-up + 3 timed optimizer steps) and the benchmark's own unit scaled down in images only (2 images x 32 crops, 2 timed
+    steps; the step is linear in images).  `value` = images/s of the 32-crop steps.  Prints a JSON object."""
     from clipself_amd.config import get_tower_cfg
     from clipself_amd.init import seeded_visual_state, synthetic_batch
     from oracle import eva_ref
@@ -112,20 +124,26 @@ def cpu_baseline_worker():
     torch.set_num_threads(cores)
     cfg = get_tower_cfg(MODEL)
     student, teacher = seeded_visual_state(cfg, 0), seeded_visual_state(cfg, 0)
-    b8 = [synthetic_batch(1, 8, SIZE, SIZE, seed=1234 + i) for i in range(2)]
-    eva_ref.train_steps(student, teacher, cfg, b8[:1])                       # warm-up (allocator, thread pools)
-    t0 = time.time()
-    eva_ref.train_steps(student, teacher, cfg, b8[1:])
-    t_step8 = time.time() - t0
-    crops16 = synthetic_batch(1, 16, SIZE, SIZE, seed=99)[2][0]
-    with torch.no_grad():
-        t0 = time.time()
-        eva_ref.encode_image(teacher, cfg, crops16)
-        t_crop = (time.time() - t0) / 16
-    dt = t_step8 + (CROPS - 8) * t_crop
-    print(json.dumps({"value": 1.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-                      "sample": f"{MODEL} fp32 CPU oracle (oracle/eva_ref.py): 1 full step on 1 image x 8 crops {SIZE}^2 ({t_step8:.2f} s) "
-                                f"+ teacher forward on 16 crops ({t_crop:.3f} s/crop); 32-crop step = {dt:.2f} s/image; {cores} torch threads"}))
+
+    def timed(batches):
+        ts = []
+        for b in batches:
+            t0 = time.time()
+            eva_ref.train_steps(student, teacher, cfg, [b])
+            ts.append(time.time() - t0)
+        return ts
+
+    cfg1 = [synthetic_batch(2, 8, SIZE, SIZE, seed=1234 + i) for i in range(4)]
+    timed(cfg1[:1])                                                          # warm-up (allocator, thread pools)
+    t1 = timed(cfg1[1:])
+    t32 = timed([synthetic_batch(2, CROPS, SIZE, SIZE, seed=4321 + i) for i in range(2)])
+    m1, m32 = sum(t1) / len(t1), sum(t32) / len(t32)
+    print(json.dumps({"value": 2.0 / m32, "unit": "images/sec", "cores": cores, "kind": "port", "cpu": cpu_model_name(),
+                      "cfg1_s_per_step": m1, "cfg1_images_per_sec": 2.0 / m1,
+                      "sample": f"{MODEL} fp32 CPU oracle (oracle/eva_ref.py), full optimizer steps (teacher + student fwd/bwd + AdamW): "
+                                f"BASELINE configs[0] exactly, 2 images x 8 boxes, {len(t1)} timed steps {m1:.2f} s/step; the benchmark's unit "
+                                f"scaled down in images only, 2 images x {CROPS} crops, {len(t32)} timed steps {m32:.2f} s/step = {2.0 / m32:.3f} images/s; "
+                                f"{cores} torch threads on {cpu_model_name()}"}))
 
 
 def cpu_baseline(timeout_s=300):
@@ -139,6 +157,30 @@ def cpu_baseline(timeout_s=300):
         return {"value": None, "error": (r.stderr or "no output")[-300:]}
     except subprocess.TimeoutExpired:
         return {"value": None, "error": f"cpu baseline exceeded {timeout_s}s"}
+
+
+def launch_ranks(n, argv):
+    """Re-execute this script as n ranks of one node (python -m torch.distributed.run, rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+    return subprocess.run(cmd, env=env).returncode
+
+
+def pmc_traffic_per_launch(chunk_crops):
+    """HBM/fabric bytes of one dominant-kernel launch from the tracked PMC summary (profiles/pmc_traffic.json: separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2 gfx950 correction; written by tools/rocprof_pmc.py), scaled linearly in the
+    chunk; None when the summary does not cover the kernel this build launches."""
+    try:
+        rec = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())["dominant"]
+        return (2.0 * rec["fetch_kb"] + rec["write_kb"]) * 1024.0 * chunk_crops / rec["chunk_crops"], rec
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def main():
@@ -155,13 +197,35 @@ def main():
                     help="run the teacher inline on the main stream instead of one batch ahead on a side stream (A/B switch)")
     ap.add_argument("--no-block-ln-fold", action="store_true",
                     help="keep norm1 / norm2 of the teacher as LayerNorm kernels (only the two sub-LayerNorms folded; A/B switch)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check without a GPU: the ranks rendezvous over gloo, all-reduce a one and rank 0 prints the world size")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
         cpu_baseline_worker()
         return
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # `python bench.py --gpus N` on its own: become the launcher -- one rank per GPU under torch.distributed.run, same arguments
+        # (the reference's launch line: scripts/train_clipself_coco_image_patches_eva_vitb16.sh:1, torchrun --nproc_per_node 8)
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", 1)) != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE')} ranks")
 
     import torch.distributed as dist
+    if a.dry_run:
+        world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
+        total = 1.0
+        if world > 1:
+            dist.init_process_group(backend="gloo", init_method="env://", world_size=world, rank=rank)
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            total = float(t)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(total)}), flush=True)
+        return
     from clipself_amd.init import synthetic_batch
     from clipself_amd.open_clip import create_model
     from clipself_amd.training.clipself import CLIPSelf
@@ -174,6 +238,10 @@ def main():
     distributed = world > 1
     # CLIPSELF_DIST_BACKEND=gloo + fewer devices than ranks is the single-GPU rehearsal of the N-rank path used by
     # tests/test_gpu_step.py (RCCL refuses two ranks on one device); the driver's runs use nccl (= RCCL), one rank per GPU.
+    if torch.cuda.device_count() < 1:
+        sys.exit("bench.py: no ROCm device visible (the step has no CPU path)")
+    if world > torch.cuda.device_count() and os.environ.get("CLIPSELF_DIST_BACKEND", "nccl") == "nccl":
+        sys.exit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPUs (RCCL needs one device per rank)")
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if distributed:
@@ -235,6 +303,7 @@ def main():
         ips = world * BATCH * a.steps / elapsed
         F = flops_per_image(cfg, CROPS, cls_only=not a.full_last_block)
         kt = timer.result()
+        traffic, pmc = pmc_traffic_per_launch(min(a.teacher_chunk, BATCH * CROPS))
         out = {
             "metric": "images/sec (student+teacher distill step), ViT-B/16 32 crops/img",
             "value": ips, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -250,11 +319,9 @@ def main():
         if kt:
             out["roofline"] = {"bound": "mfma", "achieved": kt["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": kt["tflops"] / PEAK_BF16_TFLOPS,
-                               # HBM/fabric bytes per launch from the committed PMC passes (profiles/r01_m_pmc_traffic.md:
-                               # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs, chunk 2048 -> 3.97 + 1.86 GB);
-                               # not re-measured here, scaled linearly in the chunk
-                               "traffic": (5.83e9 * min(a.teacher_chunk, BATCH * CROPS) / 2048.0),
-                               "kernel": "gemm_persist_kernel<EPI_SWIGLU_BF16> (teacher W1|W2 GEMM with norm2 folded in + SiLU*mul + ffn_ln partial statistics, M=chunk*197,N=4096,K=768)",
+                               # HBM/fabric bytes per launch from the tracked PMC summary (not re-measured in this run)
+                               "traffic": traffic, "traffic_source": (pmc or {}).get("source"),
+                               "kernel": DOMINANT_KERNEL,
                                "launches": kt["launches"], "mean_us": kt["mean_us"], "flops_per_launch": kt["flops_per_launch"]}
             if not a.no_overlap:
                 # In the overlapped schedule this kernel shares the CUs with the student's kernels for part of the step, which

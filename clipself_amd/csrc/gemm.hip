@@ -1077,7 +1077,8 @@ int launch_persist(GemmArgs a, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + BN / 2 - 1) / (BN / 2) : (a.N + BN - 1) / BN;
     const long ntiles = (long)a.tiles_m * a.tiles_n;
-    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
+    const long cap = 256 - (a.reserve > 0 && a.reserve < 200 ? a.reserve : 0);       // flags bits 20-26: compute units left free
+    const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
     if constexpr (EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16) {           // the wide-N GEMMs of the towers (q|k|v, W1|W2)
         const bool parts_ok = grid == 256 && a.tiles_n >= a.nsplit && a.tiles_m >= 8 / a.nsplit;
         if (a.rm == 1 && parts_ok) return launch_persist_rm<EPI, 1>(a, grid, stream);
@@ -1152,24 +1153,31 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
         cfg = (c3 <= c2 && c3 <= c1) ? 3 : (c2 <= c1 ? 2 : 1);
         // split rings: +1..3 % over the lockstep 2-stage ring on the tower shapes; as a persistent tile loop (bf16 / GELU / SwiGLU /
         // residual epilogues, case 9 falls back to 7 for the others): another -2.4 % (q|k|v) / -4.9 % (W1|W2) per launch
-        if (cfg == 3 && use_glds) cfg = PP_DEFAULT ? 5 : 9;
+        // ... and with register-level epilogues on a continuous operand ring (gemm_stream.hip) for the bf16 / QuickGELU / SwiGLU outputs:
+        // q|k|v 1600 -> 1500 us, W1|W2 2840 -> 2470 us per 2048-crop launch; the fp32 residual epilogues are HBM-bound and keep
+        // the slab (full-line) epilogue of the persistent kernel (profiles/r02_a_stream_gemm.md)
+        if (cfg == 3 && use_glds) cfg = PP_DEFAULT ? 5 : ((EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) ? 9 : 11);
     }
     const int ns = sp[(cfg == 4 || cfg == 8) ? 2 : (cfg >= 5 ? 3 : cfg)];   // cfgs 5..7, 9 and 10 are 256x256 variants
     a.ktiles_per_split = (ktiles + ns - 1) / ns;
     switch (cfg) {
-        case 12:                                                                                // streaming persistent kernel, register epilogues,
-        case 11:                                                                                // 12 = with early (hand-counted) epilogue operand loads
+        case 11:                                                                                // streaming persistent kernel, register epilogues
             if (use_glds && ns == 1) {
-                const int rc = cs_gemm_stream_launch(a, EPI, cfg == 12, a.reserve, stream);
+                const int rc = cs_gemm_stream_launch(a, EPI, a.reserve, stream);
                 if (rc <= 0) return rc;
             }
-            [[fallthrough]];
+            cfg = 9;                                                                            // outside its coverage: slab-epilogue persistent kernel
+            break;
         case 10:                                                                                // persistent ping-pong (packed epilogues)
             if constexpr (epi_is_bf16(EPI) || EPI == EPI_SWIGLU_BF16) {
                 if (use_glds && ns == 1) return launch_pp_persist<EPI>(a, stream);
             }
-            [[fallthrough]];
-        case 9:                                                                                 // persistent split rings (packed epilogues)
+            cfg = 9;
+            break;
+        default: break;
+    }
+    switch (cfg) {
+        case 9:                                                                                 // persistent split rings (packed / residual epilogues)
             if constexpr (epi_is_bf16(EPI) || EPI == EPI_SWIGLU_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
                 if (use_glds && ns == 1) return launch_persist<EPI>(a, stream);
             }
@@ -1197,10 +1205,13 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 //       bits 4-7: force schedule (1 = 128x128, 2 = 256x128, 3 = 256x256 lockstep, 4 = 256x128 3-stage ring,
 //                 5 = 256x256 ping-pong, 6 = 256x256 lockstep + L2 warm-up, 7 = 256x256 split rings A3/B2,
 //                 8 = 256x128 K-32 ring, two workgroups per CU, 9 = persistent split rings (bf16 / GELU / SwiGLU / residual epilogues),
-//                 10 = persistent ping-pong (bf16 / GELU / SwiGLU epilogues; others fall back to 9); 0 = heuristic)
+//                 10 = persistent ping-pong (bf16 / GELU / SwiGLU epilogues; others fall back to 9),
+//                 11 = streaming persistent kernel with register epilogues (gemm_stream.hip: bf16 / QuickGELU / SwiGLU / residual;
+//                      others fall back to 9); 0 = heuristic)
 //       bits 8-11: raster group height override (0 = 8)
 //       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue;
 //       bit 15: split-ring schedule issues its DMA in one burst behind the barrier instead of interleaved with the MFMAs
+//       bits 20-26: compute units the persistent kernels leave free (grid = 256 - n; multi-GPU runs keep room for RCCL's kernels)
 //       bits 16-17 (persistent kernel, epilogues 0 and 3): 1 = B-stationary raster (each XCD keeps its share of B in L2; bits 8-11 = N parts,
 //                 0 = automatic), 2 = the same with non-temporal A loads, 3 = grouped raster with non-temporal B loads
 static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias, const float* extra, const float* ln_mean,

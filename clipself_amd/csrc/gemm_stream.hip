@@ -16,9 +16,9 @@
 //   * The epilogue's stores are never waited for: vmcnt retires in order on gfx9, so the first K tile after an epilogue waits
 //     vmcnt(4 + S) with S = the fixed number of store instructions an epilogue issues (buffer stores with out-of-range offsets for
 //     masked rows / columns keep that count exact).
-//   * EARLY variant: the few per-row / per-column operands of the epilogue are loaded (inline asm, counted by hand) at the top of the
-//     tile's LAST K iteration, ahead of that iteration's operand DMA, so that consuming them does not drain the DMA queue
-//     (hipcc waits vmcnt(0) for any ordinary load while an LDS-DMA is pending).
+//   * The epilogue's own operand loads (row statistics, column constants, residual rows) are ordinary loads: hipcc waits vmcnt(0) at
+//     their first use, which also retires the next tile's operand DMA -- issued one to two K tiles earlier, it has landed by then.
+//     (Measured: a variant that fetched these operands ahead of the last K tile's DMA with hand-counted waits was not faster.)
 //
 // Epilogues: bf16 (+bias, optional GELU / QuickGELU, optional folded LayerNorm), fused SwiGLU (+folded LayerNorm, +row statistics of the
 // hidden matrix), fp32 residual (+folded LayerNorm, + bf16 copy and row statistics of the new stream).  Reference call sites:
@@ -294,17 +294,10 @@ constexpr int epi_stores() {
     return 16;
 }
 
-// dword load the compiler does not see (no vmcnt(0) drain of the pending LDS-DMA at its use): counted by hand, see EARLY below
-__device__ __forceinline__ float asm_load_f32(const float* base /* wave-uniform */, unsigned byte_off) {
-    float v;
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
-    return v;
-}
-
 #define CS_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 // EPI: EPI_BF16 / EPI_GELU_BF16 / EPI_QGELU_BF16 / EPI_SWIGLU_BF16 / EPI_RESID_F32 (the latter with LN = folded LayerNorm, i.e. epilogue 6)
-template <int EPI, bool LN, bool AUX, bool EARLY>
+template <int EPI, bool LN, bool AUX>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     constexpr bool SWI = EPI == EPI_SWIGLU_BF16, RES = EPI == EPI_RESID_F32;
     static_assert(SWI || RES || epi_is_bf16(EPI), "register epilogues");
@@ -414,34 +407,27 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         EpiOps eo;
-        // operand addresses of the epilogue loads: rows of the wave's four blocks, columns of its 64-column slice
-        auto load_epi_ops = [&](auto asm_c) {
-            constexpr bool ASM = decltype(asm_c)::value;
+        // epilogue operands: LayerNorm statistics of the rows of the wave's four blocks (lane = row), constants of its 64 columns (lane = column)
+        auto load_epi_ops = [&]() {
 #pragma unroll
             for (int i = 0; i < 4; ++i) eo.mean[i] = eo.rstd[i] = 0.f;
             eo.cb = eo.cc = 0.f;
             if (LN) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const unsigned ro = (unsigned)min(row0 + i * 32 + l31, p.M - 1) * 4u;
-                    if (ASM) {
-                        eo.mean[i] = asm_load_f32(p.ln_mean, ro);
-                        eo.rstd[i] = asm_load_f32(p.ln_rstd, ro);
-                    } else {
-                        eo.mean[i] = p.ln_mean[ro >> 2];
-                        eo.rstd[i] = p.ln_rstd[ro >> 2];
-                    }
+                    const int r = min(row0 + i * 32 + l31, p.M - 1);
+                    eo.mean[i] = p.ln_mean[r];
+                    eo.rstd[i] = p.ln_rstd[r];
                 }
             }
-            unsigned co;
-            if (SWI) co = (unsigned)(hf * p.group + min(tn * 128 + wn * 32 + l31, p.group - 1)) * 4u;
-            else co = (unsigned)min(colw + lane, p.N - 1) * 4u;
-            if (p.bias) eo.cb = ASM ? asm_load_f32(p.bias, co) : p.bias[co >> 2];
-            if (LN) eo.cc = ASM ? asm_load_f32(p.ln_colsum, co) : p.ln_colsum[co >> 2];
+            int co;
+            if (SWI) co = hf * p.group + min(tn * 128 + wn * 32 + l31, p.group - 1);
+            else co = min(colw + lane, p.N - 1);
+            if (p.bias) eo.cb = p.bias[co];
+            if (LN) eo.cc = p.ln_colsum[co];
         };
 
-        auto ktile = [&](auto last_c) {
-            constexpr bool LAST = decltype(last_c)::value;
+        auto ktile = [&]() {
             // In issue order this wave's pending ops are ... A(g), B(g), A(g+1) [, the previous epilogue's S stores]: everything older
             // than A(g+1) must have landed; vmcnt retires in order, so the stores (newest) may stay in flight as well.
             if (after_epi) {
@@ -452,7 +438,6 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             after_epi = false;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();     // K tile g landed everywhere; A slot (g+2)%3 and B slot (g+1)&1 are free
-            if constexpr (LAST && EARLY) load_epi_ops(std::true_type{});
             const char* la = smem + curA * A_BYTES + a_base;
             const char* lb = b_ring + gpar * B_BYTES + b_base;
             const int slot_a2 = curA == 0 ? 2 : curA - 1, slot_b1 = gpar ^ 1;
@@ -488,59 +473,40 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             pendA = a_iss;
             curA = curA == 2 ? 0 : curA + 1;
             gpar ^= 1;
-            if constexpr (LAST && EARLY) {
-                // the epilogue operands were issued ahead of this iteration's DMA pieces: wait for them, not for the DMA
-#define CS_EARLY_WAIT(N)                                                                                                             \
-    asm volatile("s_waitcnt vmcnt(%10)"                                                                                              \
-                 : "+v"(eo.mean[0]), "+v"(eo.mean[1]), "+v"(eo.mean[2]), "+v"(eo.mean[3]), "+v"(eo.rstd[0]), "+v"(eo.rstd[1]),       \
-                   "+v"(eo.rstd[2]), "+v"(eo.rstd[3]), "+v"(eo.cb), "+v"(eo.cc)                                                      \
-                 : "n"(N)                                                                                                            \
-                 : "memory")
-                if (a_iss && b_iss) CS_EARLY_WAIT(8);
-                else if (a_iss || b_iss) CS_EARLY_WAIT(4);
-                else CS_EARLY_WAIT(0);
-#undef CS_EARLY_WAIT
-            }
         };
-        for (int kt = 0; kt + 1 < ktiles; ++kt) ktile(std::false_type{});
-        ktile(std::true_type{});
-        if constexpr (!EARLY) load_epi_ops(std::false_type{});
+        for (int kt = 0; kt < ktiles; ++kt) ktile();
+        if (p.dbg & 4) continue;               // timing ablation (tools/gemm_bench.py): no epilogue, results are wrong
+        after_epi = true;
+        load_epi_ops();
 
         if constexpr (SWI) epi_swiglu<LN, AUX>(p, acc, lane, row0, tn, wn, eo);
         else if constexpr (RES) epi_resid<LN, AUX>(p, acc, lane, row0, colw, tn, wn, eo);
         else epi_bf16<epi_act(EPI), LN>(p, acc, lane, row0, colw, eo);
-        after_epi = true;
     }
 #undef ISSUE_A
 #undef ISSUE_B
 }
 
 template <int EPI, bool LN, bool AUX>
-int launch_stream_t(const GemmArgs& a, unsigned grid, bool early, hipStream_t stream) {
+int launch_stream_t(const GemmArgs& a, unsigned grid, hipStream_t stream) {
     constexpr size_t lds = 160 * 1024;
-    if (early) {
-        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, LN, AUX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL((gemm_stream_kernel<EPI, LN, AUX, true>), dim3(grid), dim3(512), lds, stream, a);
-    } else {
-        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, LN, AUX, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL((gemm_stream_kernel<EPI, LN, AUX, false>), dim3(grid), dim3(512), lds, stream, a);
-    }
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, LN, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL((gemm_stream_kernel<EPI, LN, AUX>), dim3(grid), dim3(512), lds, stream, a);
     CS_LAUNCH_CHECK();
     return 0;
 }
 
 template <int EPI>
-int launch_stream_bf16(const GemmArgs& a, unsigned grid, bool early, hipStream_t stream) {
-    return a.ln_mean ? launch_stream_t<EPI, true, false>(a, grid, early, stream) : launch_stream_t<EPI, false, false>(a, grid, early, stream);
+int launch_stream_bf16(const GemmArgs& a, unsigned grid, hipStream_t stream) {
+    return a.ln_mean ? launch_stream_t<EPI, true, false>(a, grid, stream) : launch_stream_t<EPI, false, false>(a, grid, stream);
 }
 
 }  // namespace
 
 // Returns 1 when the problem is outside what the register epilogues cover (the caller falls back to gemm_persist_kernel), 0 on launch,
 // < 0 on error.  `a` arrives with M/N/K, leading dimensions, operands and epilogue operands set (gemm_nt_impl); reserve = CUs to leave free.
-int cs_gemm_stream_launch(GemmArgs a, int epi, int early, int reserve, hipStream_t stream) {
+int cs_gemm_stream_launch(GemmArgs a, int epi, int reserve, hipStream_t stream) {
     const bool swi = epi == EPI_SWIGLU_BF16, res = epi == EPI_RESID_F32 || epi == EPI_RESID_LN_F32;
     if (!(swi || res || epi == EPI_BF16 || epi == EPI_QGELU_BF16)) return 1;      // exact GELU (erf) keeps the slab epilogue: register pressure
     if (a.M < 1 || a.K % BK != 0) return 1;
@@ -559,16 +525,15 @@ int cs_gemm_stream_launch(GemmArgs a, int epi, int early, int reserve, hipStream
     const long ntiles = (long)a.tiles_m * a.tiles_n;
     const long cap = 256 - (reserve > 0 && reserve < 200 ? reserve : 0);
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
-    const bool e = early != 0;
     if (swi) {
-        if (ln) return aux ? launch_stream_t<EPI_SWIGLU_BF16, true, true>(a, grid, e, stream) : launch_stream_t<EPI_SWIGLU_BF16, true, false>(a, grid, e, stream);
-        return aux ? launch_stream_t<EPI_SWIGLU_BF16, false, true>(a, grid, e, stream) : launch_stream_t<EPI_SWIGLU_BF16, false, false>(a, grid, e, stream);
+        if (ln) return aux ? launch_stream_t<EPI_SWIGLU_BF16, true, true>(a, grid, stream) : launch_stream_t<EPI_SWIGLU_BF16, true, false>(a, grid, stream);
+        return aux ? launch_stream_t<EPI_SWIGLU_BF16, false, true>(a, grid, stream) : launch_stream_t<EPI_SWIGLU_BF16, false, false>(a, grid, stream);
     }
     if (res) {
-        if (ln) return aux ? launch_stream_t<EPI_RESID_F32, true, true>(a, grid, e, stream) : launch_stream_t<EPI_RESID_F32, true, false>(a, grid, e, stream);
+        if (ln) return aux ? launch_stream_t<EPI_RESID_F32, true, true>(a, grid, stream) : launch_stream_t<EPI_RESID_F32, true, false>(a, grid, stream);
         if (aux) return 1;
-        return launch_stream_t<EPI_RESID_F32, false, false>(a, grid, e, stream);
+        return launch_stream_t<EPI_RESID_F32, false, false>(a, grid, stream);
     }
-    if (epi == EPI_BF16) return launch_stream_bf16<EPI_BF16>(a, grid, e, stream);
-    return launch_stream_bf16<EPI_QGELU_BF16>(a, grid, e, stream);
+    if (epi == EPI_BF16) return launch_stream_bf16<EPI_BF16>(a, grid, stream);
+    return launch_stream_bf16<EPI_QGELU_BF16>(a, grid, stream);
 }

@@ -114,6 +114,14 @@ class HipOps:
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise RuntimeError("HipOps needs a ROCm device (torch.cuda.is_available() is False); no CPU fallback exists")
+        # OR-ed into the flags of every GEMM call: bits 20-26 = compute units the persistent GEMM kernels leave free
+        # (training/distributed.py reserves a few for RCCL's reduction kernels in data-parallel runs)
+        self.gemm_flags = 0
+
+    def reserve_compute_units(self, n: int):
+        """Persistent GEMM grids use 256 - n compute units from now on (0 = all)."""
+        assert 0 <= n < 128
+        self.gemm_flags = (self.gemm_flags & ~(127 << 20)) | (int(n) << 20)
 
     # -- helpers ---------------------------------------------------------------------------------
     def _stream(self):
@@ -144,7 +152,7 @@ class HipOps:
         if extra is not None and epi in (EPI_RESID_F32, EPI_PATCH_F32):
             assert extra.stride(0) == C.stride(0), "extra must share C's row stride"
         self._ok(self.lib.cs_gemm_nt(_p(A), _p(B), _p(C), _p(bias), _p(extra), M, N, K, A.stride(0), B.stride(0),
-                                     C.stride(0), epi, splits, group, flags, self._stream()), "cs_gemm_nt")
+                                     C.stride(0), epi, splits, group, flags | self.gemm_flags, self._stream()), "cs_gemm_nt")
 
     def gemm_nt_ln(self, A, B, C, bias=None, extra=None, ln_mean=None, ln_rstd=None, ln_colsum=None, stats_part=None, xb_out=None,
                    epi=EPI_RESID_LN_F32, group=0, flags=0):
@@ -161,7 +169,7 @@ class HipOps:
             assert xb_out.dtype == torch.bfloat16 and xb_out.stride(1) == 1 and xb_out.shape[0] == M
         self._ok(self.lib.cs_gemm_nt_ln(_p(A), _p(B), _p(C), _p(bias), _p(extra), _p(ln_mean), _p(ln_rstd), _p(ln_colsum), _p(stats_part),
                                         _p(xb_out), xb_out.stride(0) if xb_out is not None else 0, M, N, K, A.stride(0), B.stride(0),
-                                        C.stride(0), epi, 1, group, flags, self._stream()), "cs_gemm_nt_ln")
+                                        C.stride(0), epi, 1, group, flags | self.gemm_flags, self._stream()), "cs_gemm_nt_ln")
 
     def crop_resize(self, image_u8, boxes, size, pad_center=True, mean=(0.48145466, 0.4578275, 0.40821073),
                     std=(0.26862954, 0.26130258, 0.27577711), out=None):

@@ -68,7 +68,9 @@ class CLIPSelf:
         _, _, crops = self._valid_crops(boxes_d, crops_d)
         main = torch.cuda.current_stream(device)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=device, priority=-1)        # the teacher is the long pole: let it win CUs
+            # single GPU: the teacher is the long pole, let it win CUs.  Data parallel: normal priority, so that RCCL's kernels
+            # (launched at default priority) are not starved behind 3 ms persistent GEMMs
+            self._side = torch.cuda.Stream(device=device, priority=0 if distributed else -1)
         side = self._side
         side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():

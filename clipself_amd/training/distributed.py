@@ -73,6 +73,19 @@ def all_gather_object(args, obj, dst=0):
     return objects
 
 
+def rccl_reserved_cus() -> int:
+    """Compute units the persistent GEMM kernels leave free in data-parallel runs (CLIPSELF_RCCL_CUS, default 16 of 256).  The GEMMs
+    of the step are persistent kernels that own every CU they are launched on for milliseconds; RCCL's ring kernels (a few
+    workgroups per channel) need somewhere to run beside them if the gradient all-reduce is to overlap with backward."""
+    return max(0, min(64, int(os.environ.get("CLIPSELF_RCCL_CUS", "16"))))
+
+
+def _reserve_for_collectives(module):
+    ops = getattr(getattr(getattr(module, "visual", None), "engine", None), "ops", None)
+    if ops is not None and hasattr(ops, "reserve_compute_units") and dist.get_world_size() > 1:
+        ops.reserve_compute_units(rccl_reserved_cus())
+
+
 class StudentDataParallel(torch.nn.Module):
     """`.module`-carrying wrapper (the reference's methods unwrap it: clipself.py:8-10) that (1) broadcasts rank 0's
     parameters once and (2) arms the engine's per-block grad-ready hook with asynchronous bucket all-reduces."""
@@ -87,6 +100,7 @@ class StudentDataParallel(torch.nn.Module):
         with torch.no_grad():
             dist.broadcast(module.logit_scale.data, src=0, group=process_group)
         eng.sync_shadow()
+        _reserve_for_collectives(module)
         self._pending = []
         if eng.trainable:
             eng.grad_ready_hook = self._on_block_ready
@@ -114,6 +128,7 @@ class FrozenDataParallel(torch.nn.Module):
         self.module = module
         dist.broadcast(module.visual.engine.master, src=0, group=process_group)
         module.visual.engine.sync_shadow()
+        _reserve_for_collectives(module)
 
     def forward(self, *a, **k):
         return self.module(*a, **k)

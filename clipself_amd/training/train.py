@@ -60,7 +60,10 @@ def train_step(model, method, batch, optimizer, scheduler, step, dist_model, arg
     if hasattr(model, "finish_grad_sync"):
         model.finish_grad_sync()
     if getattr(args, "grad_clip_norm", None) is not None:
-        torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], args.grad_clip_norm, norm_type=2.0)
+        # data parallel: the buckets carry the SUM over ranks until AdamW divides by the world size, so the threshold is scaled
+        # with it -- the clip coefficient then equals the one of the mean gradient (= a single process on the union batch)
+        scale = float(getattr(model, "world", 1))
+        torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], args.grad_clip_norm * scale, norm_type=2.0)
     optimizer.step()
     with torch.no_grad():
         unwrap_model(model).logit_scale.clamp_(0, math.log(100))

@@ -32,7 +32,9 @@ const char* cs_last_error(void);
  *      5 patch embed: out row = row + row/group + 1, value += extra[(row%group+1)*ldc + col]   (cls/pos layout :540-543) |
  *      7 bf16 = GELU(acc+bias), 8 bf16 = QuickGELU(acc+bias): c_fc + activation of the OpenAI-CLIP ViT MLP
  *        (src/open_clip/transformer.py:209-213 `mlp`, :31-34 `QuickGELU`)
- * flags bit0: use register staging instead of the global_load_lds DMA path. */
+ * flags bit0: use register staging instead of the global_load_lds DMA path; bits 4-7: force a tile schedule (0 = heuristic; 11 = the
+ * streaming persistent kernel with register-level epilogues, the default for the bf16 / QuickGELU / SwiGLU epilogues of large problems);
+ * bits 20-26: compute units the persistent kernels leave free (0 = use all 256; data-parallel runs reserve a few for RCCL's kernels). */
 int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
                int lda, int ldb, int ldc, int epi, int splits, int group, int flags, cs_stream_t stream);
 

@@ -314,3 +314,32 @@ def train_steps(student_sd, teacher_sd, cfg, batches, lr=1e-5, wd=0.1, warmup=10
             student_sd["logit_scale"].clamp_(0, math.log(100))
         log.append({"loss": float(loss.detach()), "lr": float(cur)})
     return log, grads
+
+
+# ------------------------------------------------------------------------------------------------ RegionCLIP (BASELINE configs[4])
+def regionclip_loss(sd, cfg, images, boxes, noun_embeddings, appeared=None, contrast_weight=1.0, emulate_bf16=False):
+    """Restatement of RegionCLIP.__call__ (/root/reference/src/training/region_clip.py:28-67): L2-normalised RoI features of the valid
+    boxes against the L2-normalised noun bank, * exp(logit_scale), binary cross-entropy over the federated column subset `appeared`
+    (get_fed_loss_inds, :7-16; drawn here with the reference's own calls when not given), summed over columns, mean over boxes.
+    boxes [B, max_boxes, 6] = (x0, y0, x1, y1 in [0,1], label, valid).  Pinned on tests/golden/tiny_regionclip.npz."""
+    import torch.nn.functional as F
+    rois, labels = [], []
+    for per_image in boxes:
+        keep = per_image[per_image[:, -1] > 0.5]
+        labels.append(keep[:, 4].long())
+        rois.append(keep[:, :4])
+    labels = torch.cat(labels)
+    feats = F.normalize(encode_pseudo_boxes(sd, cfg, images, rois, emulate_bf16=emulate_bf16), dim=-1)
+    nouns = F.normalize(noun_embeddings.float(), dim=-1)
+    temp = (sd["logit_scale"] if "logit_scale" in sd else torch.ones([]) * math.log(1 / 0.07)).exp().detach()
+    logits = feats @ nouns.T * temp
+    target = torch.zeros_like(logits)
+    target[range(len(labels)), labels] = 1.0
+    if appeared is None:
+        appeared = torch.unique(labels)
+        if len(appeared) < 100:
+            prob = appeared.new_ones(nouns.shape[0]).float()
+            prob[appeared] = 0
+            appeared = torch.cat([appeared, torch.multinomial(prob, 100 - len(appeared), replacement=False)])
+    loss = F.binary_cross_entropy_with_logits(logits[:, appeared], target[:, appeared], reduction="none").sum(-1).mean()
+    return loss * contrast_weight

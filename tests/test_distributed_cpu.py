@@ -40,12 +40,12 @@ def _build(cfg, device):
     return student, teacher, seeded_visual_state
 
 
-def _args(distributed, device):
-    return SimpleNamespace(device=device, precision="amp", distributed=distributed, skip_scheduler=True, grad_clip_norm=None,
+def _args(distributed, device, clip=None):
+    return SimpleNamespace(device=device, precision="amp", distributed=distributed, skip_scheduler=True, grad_clip_norm=clip,
                            multiscale=False, extract_type="v2", cosine_weight=1.0)
 
 
-def _worker(rank, world, port, out_dir, device, family="eva02"):
+def _worker(rank, world, port, out_dir, device, family="eva02", clip=None):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -65,16 +65,16 @@ def _worker(rank, world, port, out_dir, device, family="eva02"):
     model, dist_model = StudentDataParallel(student), FrozenDataParallel(teacher)
     opt = FlatAdamW(student, lr=1e-3, weight_decay=0.1, grad_divisor=float(world))
     batch = synthetic_batch(2, 3, cfg.image_size, cfg.image_size, seed=40 + rank)
-    train_step(model, CLIPSelf(), batch, opt, None, 0, dist_model, _args(True, device))
+    train_step(model, CLIPSelf(), batch, opt, None, 0, dist_model, _args(True, device, clip))
     eng = student.visual.engine
     torch.save({"grad": eng.grad.cpu().clone(), "master": eng.master.cpu().clone()}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def run_two_rank_equivalence(device, tmp_path, tol, family="eva02"):
+def run_two_rank_equivalence(device, tmp_path, tol, family="eva02", clip=None):
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), device, family), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), device, family, clip), nprocs=world, join=True)
     r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
     assert torch.equal(r0["master"], r1["master"]), "ranks diverged after the step"
     assert torch.equal(r0["grad"], r1["grad"]), "all-reduced gradients differ between ranks"
@@ -91,8 +91,10 @@ def run_two_rank_equivalence(device, tmp_path, tol, family="eva02"):
     parts = [synthetic_batch(2, 3, cfg.image_size, cfg.image_size, seed=40 + r) for r in range(2)]
     union = tuple(torch.cat([p[i] for p in parts]) for i in range(3))
     opt = FlatAdamW(student, lr=1e-3, weight_decay=0.1)
-    train_step(student, CLIPSelf(), union, opt, None, 0, teacher, _args(False, device))
+    train_step(student, CLIPSelf(), union, opt, None, 0, teacher, _args(False, device, clip))
     eng = student.visual.engine
+    if clip is not None:
+        assert float(eng.grad.norm()) <= clip * 1.001, "the clip threshold must actually bite in this scenario"
     g_single, g_dist = eng.grad.cpu(), r0["grad"] / world          # SUM on the wire, 1/world applied inside AdamW
     rel = float((g_single - g_dist).norm() / g_single.norm())
     assert rel < tol, rel
@@ -110,3 +112,10 @@ def test_two_rank_step_equals_single_process_on_the_union_batch(tmp_path):
 def test_two_rank_step_equals_single_process_openai_vit(tmp_path):
     """The same scenario on the OpenAI-CLIP ViT family (block buckets found through ClipVitEngine.block_index)."""
     run_two_rank_equivalence("cpu", tmp_path, 1e-3, family="openai")
+
+
+def test_two_rank_grad_clipping_matches_single_process(tmp_path):
+    """--grad-clip-norm under data parallel: the all-reduced buckets hold the SUM over ranks until AdamW divides, so the clip must
+    act on the mean gradient -- same clipped gradient and same parameters as one process on the union batch (train.py:104-113 of
+    the reference clips after unscale_, i.e. the averaged gradient)."""
+    run_two_rank_equivalence("cpu", tmp_path, 1e-3, clip=0.05)

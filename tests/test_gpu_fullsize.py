@@ -1,0 +1,163 @@
+"""`-m gpu`: every BASELINE.json configuration at its FULL size on the MI355X -- the launches `bench.py` times (M = 2048 crops x 197
+tokens = 403 456 rows per GEMM, outputs past 2^31 bytes) and the L/14-336 RegionCLIP configuration -- against the CPU oracle on
+sampled rows / a scaled-down batch and through size-independent properties.  Measured errors go to gpurun_out/parity_metrics.txt
+(copied to profiles/r02_parity.md)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from clipself_amd.config import get_tower_cfg              # noqa: E402
+from clipself_amd.init import seeded_visual_state, synthetic_batch  # noqa: E402
+from test_gpu_step import _args, _pair, one_minus_cos, rel  # noqa: E402
+
+
+def _log(msg):
+    from pathlib import Path
+    p = Path(__file__).resolve().parent.parent / "gpurun_out"
+    p.mkdir(exist_ok=True)
+    with open(p / "parity_metrics.txt", "a") as f:
+        f.write(msg + "\n")
+
+
+def test_cfg1_teacher_all_2048_crops_in_one_pass_against_the_oracle():
+    """BASELINE configs[1], teacher side: all 64 x 32 = 2048 crops in ONE pass (the launch shape of bench.py: every GEMM has
+    M = 403 456 rows) must equal the 256-crop chunked schedule bit for bit, and 64 crops sampled over the whole row range (first /
+    last tiles included) must match oracle/eva_ref.encode_image (fp32 CPU restatement of the reference, pinned on its goldens)."""
+    from oracle import eva_ref
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    _, teacher = _pair(cfg, 0)
+    _, _, crops = synthetic_batch(64, 32, 224, 224, seed=1234)
+    crops = crops.flatten(0, 1)
+    dev = crops.cuda()
+    with torch.no_grad():
+        teacher.visual.teacher_chunk = 2048
+        one_pass = teacher.encode_image(dev)
+        teacher.visual.teacher_chunk = 256
+        chunked = teacher.encode_image(dev)
+    assert one_pass.shape == (2048, cfg.embed_dim) and torch.isfinite(one_pass).all()
+    assert torch.equal(one_pass, chunked), f"{int((one_pass != chunked).any(-1).sum())} of 2048 rows differ between chunk 2048 and chunk 256"
+    idx = torch.unique(torch.cat([torch.arange(0, 2048, 37), torch.tensor([1, 255, 256, 1023, 1024, 2046, 2047])]))[:64]
+    with torch.no_grad():
+        want = eva_ref.encode_image(seeded_visual_state(cfg, 0), cfg, crops[idx])
+    got = one_pass[idx.cuda()]
+    r, c = rel(got, want), one_minus_cos(got, want)
+    _log(f"cfg1 full size teacher (2048 crops, one pass) vs oracle on {len(idx)} sampled crops: rel-L2 {r:.3e}, max 1-cos {c:.2e}")
+    assert r < 1.2e-2 and c < 1e-4
+
+
+def test_cfg1_full_size_step_inline_and_prefetch_schedules_agree():
+    """BASELINE configs[1], whole step at full size (64 images x 32 crops): finite loss and gradients, the loss equals an fp64 recomputation
+    from the step's own features, student RoI features of two images match the oracle, and the one-batch-ahead teacher schedule
+    (bench.py default) produces the same loss and gradient as the inline schedule (`--no-overlap`)."""
+    from oracle import eva_ref
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.train import train_step
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    batch = tuple(t.cuda() for t in synthetic_batch(64, 32, 224, 224, seed=1234))
+    nxt = tuple(t.cuda() for t in synthetic_batch(64, 32, 224, 224, seed=2211))
+
+    def run(prefetch):
+        student, teacher = _pair(cfg, 0)
+        opt = FlatAdamW(student, lr=1e-5, weight_decay=0.1)
+        method = CLIPSelf()
+        a = _args(skip_scheduler=True)
+        a.teacher_prefetch = prefetch
+        if prefetch:                                   # step 0 on `nxt` launches the teacher pass over `batch` on the side stream
+            train_step(student, method, nxt, FlatAdamW(student, lr=0.0, weight_decay=0.0), None, 0, teacher, a, next_batch=batch)
+            assert method._pending is not None
+        out, _, _ = train_step(student, method, batch, opt, None, 0, teacher, a)
+        torch.cuda.synchronize()
+        return float(out["loss"].detach()), student.visual.engine.grad.clone(), student, teacher
+
+    loss_i, grad_i, student, teacher = run(False)
+    assert np.isfinite(loss_i) and 0.0 < loss_i < 2.0
+    assert torch.isfinite(grad_i).all() and float(grad_i.abs().sum()) > 0
+    loss_p, grad_p, _, _ = run(True)
+    gn_i, gn_p = float(grad_i.double().norm()), float(grad_p.double().norm())
+    _log(f"cfg1 full size step: loss inline {loss_i:.6f} prefetch {loss_p:.6f}; |grad| inline {gn_i:.6e} prefetch {gn_p:.6e}; grad rel {rel(grad_p, grad_i):.2e}")
+    assert abs(loss_i - loss_p) < 1e-6 and rel(grad_p, grad_i) < 1e-5
+    # the loss kernel at K = 2048 boxes against fp64 on the step's own features
+    images, boxes, crops = batch
+    with torch.no_grad():
+        t = teacher.encode_image(crops.flatten(0, 1)).double()
+        idx = torch.arange(64, device="cuda", dtype=torch.float32).repeat_interleave(32)[:, None]
+        fresh_student, _ = _pair(cfg, 0)
+        s = fresh_student.encode_pseudo_boxes(images, torch.cat([idx, boxes[..., :4].reshape(-1, 4)], 1)).double()
+        want = float(1 - torch.nn.functional.cosine_similarity(s, t, dim=-1).mean())
+        _log(f"cfg1 full size loss: kernel {loss_i:.7f} vs fp64 on the same features {want:.7f}")
+        assert abs(loss_i - want) < 2e-6
+        # two images of the batch against the oracle
+        sd = seeded_visual_state(cfg, 0)
+        ref = eva_ref.encode_pseudo_boxes(sd, cfg, images[:2].cpu(), [b[:, :4].cpu() for b in boxes[:2]])
+        r, c = rel(s[:64], ref), one_minus_cos(s[:64], ref)
+        _log(f"cfg1 full size student RoI features (2 of 64 images) vs oracle: rel-L2 {r:.3e}, max 1-cos {c:.2e}")
+        assert r < 1.5e-2 and c < 2e-4
+
+
+def _regionclip_batch(cfg, B, n_nouns=4764, max_boxes=20, seed=77):
+    g = np.random.Generator(np.random.PCG64(seed))
+    images, nb, _ = synthetic_batch(B, max_boxes, cfg.image_size, 32, seed=seed)
+    labels = torch.from_numpy(g.integers(0, n_nouns, size=(B, max_boxes, 1)).astype(np.float32))
+    valid = torch.from_numpy((g.random((B, max_boxes, 1)) < 0.7).astype(np.float32))
+    valid[:, 0] = 1.0
+    bx = torch.cat([nb[..., :4], labels, valid], dim=-1)
+    nouns = torch.from_numpy(g.standard_normal((n_nouns, cfg.embed_dim)).astype(np.float32))
+    return images, bx, nouns
+
+
+def test_cfg4_l14_336_regionclip_real_config(monkeypatch):
+    """BASELINE configs[4] in bf16: EVA02-CLIP-L-14-336 RegionCLIP (region-text) with the real noun-bank size (4764 x 768), <= 20 boxes
+    per image: (a) 2 images against oracle/eva_ref.regionclip_loss (pinned on the reference's golden) -- loss and three gradients,
+    with the federated column subset fixed on both sides; (b) the full per-GPU batch of 32 images: finite loss / gradients and
+    the optimizer step."""
+    from oracle import eva_ref
+    from clipself_amd.open_clip.model import CustomCLIP
+    from clipself_amd.training import region_clip as rc
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.train import train_step
+    cfg = get_tower_cfg("EVA02-CLIP-L-14-336")
+    student = CustomCLIP(cfg, trainable=True)
+    sd0 = seeded_visual_state(cfg, 3)
+    student.visual.engine.load_state(sd0)
+    student.lock_image_tower(unlocked_groups=cfg.layers)
+    student.train()
+    images, bx, nouns = _regionclip_batch(cfg, 2)
+    labels = torch.cat([b[b[:, -1] > 0.5][:, 4].long() for b in bx])
+    appeared = torch.unique(labels)
+    extra = torch.from_numpy(np.setdiff1d(np.arange(4764), appeared.numpy())[: 100 - len(appeared)])
+    appeared = torch.cat([appeared, extra])
+    monkeypatch.setattr(rc, "get_fed_loss_inds", lambda gt, n, C: appeared.to(gt.device))
+    method = rc.RegionCLIP(SimpleNamespace(), noun_embeddings=nouns)
+    a = SimpleNamespace(extract_type="v2", contrast_weight=1.0)
+    losses, bs, temp = method((images, bx), student, None, None, "cuda", None, False, a)
+    total = sum(losses.values())
+    total.backward()
+    names = ["visual.blocks.0.attn.q_bias", "visual.blocks.12.mlp.w1.weight", "visual.blocks.23.mlp.w3.bias"]
+    sd = {k: v.clone().requires_grad_(k in names) for k, v in sd0.items()}
+    want = eva_ref.regionclip_loss(sd, cfg, images, bx, nouns, appeared=appeared)
+    want.backward()
+    lr_ = abs(float(total.detach()) - float(want.detach())) / float(want.detach())
+    grs = {n: rel(dict(student.named_parameters())[n].grad, sd[n].grad) for n in names}
+    _log(f"cfg4 L/14-336 RegionCLIP (2 images, 4764 nouns) vs oracle: loss {float(total.detach()):.5f} vs {float(want.detach()):.5f} (rel {lr_:.2e}); "
+         + ", ".join(f"grad {n} rel {r:.2e}" for n, r in grs.items()))
+    assert lr_ < 2e-3
+    assert all(r < 6e-2 for r in grs.values()), grs
+    # full per-GPU batch of the configuration
+    monkeypatch.undo()
+    images, bx, nouns = _regionclip_batch(cfg, 32, seed=78)
+    method = rc.RegionCLIP(SimpleNamespace(), noun_embeddings=nouns)
+    opt = FlatAdamW(student, lr=1e-5, weight_decay=0.1)
+    args = _args(skip_scheduler=True, contrast_weight=1.0)
+    before = student.visual.engine.master.clone()
+    out, bs, _ = train_step(student, method, (images, bx), opt, None, 0, None, args)
+    torch.cuda.synchronize()
+    g = student.visual.engine.grad
+    _log(f"cfg4 L/14-336 RegionCLIP full batch (32 images x <=20 boxes): loss {float(out['loss']):.5f}, |grad| {float(g.double().norm()):.4e}")
+    assert bs == 32 and torch.isfinite(out["loss"]).item() and torch.isfinite(g).all().item() and float(g.abs().sum()) > 0
+    after = student.visual.engine.master
+    assert torch.isfinite(after).all().item() and not torch.equal(after, before)

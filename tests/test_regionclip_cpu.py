@@ -61,3 +61,19 @@ def test_fed_loss_inds_semantics():
     assert got[:3].tolist() == [5, 9, 200]
     many = torch.arange(130)
     assert torch.equal(get_fed_loss_inds(many, 100, 4764), many)
+
+
+def test_oracle_regionclip_loss_is_pinned_on_the_reference_golden(golden_dir):
+    """oracle/eva_ref.regionclip_loss (the checker of the full-size `-m gpu` RegionCLIP test) against the loss and gradients captured
+    from the reference's own RegionCLIP.__call__."""
+    from oracle import eva_ref
+    g = np.load(golden_dir / "tiny_regionclip.npz")
+    cfg = tiny_cfg()
+    names = [k[5:] for k in g.files if k.startswith("grad/")]
+    sd = {k: v.clone().requires_grad_(k in names) for k, v in seeded_visual_state(cfg, 4).items()}
+    images, bx, nouns = regionclip_inputs(cfg)
+    loss = eva_ref.regionclip_loss(sd, cfg, images, bx, nouns)
+    assert abs(float(loss.detach()) - float(g["loss"])) / float(g["loss"]) < 2e-6, (float(loss.detach()), float(g["loss"]))
+    loss.backward()
+    for n in names:
+        assert rel(sd[n].grad, g["grad/" + n]) < 2e-5, n
