@@ -545,6 +545,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
         if (ktiles > 1) stage_tile<A_INSTR, true, AUX_A>(p.A, p.lda, BK, smem + A_BYTES, wave * A_INSTR, lane, arow, achk);
     };
     prologue();
+    if (p.dbg & 1) dephase_start(ktiles, 4200);
     bool first = true;
     for (;;) {
         const int m0 = tm * BM, n0 = tn * BN, tn_cur = tn;

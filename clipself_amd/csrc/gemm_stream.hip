@@ -393,6 +393,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         adv_a();
     }
 
+    if (p.dbg & 1) dephase_start(ktiles, 4200);
     int curA = 0, gpar = 0;                  // A slot of K tile g, parity of g
     bool after_epi = false;
     for (int tile = blockIdx.x; tile < ntiles; tile += G) {

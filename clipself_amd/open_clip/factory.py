@@ -139,17 +139,6 @@ def _create_openai_vit(cfg, model_name, pretrained, force_quick_gelu, cache_dir,
     return model
 
 
-class _HostTransformOutOfScope:
-    """The PIL/torchvision preprocessing pipeline (reference: src/open_clip/transform.py) is outside the hot path
-    (SURVEY.md §8 row N3); the training entrypoint here feeds tensors that already follow the batch contract."""
-
-    def __init__(self, name, size):
-        self.name, self.size = name, size
-
-    def __call__(self, *a, **k):
-        raise NotImplementedError(f"{self.name}: host-side image preprocessing is out of scope of the MI355X hot path")
-
-
 def create_model_and_transforms(model_name: str, pretrained: Optional[str] = None, precision: str = "fp32", device="cpu",
                                 jit: bool = False, force_quick_gelu: bool = False, force_custom_text: bool = False,
                                 force_patch_dropout=None, force_image_size=None, pretrained_image: bool = False,
@@ -161,9 +150,21 @@ def create_model_and_transforms(model_name: str, pretrained: Optional[str] = Non
                          force_patch_dropout=force_patch_dropout, force_image_size=force_image_size,
                          pretrained_image=pretrained_image, pretrained_hf=pretrained_hf, cache_dir=cache_dir,
                          output_dict=output_dict, ops=ops)
-    det = _HostTransformOutOfScope("det_image_transform", det_image_size)
-    crop = _HostTransformOutOfScope("image_transform", model.visual.image_size)
-    return model, [det, crop], [det, crop]
+    # factory.py:303-350 of the reference: [det transform (ResizeLongest), crop transform (ResizeMaxSize)] for the distillation /
+    # region_clip datasets, the train-augmentation transform otherwise; the validation pair is always [det, crop]
+    from .transform import det_image_transform, image_transform
+    image_mean = image_mean or getattr(model.visual, "image_mean", None)
+    image_std = image_std or getattr(model.visual, "image_std", None)
+    kops = ops if ops is not None else getattr(getattr(model.visual, "engine", None), "ops", None)
+    val_det = det_image_transform(det_image_size, is_train=False, mean=image_mean, std=image_std, ops=kops)
+    val_img = image_transform(model.visual.image_size, is_train=False, mean=image_mean, std=image_std, resize_longest_max=True, ops=kops)
+    if dataset_type == "sanity_check":
+        train = image_transform(det_image_size, is_train=True, mean=image_mean, std=image_std, aug_cfg=aug_cfg)
+    elif dataset_type is not None and ("distill" in dataset_type or dataset_type in ("region_clip", "clipself", "clipself_proposals", "coop")):
+        train = [val_det, val_img]
+    else:
+        train = image_transform(model.visual.image_size, is_train=True, mean=image_mean, std=image_std, aug_cfg=aug_cfg)
+    return model, train, [val_det, val_img]
 
 
 def get_tokenizer(model_name):

@@ -293,6 +293,9 @@ class CustomCLIP(nn.Module):
         return features
 
     def encode_masks(self, image, masks, normalize=True, mask_attn=False):
+        if mask_attn:
+            raise NotImplementedError("mask_attn=True (attention-masked pooling, transformer.py:560-590) is not built; only mask pooling "
+                                      "of the dense map")
         mask_pooled = self.visual.mask_pool(image, masks)
         if normalize:
             mask_pooled = F.normalize(mask_pooled, dim=-1)
@@ -312,6 +315,13 @@ class ClipVisionTower(EVAVisionTower):
         self.output_dim = cfg.embed_dim
         self.grid_size = (cfg.grid, cfg.grid)
         self.patch_size = (cfg.patch_size, cfg.patch_size)
+
+    def extract_roi_features(self, x, normed_boxes, extract_type="v2", **kwargs):
+        """The reference dispatches `extract_type` for this family (open_clip/transformer.py:515-521): 'v2' = the dense map +
+        RoIAlign built here; 'v1' (attention-masked CLS queries per box) is not on the CLIPSelf path and not built."""
+        if extract_type != "v2":
+            raise NotImplementedError(f"extract_type={extract_type!r}: only the dense 'v2' path exists for the OpenAI-CLIP ViT family")
+        return super().extract_roi_features(x, normed_boxes)
 
     def _register_tables(self):
         pass                                                # no rotary tables in this family

@@ -50,7 +50,12 @@ class DataInfo:
     dataloader: object
 
     def set_epoch(self, epoch):
-        self.dataloader.epoch = epoch
+        """Epoch-dependent shuffles AND per-sample draws (grid choice, box order): a run resumed at epoch e continues with epoch e's
+        draws instead of replaying epoch 0's (epoch 0 keeps the loader's construction-time stream)."""
+        dl = self.dataloader
+        dl.epoch = epoch
+        if epoch and hasattr(dl, "rng") and hasattr(dl, "seed"):
+            dl.rng = random.Random(dl.seed + 7919 * epoch)
 
 
 def _read_ahead(images, order, num_batches, batch_size):
@@ -88,7 +93,7 @@ class GpuGridDistillLoader:
         self.templates = {c: grid_boxes(*c) for c in self.choices}
         self.num_batches = steps if steps is not None else len(images_u8) // batch_size
         self.num_samples = self.num_batches * batch_size
-        self.rng = random.Random(seed)
+        self.seed, self.rng = seed, random.Random(seed)
         self.epoch = 0
 
     def __len__(self):
@@ -143,7 +148,7 @@ class GpuProposalDistillLoader:
         self.min_size, self.max_size, self.max_anns = min_size, max_size, max_anns
         self.num_batches = steps if steps is not None else len(images_u8) // batch_size
         self.num_samples = self.num_batches * batch_size
-        self.rng = random.Random(seed)
+        self.seed, self.rng = seed, random.Random(seed)
         self.epoch = 0
 
     def __len__(self):

@@ -98,8 +98,12 @@ def main(argv):
     random_seed(args.seed, args.rank)
     if args.lock_image:
         model.lock_image_tower(unlocked_groups=args.lock_image_unlocked_groups, freeze_bn_stats=args.lock_image_freeze_bn_stats)
-    else:
-        model.lock_image_tower(unlocked_groups=model.visual.cfg.layers)
+    elif args.train_data:
+        # Without --lock-image the reference trains the whole visual tower (stem, positional embedding, final norm, head) plus
+        # logit_scale through the dense path; this engine differentiates transformer blocks only.  Every shipped recipe passes
+        # --lock-image (scripts/*.sh), so refuse instead of silently freezing what the reference would train.
+        raise NotImplementedError("training without --lock-image is not supported: only transformer blocks are trainable here "
+                                  "(pass --lock-image --lock-image-unlocked-groups N, as the reference's scripts do)")
     if is_master(args):
         with open(os.path.join(args.logs, args.name, "params.txt"), "w") as f:
             for name in sorted(vars(args)):
@@ -151,7 +155,9 @@ def main(argv):
             target_sd = student_teacher_ensemble(student_sd, teacher_sd, args.alpha)
         else:
             target_sd = student_sd
-        if "val" in data:                                       # main.py:300-342: the saved (ensembled) weights are what gets evaluated
+        eval_due = "val" in data and args.zeroshot_frequency != 0 and (
+            completed_epoch % args.zeroshot_frequency == 0 or completed_epoch == args.epochs)       # the condition of zero_shot_eval
+        if eval_due:                                            # main.py:300-342: the saved (ensembled) weights are what gets evaluated
             test_model = create_model(args.model, args.pretrained, device=device, precision=args.precision, cache_dir=None,
                                       trainable=False)
             test_model.load_state_dict(target_sd)

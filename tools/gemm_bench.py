@@ -294,7 +294,7 @@ def stream_ab():
     for name, flops, out, run in cases:
         line = f"{name} M={M}: "
         for rep in range(2):
-            for tag, f in (("cfg9", 0x90), ("cfg11", 0xB0), ("cfg11 no epilogue", 0x40B0), ("cfg11 232 CUs", 0xB0 | (24 << 20))):
+            for tag, f in (("cfg9", 0x90), ("cfg9 dephased", 0x1090), ("cfg11", 0xB0), ("cfg11 dephased", 0x10B0), ("cfg11 no epilogue", 0x40B0)):
                 for _ in range(2):
                     run(f)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
