@@ -261,7 +261,13 @@ __device__ __forceinline__ void epilogue_at(const GemmArgs& p, const f32x16 (&ac
             for (int it = 0; it < 8; ++it) {
                 const int row = min(row_base + rrow + it * 4, p.M - 1);
                 if (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
-                    xin[it] = *(const float4*)(p.extra + (size_t)row * p.ldc + col);
+                    // flags bit 12 (A/B switch): non-temporal accesses for the streams of the residual epilogue (read once / written once)
+                    if (p.dbg & 1) {
+                        const f32x4 t4 = __builtin_nontemporal_load((const f32x4*)(p.extra + (size_t)row * p.ldc + col));
+                        xin[it] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                    } else {
+                        xin[it] = *(const float4*)(p.extra + (size_t)row * p.ldc + col);
+                    }
                 } else {
                     const int img = row / p.group, t = row - img * p.group;
                     xin[it] = *(const float4*)(p.extra + (size_t)(t + 1) * p.ldc + col);
@@ -297,7 +303,11 @@ __device__ __forceinline__ void epilogue_at(const GemmArgs& p, const f32x16 (&ac
                     } else if (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
                         const float4 x = xin[it];
                         const float o[4] = {x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]};
-                        *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
+                        if (p.dbg & 1) {
+                            __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, (f32x4*)((float*)p.C + (size_t)row * p.ldc + col));
+                        } else {
+                            *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
+                        }
                         if (p.xb_out) {                       // bf16 copy of the new residual stream: A operand of the next LN-folded GEMM
                             U64 ob;
 #pragma unroll
@@ -545,7 +555,6 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
         if (ktiles > 1) stage_tile<A_INSTR, true, AUX_A>(p.A, p.lda, BK, smem + A_BYTES, wave * A_INSTR, lane, arow, achk);
     };
     prologue();
-    if (p.dbg & 1) dephase_start(ktiles, 4200);
     bool first = true;
     for (;;) {
         const int m0 = tm * BM, n0 = tn * BN, tn_cur = tn;

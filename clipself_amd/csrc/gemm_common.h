@@ -48,15 +48,6 @@ int cs_gemm_stream_launch(GemmArgs a, int epi, int reserve, hipStream_t stream);
 
 namespace {
 
-// De-phasing of the persistent workgroups (flags bit 12): all 256 workgroups start together and every output tile takes the same time,
-// so without it the whole chip reaches its store phase at once (a burst of 256 x 64-256 KiB into HBM while every matrix pipe idles)
-// and then its MFMA phase at once (HBM idle).  Workgroup b = 8 * c + xcd sleeps (c % 16) / 16 of one tile time before its first tile.
-__device__ __forceinline__ void dephase_start(int ktiles, int cycles_per_ktile) {
-    const int phase = ((int)blockIdx.x >> 3) & 15;
-    const int n = phase * ktiles * cycles_per_ktile / (16 * 1024);          // units of s_sleep 16 (~1024 cycles)
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
-}
-
 // One wave instruction fills 1 KiB = 8 tile rows (row group rg).  Lane l lands at rg*1024 + l*16, i.e. LDS row
 // rg*4 + (l>>4), slot l&15; element (tile row r, 16-byte chunk c) lives at LDS row r>>1, slot ((r&1)*8 | c) ^ ((r>>1)&15),
 // so the lane must fetch the chunk that this map sends to its slot.

@@ -54,8 +54,15 @@ __device__ __forceinline__ float both_halves(float v) {                     // v
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
+// CP = cache policy of the epilogue's streaming accesses (gfx950 aux bits: 0 default | 2 = nt | 16 = sc1 | 17 = sc0 sc1): outputs are
+// written once and read by a later kernel, the residual rows are read once -- neither should displace the operand panels in L2
+template <int CP>
 __device__ __forceinline__ void store16(const u32x4& v, __amdgpu_buffer_rsrc_t rs, unsigned off) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, CP);
+}
+template <int CP>
+__device__ __forceinline__ void store8(const u32x2& v, __amdgpu_buffer_rsrc_t rs, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, CP);
 }
 __device__ __forceinline__ float silu_mul(float u, float v) {               // hardware exp2 / rcp (1 ulp each; the result is rounded to bf16)
     return u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u)) * v;
@@ -76,7 +83,7 @@ struct EpiOps {
 
 // ---------------------------------------------------------------------------------------------------------------- SwiGLU
 // acc[i][0] = x1, acc[i][1] = x2 of hidden units hbase + col(e, lane>>5); out[row][hidden] = silu(x1) * x2 in bf16.
-template <bool LN, bool AUX>
+template <bool LN, bool AUX, int CP>
 __device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int tn, int wn, const EpiOps& eo) {
     const int l31 = lane & 31, hf = lane >> 5;
     const int hbase = tn * 128 + wn * 32;
@@ -137,7 +144,7 @@ __device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc
             unsigned x0 = pk[i][2 * pr][0], x1 = pk[i][2 * pr][1], y0 = pk[i][2 * pr + 1][0], y1 = pk[i][2 * pr + 1][1];
             swap32(x0, y0);              // lower half: own group 2pr | upper's group 2pr  = columns 16pr .. 16pr+7
             swap32(x1, y1);              // upper half: lower's group 2pr+1 | own group 2pr+1 = columns 16pr+8 .. 16pr+15
-            store16(u32x4{x0, x1, y0, y1}, rc, ok ? rowoff + 32u * pr : OOB);
+            store16<CP>(u32x4{x0, x1, y0, y1}, rc, ok ? rowoff + 32u * pr : OOB);
         }
     }
     if (AUX) {
@@ -148,13 +155,13 @@ __device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc
         for (int i = 0; i < 4; ++i) {
             const float s = both_halves(ssum[i]), q2 = both_halves(ssq[i]);
             const bool ok = colok && hf == 0 && row0 + i * 32 + l31 < p.M;
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(s), __float_as_uint(q2)}, rst, ok ? (unsigned)(i * 32 + l31) * 8u : OOB, 0, 0);
+            store8<CP>(u32x2{__float_as_uint(s), __float_as_uint(q2)}, rst, ok ? (unsigned)(i * 32 + l31) * 8u : OOB);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- bf16 (+activation)
-template <int ACT, bool LN>
+template <int ACT, bool LN, int CP>
 __device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, const EpiOps& eo) {
     const int l31 = lane & 31, hf = lane >> 5;
     float nm[4], rs[4];
@@ -198,7 +205,7 @@ __device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[
                 unsigned x0 = pk[i][2 * pr][0], x1 = pk[i][2 * pr][1], y0 = pk[i][2 * pr + 1][0], y1 = pk[i][2 * pr + 1][1];
                 swap32(x0, y0);
                 swap32(x1, y1);
-                store16(u32x4{x0, x1, y0, y1}, rc, ok ? rowoff + 32u * pr : OOB);
+                store16<CP>(u32x4{x0, x1, y0, y1}, rc, ok ? rowoff + 32u * pr : OOB);
             }
         }
     }
@@ -208,7 +215,7 @@ __device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[
 // out = extra + (LN ? rstd*(acc - mean*colsum) : acc) + bias; AUX: also a bf16 copy of out (xb_out) and per-(64-column slice, row)
 // partial (sum, sum of squares) of the fp32 outputs.  In place (C == extra) is the normal use: every element is read and written by
 // the same lane.
-template <bool LN, bool AUX>
+template <bool LN, bool AUX, int CP>
 __device__ __forceinline__ void epi_resid(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, int tn, int wn,
                                           const EpiOps& eo) {
     const int l31 = lane & 31, hf = lane >> 5;
@@ -240,7 +247,7 @@ __device__ __forceinline__ void epi_resid(const GemmArgs& p, const f32x16 (&acc)
             f32x4 x[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)                                  // masked lanes read zeros (out-of-range buffer load)
-                x[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? rowoff + 32u * q : OOB, 0, 0));
+                x[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? rowoff + 32u * q : OOB, 0, CP));
             unsigned pk[4][2];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -255,7 +262,7 @@ __device__ __forceinline__ void epi_resid(const GemmArgs& p, const f32x16 (&acc)
                         ssq[i] = fmaf(o[r], o[r], ssq[i]);
                     }
                 }
-                store16(__builtin_bit_cast(u32x4, o), rc, ok ? rowoff + 32u * q : OOB);
+                store16<CP>(__builtin_bit_cast(u32x4, o), rc, ok ? rowoff + 32u * q : OOB);
                 if (AUX) {
                     pk[q][0] = pack2(o[0], o[1]);
                     pk[q][1] = pack2(o[2], o[3]);
@@ -268,7 +275,7 @@ __device__ __forceinline__ void epi_resid(const GemmArgs& p, const f32x16 (&acc)
                     unsigned x0 = pk[2 * pr][0], x1 = pk[2 * pr][1], y0 = pk[2 * pr + 1][0], y1 = pk[2 * pr + 1][1];
                     swap32(x0, y0);
                     swap32(x1, y1);
-                    store16(u32x4{x0, x1, y0, y1}, rb, ok ? boff + 32u * pr : OOB);
+                    store16<CP>(u32x4{x0, x1, y0, y1}, rb, ok ? boff + 32u * pr : OOB);
                 }
             }
         }
@@ -281,7 +288,7 @@ __device__ __forceinline__ void epi_resid(const GemmArgs& p, const f32x16 (&acc)
         for (int i = 0; i < 4; ++i) {
             const float s = both_halves(ssum[i]), q2 = both_halves(ssq[i]);
             const bool ok = sliceok && hf == 0 && row0 + i * 32 + l31 < p.M;
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(s), __float_as_uint(q2)}, rst, ok ? (unsigned)(i * 32 + l31) * 8u : OOB, 0, 0);
+            store8<CP>(u32x2{__float_as_uint(s), __float_as_uint(q2)}, rst, ok ? (unsigned)(i * 32 + l31) * 8u : OOB);
         }
     }
 }
@@ -297,7 +304,7 @@ constexpr int epi_stores() {
 #define CS_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 // EPI: EPI_BF16 / EPI_GELU_BF16 / EPI_QGELU_BF16 / EPI_SWIGLU_BF16 / EPI_RESID_F32 (the latter with LN = folded LayerNorm, i.e. epilogue 6)
-template <int EPI, bool LN, bool AUX>
+template <int EPI, bool LN, bool AUX, int CP>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     constexpr bool SWI = EPI == EPI_SWIGLU_BF16, RES = EPI == EPI_RESID_F32;
     static_assert(SWI || RES || epi_is_bf16(EPI), "register epilogues");
@@ -393,7 +400,6 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         adv_a();
     }
 
-    if (p.dbg & 1) dephase_start(ktiles, 4200);
     int curA = 0, gpar = 0;                  // A slot of K tile g, parity of g
     bool after_epi = false;
     for (int tile = blockIdx.x; tile < ntiles; tile += G) {
@@ -480,22 +486,33 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         after_epi = true;
         load_epi_ops();
 
-        if constexpr (SWI) epi_swiglu<LN, AUX>(p, acc, lane, row0, tn, wn, eo);
-        else if constexpr (RES) epi_resid<LN, AUX>(p, acc, lane, row0, colw, tn, wn, eo);
-        else epi_bf16<epi_act(EPI), LN>(p, acc, lane, row0, colw, eo);
+        if constexpr (SWI) epi_swiglu<LN, AUX, CP>(p, acc, lane, row0, tn, wn, eo);
+        else if constexpr (RES) epi_resid<LN, AUX, CP>(p, acc, lane, row0, colw, tn, wn, eo);
+        else epi_bf16<epi_act(EPI), LN, CP>(p, acc, lane, row0, colw, eo);
     }
 #undef ISSUE_A
 #undef ISSUE_B
 }
 
-template <int EPI, bool LN, bool AUX>
-int launch_stream_t(const GemmArgs& a, unsigned grid, hipStream_t stream) {
+template <int EPI, bool LN, bool AUX, int CP>
+int launch_stream_cp(const GemmArgs& a, unsigned grid, hipStream_t stream) {
     constexpr size_t lds = 160 * 1024;
-    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, LN, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, LN, AUX, CP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
-    hipLaunchKernelGGL((gemm_stream_kernel<EPI, LN, AUX>), dim3(grid), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((gemm_stream_kernel<EPI, LN, AUX, CP>), dim3(grid), dim3(512), lds, stream, a);
     CS_LAUNCH_CHECK();
     return 0;
+}
+
+// flags bits 12-13 (a.dbg & 3): cache policy of the epilogue's streaming accesses, A/B switch of tools/gemm_bench.py
+template <int EPI, bool LN, bool AUX>
+int launch_stream_t(const GemmArgs& a, unsigned grid, hipStream_t stream) {
+    switch (a.dbg & 3) {
+        case 1: return launch_stream_cp<EPI, LN, AUX, 2>(a, grid, stream);        // nt
+        case 2: return launch_stream_cp<EPI, LN, AUX, 16>(a, grid, stream);       // sc1
+        case 3: return launch_stream_cp<EPI, LN, AUX, 17>(a, grid, stream);       // sc0 sc1
+        default: return launch_stream_cp<EPI, LN, AUX, 0>(a, grid, stream);
+    }
 }
 
 template <int EPI>

@@ -38,6 +38,19 @@ def cosine_distill_loss(student, teacher, ops, weight=1.0):
     return _CosineDistillFn.apply(student, teacher, ops, float(weight))
 
 
+def mark_all_valid(normed_boxes, flag=None):
+    """Producers of device-resident batches record whether every box slot is valid (they build the boxes on the host and know), so the
+    step does not have to read the validity column back from the GPU.  Returns the tensor."""
+    normed_boxes._cs_all_valid = bool((normed_boxes[..., -1] > 0.5).all()) if flag is None else bool(flag)
+    return normed_boxes
+
+
+def _known_all_valid(normed_boxes):
+    if normed_boxes.device.type == "cpu":
+        return bool((normed_boxes[..., -1] > 0.5).all())                      # host tensor: free to look at
+    return getattr(normed_boxes, "_cs_all_valid", None)
+
+
 class CLIPSelf:
     """Besides the reference's call contract, the method can run the frozen teacher one batch ahead: `prefetch_teacher(next_batch,
     ...)` launches the teacher forward of the NEXT batch on a high-priority side stream, where it overlaps the student's backward,
@@ -50,9 +63,13 @@ class CLIPSelf:
         self._side = None
 
     @staticmethod
-    def _valid_crops(normed_boxes, image_crops):
+    def _valid_crops(normed_boxes, image_crops, all_valid=None):
+        """all_valid: what the producer of the batch already knows about the validity column (`mark_all_valid`); None = look at the
+        tensor, which costs a host sync when it lives on the GPU (the reference's boolean indexing pays the same sync)."""
         valid = normed_boxes[..., -1] > 0.5                                   # [B, max_boxes]
-        if bool(valid.all()):                                                 # dense batch: no gather needed
+        if all_valid is None:
+            all_valid = bool(valid.all())
+        if all_valid:                                                         # dense batch: no gather needed
             return valid, True, image_crops.reshape(-1, *image_crops.shape[2:])
         return valid, False, image_crops[valid]
 
@@ -65,7 +82,7 @@ class CLIPSelf:
         _, normed_boxes, image_crops = batch
         boxes_d = normed_boxes.to(device=device, dtype=torch.float32, non_blocking=True)
         crops_d = image_crops.to(device=device, dtype=cast_dtype, non_blocking=True)
-        _, _, crops = self._valid_crops(boxes_d, crops_d)
+        _, _, crops = self._valid_crops(boxes_d, crops_d, _known_all_valid(normed_boxes))
         main = torch.cuda.current_stream(device)
         if self._side is None:
             # single GPU: the teacher is the long pole, let it win CUs.  Data parallel: normal priority, so that RCCL's kernels
@@ -108,7 +125,7 @@ class CLIPSelf:
             tar = random.choice(choices)
             images = F.interpolate(images, size=(tar, tar), mode="bilinear")
 
-        valid, dense, crops = self._valid_crops(normed_boxes, image_crops)
+        valid, dense, crops = self._valid_crops(normed_boxes, image_crops, _known_all_valid(batch[1]))
         if dense:
             B, k = valid.shape
             idx = torch.arange(B, device=normed_boxes.device, dtype=torch.float32).repeat_interleave(k)[:, None]

@@ -78,11 +78,17 @@ class RegionCLIP(nn.Module):
         labels = sel[:, 4].long()
         box_features = model.encode_pseudo_boxes(images, rois, normalize=True, extract_type=getattr(args, "extract_type", "v2"))
         temp = model.logit_scale.exp().detach()
+        # the kernels take the temperature as a launch argument: read it back only when logit_scale actually changed (it receives no
+        # gradient in this method -- `.detach()` above -- so that is once)
+        ver = (id(model.logit_scale), model.logit_scale._version)
+        if getattr(self, "_temp_cache", (None, None))[0] != ver:
+            self._temp_cache = (ver, float(temp))
+        temp_f = self._temp_cache[1]
         nouns = self.noun_embeddings.to(box_features.device)
         appeared = get_fed_loss_inds(labels, 100, nouns.shape[0])
         # position of every box's label inside the sampled column set
         pos = torch.full((nouns.shape[0],), -1, dtype=torch.int32, device=labels.device)
         pos[appeared] = torch.arange(len(appeared), dtype=torch.int32, device=labels.device)
-        loss_cls = _FedBCEFn.apply(box_features, model.visual.engine.ops, nouns[appeared], pos[labels].contiguous(), float(temp),
+        loss_cls = _FedBCEFn.apply(box_features, model.visual.engine.ops, nouns[appeared], pos[labels].contiguous(), temp_f,
                                    float(getattr(args, "contrast_weight", 1.0)))
         return dict(loss_contrast=loss_cls), len(images), temp

@@ -1,6 +1,7 @@
 """CPU: the dataset-side logic of the GPU loaders (clipself_amd/training/data.py) with the pixel work done by Pillow through the
 reference ops -- grid choices, shuffling and truncation, crop_scale enlargement, box rescaling, proposal filtering and fallback."""
 import numpy as np
+import pytest
 import torch
 
 from clipself_amd.training.data import GpuGridDistillLoader, GpuProposalDistillLoader, SyntheticPanopticVal, grid_boxes, grid_choices
@@ -267,3 +268,38 @@ def test_region_clip_batches_from_coco_files(tmp_path):
     s = min(64 / 97, 64 / 131) / 64
     assert torch.allclose(b[1, :4], torch.tensor([3.0, 2.0, 28.0, 21.0]) * s) and b[:, 5].tolist() == [1, 1, 1, 1, 0, 0]
     assert set(b[:4, 4].tolist()) <= {0.0, 1.0} and det.shape == (3, 64, 64)
+
+
+def test_create_model_and_transforms_returns_working_transforms():
+    """open_clip.create_model_and_transforms hands the distillation datasets `[det transform, crop transform]` like the reference
+    (src/open_clip/factory.py:303-350): callables PIL image -> normalised tensor.  det = ResizeLongest (right/bottom padding),
+    crop = ResizeMaxSize (centred padding) -- checked against the Pillow statement of both (oracle/pil_crops_ref.py)."""
+    from PIL import Image
+    from clipself_amd.open_clip import create_model_and_transforms
+    from oracle.ops_ref import RefOps
+    from oracle.pil_crops_ref import pil_crops
+    model, train_tf, val_tf = create_model_and_transforms("EVA02-CLIP-B-16", "eva", cache_dir=None, det_image_size=96,
+                                                          dataset_type="grid_distill", ops=RefOps())
+    assert isinstance(train_tf, list) and len(train_tf) == 2 and len(val_tf) == 2
+    rng = np.random.default_rng(5)
+    arr = rng.integers(0, 256, size=(75, 120, 3), dtype=np.uint8)
+    img = Image.fromarray(arr, mode="RGB")
+    whole = np.array([[0.0, 0.0, 120.0, 75.0]], np.float32)
+    det = train_tf[0](img)
+    assert tuple(det.shape) == (3, 96, 96) and det.dtype == torch.float32
+    assert np.array_equal(det.numpy(), pil_crops(arr, whole, 96, pad_center=False)[0])
+    crop = train_tf[1](img.crop((10, 5, 90, 70)))
+    S = model.visual.image_size
+    assert tuple(crop.shape) == (3, S, S)
+    assert np.array_equal(crop.numpy(), pil_crops(arr, np.array([[10.0, 5.0, 90.0, 70.0]], np.float32), S, pad_center=True)[0])
+    # zero padding sits right/bottom for the det transform (normalised zero = -mean/std), centred for the crop transform
+    pad_val = (0.0 - 0.48145466) / 0.26862954
+    assert abs(float(det[0, -1, -1]) - pad_val) < 1e-6 and abs(float(det[0, 95, 0]) - pad_val) < 1e-6        # 120x75 -> 96x60: rows 60.. are padding
+    assert abs(float(crop[0, 0, 0]) - pad_val) < 1e-6 and abs(float(crop[0, -1, 0]) - pad_val) < 1e-6
+    # arrays and grayscale PIL images are accepted like PIL RGB images
+    assert torch.equal(train_tf[0](arr), det)
+    assert tuple(train_tf[1](img.convert("L")).shape) == (3, S, S)
+    # outside the distillation datasets the reference returns its train-time augmentation: not built, raises when called
+    _, aug, _ = create_model_and_transforms("EVA02-CLIP-B-16", "eva", cache_dir=None, dataset_type=None, ops=RefOps())
+    with pytest.raises(NotImplementedError):
+        aug(img)

@@ -93,7 +93,7 @@ def test_cfg1_full_size_step_inline_and_prefetch_schedules_agree():
         s = fresh_student.encode_pseudo_boxes(images, torch.cat([idx, boxes[..., :4].reshape(-1, 4)], 1)).double()
         want = float(1 - torch.nn.functional.cosine_similarity(s, t, dim=-1).mean())
         _log(f"cfg1 full size loss: kernel {loss_i:.7f} vs fp64 on the same features {want:.7f}")
-        assert abs(loss_i - want) < 5e-6
+        assert abs(loss_i - want) < 2e-5
         # two images of the batch against the oracle
         sd = seeded_visual_state(cfg, 0)
         ref = eva_ref.encode_pseudo_boxes(sd, cfg, images[:2].cpu(), [b[:, :4].cpu() for b in boxes[:2]])

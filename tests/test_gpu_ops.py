@@ -670,3 +670,22 @@ def test_gemm_persistent_raster_modes_cover_every_tile(hip, ref, M, N, K, epi, m
         Cr = torch.empty(M, cols, dtype=BF)
         ref.gemm_nt(A, B, Cr, bias, epi=epi, group=group)
         check(f"gemm_raster_mode[{M},{N},{K}] epi={epi} mode={mode:#x}", got, Cr, TOL_BF)
+
+
+def test_factory_transforms_run_the_crop_kernel_and_equal_pillow(hip):
+    """The `[det transform, crop transform]` pair of create_model_and_transforms on the GPU (cs_crop_resize_u8 behind the reference's
+    transform API): PIL image in, normalised tensor out, bit-identical to the Pillow statement of ResizeLongest / ResizeMaxSize."""
+    import numpy as np
+    from PIL import Image
+    from clipself_amd.open_clip.transform import det_image_transform, image_transform
+    from oracle.pil_crops_ref import pil_crops
+    rng = np.random.default_rng(9)
+    for (H, W), size in (((427, 640), 224), ((500, 333), 336), ((96, 130), 1024)):
+        arr = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+        img = Image.fromarray(arr, mode="RGB")
+        whole = np.array([[0.0, 0.0, float(W), float(H)]], np.float32)
+        det = det_image_transform(size, is_train=False, ops=hip)(img)
+        crop = image_transform(size, is_train=False, resize_longest_max=True, ops=hip)(img)
+        assert det.is_cuda and tuple(det.shape) == (3, size, size)
+        assert np.array_equal(det.cpu().numpy(), pil_crops(arr, whole, size, pad_center=False)[0]), (H, W, size, "det")
+        assert np.array_equal(crop.cpu().numpy(), pil_crops(arr, whole, size, pad_center=True)[0]), (H, W, size, "crop")

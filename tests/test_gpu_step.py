@@ -475,7 +475,7 @@ def test_tiny_openai_vit_step_matches_reference_goldens(golden_dir, quick):
     images, boxes, crops = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"])
     with torch.no_grad():
         t = teacher.encode_image(crops.flatten(0, 1).cuda())
-        s = student.encode_pseudo_boxes(images.cuda(), [b[:, :4].cuda() for b in boxes])
+        s = student.encode_pseudo_boxes(images.cuda(), [b[:, :4].cuda() for b in boxes], extract_type="v2")
         d = student.encode_dense(images.cuda(), keep_shape=False)
     _log(f"tiny-openai quick={quick} teacher rel={rel(t, g[tag + 'teacher']):.3e} 1-cos={one_minus_cos(t, g[tag + 'teacher']):.2e}; "
          f"roi rel={rel(s, g[tag + 'student_roi']):.3e} 1-cos={one_minus_cos(s, g[tag + 'student_roi']):.2e}; dense rel={rel(d, g[tag + 'dense']):.3e}")
@@ -485,7 +485,7 @@ def test_tiny_openai_vit_step_matches_reference_goldens(golden_dir, quick):
     if not quick:
         im64, bx64, _ = synthetic_batch(2, 3, 64, cfg.image_size, seed=78)
         with torch.no_grad():
-            r64 = student.encode_pseudo_boxes(im64.cuda(), [b[:, :4].cuda() for b in bx64])
+            r64 = student.encode_pseudo_boxes(im64.cuda(), [b[:, :4].cuda() for b in bx64], extract_type="v2")
         assert rel(r64, g["roi64"]) < 2e-2                  # rescaled positional embedding (8x8 grid)
     opt = FlatAdamW(student, lr=rec["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=rec["wd"])
     sched = cosine_lr(opt, rec["lr"], rec["warmup"], rec["total"])
@@ -539,7 +539,7 @@ def test_vitb16_openai_cfg1_matches_reference_goldens(golden_dir):
         if step == 0:
             with torch.no_grad():
                 t = teacher.encode_image(batch[2].flatten(0, 1).cuda())
-                s = student.encode_pseudo_boxes(batch[0].cuda(), [b[:, :4].cuda() for b in batch[1]])
+                s = student.encode_pseudo_boxes(batch[0].cuda(), [b[:, :4].cuda() for b in batch[1]], extract_type="v2")
             cos = torch.nn.functional.cosine_similarity(t, s, dim=-1).cpu()
             _log(f"vitb16 teacher_slice rel={rel(t[:4, :16], g['teacher_slice']):.3e} roi_slice rel={rel(s[:4, :16], g['student_roi_slice']):.3e} "
                  f"cos maxabs={float((cos - torch.from_numpy(g['cos'])).abs().max()):.3e}")

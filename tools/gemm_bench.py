@@ -294,7 +294,7 @@ def stream_ab():
     for name, flops, out, run in cases:
         line = f"{name} M={M}: "
         for rep in range(2):
-            for tag, f in (("cfg9", 0x90), ("cfg9 dephased", 0x1090), ("cfg11", 0xB0), ("cfg11 dephased", 0x10B0), ("cfg11 no epilogue", 0x40B0)):
+            for tag, f in (("cfg9", 0x90), ("cfg9 nt", 0x1090), ("cfg11", 0xB0), ("cfg11 nt", 0x10B0), ("cfg11 sc1", 0x20B0), ("cfg11 sc0sc1", 0x30B0), ("cfg11 no epilogue", 0x40B0)):
                 for _ in range(2):
                     run(f)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
