@@ -1164,9 +1164,9 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
         // split rings: +1..3 % over the lockstep 2-stage ring on the tower shapes; as a persistent tile loop (bf16 / GELU / SwiGLU /
         // residual epilogues, case 9 falls back to 7 for the others): another -2.4 % (q|k|v) / -4.9 % (W1|W2) per launch
         // ... and with register-level epilogues on a continuous operand ring (gemm_stream.hip) for the bf16 / QuickGELU / SwiGLU outputs:
-        // q|k|v 1600 -> 1500 us, W1|W2 2840 -> 2470 us per 2048-crop launch; the fp32 residual epilogues are HBM-bound and keep
-        // the slab (full-line) epilogue of the persistent kernel (profiles/r02_a_stream_gemm.md)
-        if (cfg == 3 && use_glds) cfg = PP_DEFAULT ? 5 : ((EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) ? 9 : 11);
+        // q|k|v 1600 -> 1480 us, W1|W2 2840 -> 2430 us per 2048-crop launch; the fp32 residual epilogues (HBM-bound, whole-line slab
+        // form) proj 870 -> 800 us, w3 1510 -> 1445 us (profiles/r02_a_stream_gemm.md)
+        if (cfg == 3 && use_glds) cfg = PP_DEFAULT ? 5 : 11;
     }
     const int ns = sp[(cfg == 4 || cfg == 8) ? 2 : (cfg >= 5 ? 3 : cfg)];   // cfgs 5..7, 9 and 10 are 256x256 variants
     a.ktiles_per_split = (ktiles + ns - 1) / ns;

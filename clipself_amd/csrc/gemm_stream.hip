@@ -18,7 +18,8 @@
 //     masked rows / columns keep that count exact).
 //   * The epilogue's own operand loads (row statistics, column constants, residual rows) are ordinary loads: hipcc waits vmcnt(0) at
 //     their first use, which also retires the next tile's operand DMA -- issued one to two K tiles earlier, it has landed by then.
-//     (Measured: a variant that fetched these operands ahead of the last K tile's DMA with hand-counted waits was not faster.)
+//     (Measured: variants that fetched these operands during the tile's last K iteration -- by hand-counted inline-asm loads ahead of
+//     that iteration's DMA, or by ordinary loads behind a burst issue of its DMA -- were not faster.)
 //
 // Epilogues: bf16 (+bias, optional GELU / QuickGELU, optional folded LayerNorm), fused SwiGLU (+folded LayerNorm, +row statistics of the
 // hidden matrix), fp32 residual (+folded LayerNorm, + bf16 copy and row statistics of the new stream).  Reference call sites:
@@ -137,7 +138,7 @@ __device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc
     const __amdgpu_buffer_rsrc_t rc = make_rsrc((const __bf16*)p.C + (size_t)row0 * p.ldc + hbase);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const bool ok = colok && row0 + i * 32 + l31 < p.M;
+        const bool ok = colok && row0 + i * 32 + l31 < p.M && !(p.dbg & 8);      // dbg 8: timing ablation, every store masked
         const unsigned rowoff = (unsigned)((i * 32 + l31) * p.ldc + 8 * hf) * 2u;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
@@ -172,10 +173,9 @@ __device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[
     }
     const __amdgpu_buffer_rsrc_t rc = make_rsrc((const __bf16*)p.C + (size_t)row0 * p.ldc + colw);
     const int sl0 = hf << 4;
+    unsigned pk[2][4][4][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const bool colok = colw + j * 32 < p.N;                         // wave-uniform: N % 32 == 0
-        unsigned pk[4][4][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float ov[4][4];
@@ -192,17 +192,22 @@ __device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                pk[i][q][0] = pack2(ov[i][0], ov[i][1]);
-                pk[i][q][1] = pack2(ov[i][2], ov[i][3]);
+                pk[j][i][q][0] = pack2(ov[i][0], ov[i][1]);
+                pk[j][i][q][1] = pack2(ov[i][2], ov[i][3]);
             }
         }
+    }
+    // stores in row-block order: the four 32-byte pieces of a row's 128-byte line (two column tiles x two group pairs) leave back to back
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = colok && row0 + i * 32 + l31 < p.M;
+    for (int i = 0; i < 4; ++i) {
+        const bool rowok = row0 + i * 32 + l31 < p.M && !(p.dbg & 8);        // dbg 8: timing ablation, every store masked
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = rowok && colw + j * 32 < p.N;                    // wave-uniform column test: N % 32 == 0
             const unsigned rowoff = (unsigned)((i * 32 + l31) * p.ldc + j * 32 + 8 * hf) * 2u;
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
-                unsigned x0 = pk[i][2 * pr][0], x1 = pk[i][2 * pr][1], y0 = pk[i][2 * pr + 1][0], y1 = pk[i][2 * pr + 1][1];
+                unsigned x0 = pk[j][i][2 * pr][0], x1 = pk[j][i][2 * pr][1], y0 = pk[j][i][2 * pr + 1][0], y1 = pk[j][i][2 * pr + 1][1];
                 swap32(x0, y0);
                 swap32(x1, y1);
                 store16<CP>(u32x4{x0, x1, y0, y1}, rc, ok ? rowoff + 32u * pr : OOB);
@@ -211,13 +216,15 @@ __device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------- fp32 residual
-// out = extra + (LN ? rstd*(acc - mean*colsum) : acc) + bias; AUX: also a bf16 copy of out (xb_out) and per-(64-column slice, row)
-// partial (sum, sum of squares) of the fp32 outputs.  In place (C == extra) is the normal use: every element is read and written by
-// the same lane.
-template <bool LN, bool AUX, int CP>
-__device__ __forceinline__ void epi_resid(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, int tn, int wn,
-                                          const EpiOps& eo) {
+// ================================================================================================================ slab epilogues
+// The register epilogues above store 32 bytes per row per instruction (quarter lines); the L2 merges the pieces, but every piece is a
+// request of its own.  The slab variants send the packed results through a wave-private LDS slab -- the A / B ring slots the tile's
+// last K iteration has just finished with (one extra workgroup barrier per tile), XOR-swizzled -- and read them back row-contiguous,
+// so that 8 (bf16: 128 bytes), 4 (SwiGLU: 64 bytes) or 16 (fp32: 256 bytes) adjacent lanes store one whole row segment.
+// Thanks to the transposed accumulators the slab is written with 8- / 16-byte DS stores (four consecutive columns per lane).
+
+template <int ACT, bool LN, int CP>
+__device__ __forceinline__ void epi_bf16_slab(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, const EpiOps& eo, char* slab) {
     const int l31 = lane & 31, hf = lane >> 5;
     float nm[4], rs[4];
 #pragma unroll
@@ -225,92 +232,211 @@ __device__ __forceinline__ void epi_resid(const GemmArgs& p, const f32x16 (&acc)
         rs[i] = LN ? eo.rstd[i] : 1.f;
         nm[i] = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
     }
-    const __amdgpu_buffer_rsrc_t rc = make_rsrc((const float*)p.C + (size_t)row0 * p.ldc + colw);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.extra + (size_t)row0 * p.ldc + colw);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(AUX ? (const void*)(p.xb_out + (size_t)row0 * p.ldxb + colw) : (const void*)p.C);
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc((const __bf16*)p.C + (size_t)row0 * p.ldc + colw);
+    const int sl0 = hf << 4;
+    const int piece = lane & 7, col = colw + piece * 8;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        // [64 rows][128 bytes]: 8-byte slot s of row r at r*128 + (s ^ ((r & 7) << 1)) * 8
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float bq[4], cq[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int sl = sl0 + ((j * 32 + 8 * q + r) << 2);
+                    bq[r] = lane_bcast(sl, eo.cb);
+                    cq[r] = LN ? lane_bcast(sl, eo.cc) : 0.f;
+                }
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = half * 2 + ii, lrow = ii * 32 + l31;
+                    float ov[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = acc[i][j][q * 4 + r];
+                        ov[r] = activate_s<ACT>(LN ? fmaf(rs[i], a, fmaf(nm[i], cq[r], bq[r])) : a + bq[r]);
+                    }
+                    const int s8 = (j * 8 + 2 * q + hf) ^ ((lrow & 7) << 1);
+                    *(uint2*)(slab + lrow * 128 + s8 * 8) = make_uint2(pack2(ov[0], ov[1]), pack2(ov[2], ov[3]));
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int lrow = (lane >> 3) + 8 * k, rrel = half * 64 + lrow;
+            const uint4 w = *(const uint4*)(slab + lrow * 128 + ((piece ^ (lrow & 7)) << 4));
+            const bool ok = row0 + rrel < p.M && col < p.N && !(p.dbg & 8);
+            store16<CP>(u32x4{w.x, w.y, w.z, w.w}, rc, ok ? (unsigned)(rrel * p.ldc + piece * 8) * 2u : OOB);
+        }
+    }
+}
+
+template <bool LN, bool AUX, int CP>
+__device__ __forceinline__ void epi_swiglu_slab(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int tn, int wn, const EpiOps& eo,
+                                                char* slab) {
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int hbase = tn * 128 + wn * 32;
+    const bool colok = hbase < p.group;
+    float nm[4], rs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rs[i] = LN ? eo.rstd[i] : 1.f;
+        nm[i] = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
+    }
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
     const int sl0 = hf << 4;
+    // [128 rows][64 bytes]: 8-byte slot s of row r at r*64 + (s ^ (((r >> 1) & 3) << 1)) * 8
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const bool colok = colw + j * 32 < p.N;
-        float bq[16], cq[16];
+    for (int q = 0; q < 4; ++q) {
+        float hv[4][4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int sl = sl0 + ((j * 32 + 8 * (e >> 2) + (e & 3)) << 2);
-            bq[e] = lane_bcast(sl, eo.cb);
-            cq[e] = LN ? lane_bcast(sl, eo.cc) : 0.f;
+        for (int r = 0; r < 4; ++r) {
+            const int e = q * 4 + r;
+            const int sl = sl0 + ((8 * q + r) << 2);
+            const float b1 = lane_bcast(sl, eo.cb), b2 = lane_bcast(sl + 128, eo.cb);
+            float c1 = 0.f, c2 = 0.f;
+            if (LN) { c1 = lane_bcast(sl, eo.cc); c2 = lane_bcast(sl + 128, eo.cc); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float u = acc[i][0][e], v = acc[i][1][e];
+                if (LN) {
+                    u = fmaf(rs[i], u, fmaf(nm[i], c1, b1));
+                    v = fmaf(rs[i], v, fmaf(nm[i], c2, b2));
+                } else {
+                    u += b1;
+                    v += b2;
+                }
+                hv[i][r] = silu_mul(u, v);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bool ok = colok && row0 + i * 32 + l31 < p.M;
-            const unsigned rowoff = (unsigned)((i * 32 + l31) * p.ldc + j * 32 + 4 * hf) * 4u;
-            f32x4 x[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)                                  // masked lanes read zeros (out-of-range buffer load)
-                x[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? rowoff + 32u * q : OOB, 0, CP));
-            unsigned pk[4][2];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int e = q * 4 + r;
-                    const float a = acc[i][j][e];
-                    o[r] = x[q][r] + (LN ? fmaf(rs[i], a, fmaf(nm[i], cq[e], bq[e])) : a + bq[e]);
-                    if (AUX) {
-                        ssum[i] += o[r];
-                        ssq[i] = fmaf(o[r], o[r], ssq[i]);
-                    }
-                }
-                store16<CP>(__builtin_bit_cast(u32x4, o), rc, ok ? rowoff + 32u * q : OOB);
-                if (AUX) {
-                    pk[q][0] = pack2(o[0], o[1]);
-                    pk[q][1] = pack2(o[2], o[3]);
-                }
-            }
+            const unsigned d0 = pack2(hv[i][0], hv[i][1]), d1 = pack2(hv[i][2], hv[i][3]);
             if (AUX) {
-                const unsigned boff = (unsigned)((i * 32 + l31) * p.ldxb + j * 32 + 8 * hf) * 2u;
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    unsigned x0 = pk[2 * pr][0], x1 = pk[2 * pr][1], y0 = pk[2 * pr + 1][0], y1 = pk[2 * pr + 1][1];
-                    swap32(x0, y0);
-                    swap32(x1, y1);
-                    store16<CP>(u32x4{x0, x1, y0, y1}, rb, ok ? boff + 32u * pr : OOB);
-                }
+                const float a0 = __uint_as_float(d0 << 16), b0 = __uint_as_float(d0 & 0xffff0000u);
+                const float a1 = __uint_as_float(d1 << 16), b1v = __uint_as_float(d1 & 0xffff0000u);
+                ssum[i] += (a0 + b0) + (a1 + b1v);
+                ssq[i] = fmaf(a0, a0, fmaf(b0, b0, fmaf(a1, a1, fmaf(b1v, b1v, ssq[i]))));
             }
+            const int lrow = i * 32 + l31;
+            const int s8 = (2 * q + hf) ^ (((lrow >> 1) & 3) << 1);
+            *(uint2*)(slab + lrow * 64 + s8 * 8) = make_uint2(d0, d1);
         }
     }
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc((const __bf16*)p.C + (size_t)row0 * p.ldc + hbase);
+    const int piece = lane & 3;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int lrow = (lane >> 2) + 16 * k;
+        const uint4 w = *(const uint4*)(slab + lrow * 64 + ((piece ^ ((lrow >> 1) & 3)) << 4));
+        const bool ok = colok && row0 + lrow < p.M && !(p.dbg & 8);
+        store16<CP>(u32x4{w.x, w.y, w.z, w.w}, rc, ok ? (unsigned)(lrow * p.ldc + piece * 8) * 2u : OOB);
+    }
     if (AUX) {
-        const size_t slice = (size_t)tn * 4 + wn;                       // 64-column slices: tile column tn has four
+        const size_t slice = (size_t)tn * 4 + wn;
         const __amdgpu_buffer_rsrc_t rst = make_rsrc(p.stats_part + (slice * p.M + row0) * 2);
-        const bool sliceok = colw < p.N;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float s = both_halves(ssum[i]), q2 = both_halves(ssq[i]);
-            const bool ok = sliceok && hf == 0 && row0 + i * 32 + l31 < p.M;
+            const bool ok = colok && hf == 0 && row0 + i * 32 + l31 < p.M && !(p.dbg & 8);
             store8<CP>(u32x2{__float_as_uint(s), __float_as_uint(q2)}, rst, ok ? (unsigned)(i * 32 + l31) * 8u : OOB);
         }
     }
 }
 
+// fp32 residual through the slab: acc (+ folded LayerNorm + bias, applied while the lane still owns a whole row) of one 32-row block goes
+// [32 rows][256 bytes] (16-byte slot s of row r at r*256 + (s ^ (r & 15)) * 16) and comes back 16 lanes per row; residual rows, outputs
+// and the bf16 copy are whole-line accesses.
+template <bool LN, bool AUX, int CP>
+__device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, int tn, int wn,
+                                               const EpiOps& eo, char* slab) {
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int rrow = lane >> 4, piece = lane & 15, col = colw + piece * 4;
+    const bool colok = col < p.N;
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc((const float*)p.C + (size_t)row0 * p.ldc + colw);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.extra + (size_t)row0 * p.ldc + colw);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(AUX ? (const void*)(p.xb_out + (size_t)row0 * p.ldxb + colw) : (const void*)p.C);
+    const size_t slice = (size_t)tn * 4 + wn;
+    const __amdgpu_buffer_rsrc_t rst = make_rsrc(AUX ? (const void*)(p.stats_part + (slice * p.M + row0) * 2) : (const void*)p.C);
+    const int sl0 = hf << 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // the residual rows of the block are requested before the accumulators go through the slab
+        f32x4 xin[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rrel = i * 32 + rrow + 4 * it;
+            const bool ok = colok && row0 + rrel < p.M && !(p.dbg & 8);
+            xin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(rrel * p.ldc + piece * 4) * 4u : OOB, 0, CP));
+        }
+        const float rs = LN ? eo.rstd[i] : 1.f, nm = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int sl = sl0 + ((j * 32 + 8 * q + r) << 2);
+                    const float b = lane_bcast(sl, eo.cb);
+                    const float a = acc[i][j][q * 4 + r];
+                    t[r] = LN ? fmaf(rs, a, fmaf(nm, lane_bcast(sl, eo.cc), b)) : a + b;
+                }
+                const int s16 = (j * 8 + 2 * q + hf) ^ (l31 & 15);
+                *(f32x4*)(slab + l31 * 256 + s16 * 16) = t;
+            }
+        const int sel = lane & 15;
+        float st_s = 0.f, st_q = 0.f;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int lrow = rrow + 4 * it, rrel = i * 32 + lrow;
+            const f32x4 sv = *(const f32x4*)(slab + lrow * 256 + ((piece ^ (lrow & 15)) << 4));
+            const bool ok = colok && row0 + rrel < p.M && !(p.dbg & 8);
+            const f32x4 o = xin[it] + sv;
+            store16<CP>(__builtin_bit_cast(u32x4, o), rc, ok ? (unsigned)(rrel * p.ldc + piece * 4) * 4u : OOB);
+            if (AUX) {
+                store8<CP>(u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])}, rb, ok ? (unsigned)(rrel * p.ldxb + piece * 4) * 2u : OOB);
+                // a row's 64 columns sit in 16 adjacent lanes (DPP butterfly); lane (lane & 15) == it keeps iteration it's row, so the
+                // 32 rows of the block leave in one 256-byte store below
+                float ps = 0.f, pq = 0.f;
+                if (colok) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { ps += o[t]; pq = fmaf(o[t], o[t], pq); }
+                }
+                const float a = sum_lanes16(ps), b = sum_lanes16(pq);
+                if (sel == it) { st_s = a; st_q = b; }
+            }
+        }
+        if (AUX) {
+            const int rrel = i * 32 + rrow + 4 * sel;
+            const bool ok = sel < 8 && row0 + rrel < p.M && colw < p.N && !(p.dbg & 8);
+            store8<CP>(u32x2{__float_as_uint(st_s), __float_as_uint(st_q)}, rst, ok ? (unsigned)rrel * 8u : OOB);
+        }
+        __builtin_amdgcn_sched_barrier(0);       // keep the next block's 8 residual loads (32 registers) out of this block
+    }
+}
+
 // store instructions one epilogue issues per wave (exact: masked lanes keep their instruction, see OOB)
-template <int EPI, bool AUX>
+template <int EPI, bool AUX, bool SLAB>
 constexpr int epi_stores() {
     if (EPI == EPI_SWIGLU_BF16) return 8 + (AUX ? 4 : 0);
-    if (EPI == EPI_RESID_F32) return 32 + (AUX ? 16 + 4 : 0);
+    if (EPI == EPI_RESID_F32) return 32 + (AUX ? 32 + 4 : 0);
     return 16;
 }
 
 #define CS_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 // EPI: EPI_BF16 / EPI_GELU_BF16 / EPI_QGELU_BF16 / EPI_SWIGLU_BF16 / EPI_RESID_F32 (the latter with LN = folded LayerNorm, i.e. epilogue 6)
-template <int EPI, bool LN, bool AUX, int CP>
+template <int EPI, bool LN, bool AUX, bool SLAB>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
+    static_assert(SLAB || EPI != EPI_RESID_F32, "the fp32 residual epilogue exists in the slab form only (whole-line traffic)");
+    constexpr int CP = 0;                      // default cache policy: the L2 must merge partial-line stores (nt / sc1 measured slower)
     constexpr bool SWI = EPI == EPI_SWIGLU_BF16, RES = EPI == EPI_RESID_F32;
     static_assert(SWI || RES || epi_is_bf16(EPI), "register epilogues");
     constexpr int BM = 256, BN = 256, WN = 4, TM = 128, TN = 64, FM = 4, FN = 2;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-    constexpr int S = epi_stores<EPI, AUX>();
+    constexpr int S = epi_stores<EPI, AUX, SLAB>() < 56 ? epi_stores<EPI, AUX, SLAB>() : 56;     // vmcnt is a 6-bit counter; fewer = safe
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -415,7 +541,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         EpiOps eo;
         // epilogue operands: LayerNorm statistics of the rows of the wave's four blocks (lane = row), constants of its 64 columns (lane = column)
-        auto load_epi_ops = [&]() {
+        auto load_epi_ops = [&](int ln) {
+            const int l31 = ln & 31, hf = ln >> 5, lane = ln;
 #pragma unroll
             for (int i = 0; i < 4; ++i) eo.mean[i] = eo.rstd[i] = 0.f;
             eo.cb = eo.cc = 0.f;
@@ -484,35 +611,50 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         for (int kt = 0; kt < ktiles; ++kt) ktile();
         if (p.dbg & 4) continue;               // timing ablation (tools/gemm_bench.py): no epilogue, results are wrong
         after_epi = true;
-        load_epi_ops();
-
-        if constexpr (SWI) epi_swiglu<LN, AUX, CP>(p, acc, lane, row0, tn, wn, eo);
-        else if constexpr (RES) epi_resid<LN, AUX, CP>(p, acc, lane, row0, colw, tn, wn, eo);
-        else epi_bf16<epi_act(EPI), LN, CP>(p, acc, lane, row0, colw, eo);
+        // Everything the epilogue derives from the lane id (swizzled slab addresses, store offsets, ds_bpermute sources: ~80 values) is
+        // loop-invariant; hoisted out of the tile loop it would live -- spilled -- across the whole MFMA loop.  An opaque copy of the
+        // lane id keeps those computations inside the epilogue.
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        if constexpr (SLAB) {
+            // the slabs alias the A / B slots K tile g has just been read from: every wave must be done with them.  The barrier at the top
+            // of the next K iteration then keeps that iteration's DMA (which refills exactly these slots) behind all slab traffic.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            char* const slab = wave < 4 ? smem + (curA == 0 ? 2 : curA - 1) * A_BYTES + wave * 8192 : b_ring + (gpar ^ 1) * B_BYTES + (wave - 4) * 8192;
+            load_epi_ops(lane_e);
+            if constexpr (RES) {
+                epi_resid_slab<LN, AUX, CP>(p, acc, lane_e, row0, colw, tn, wn, eo, slab);
+            } else {
+                if constexpr (SWI) epi_swiglu_slab<LN, AUX, CP>(p, acc, lane_e, row0, tn, wn, eo, slab);
+                else epi_bf16_slab<epi_act(EPI), LN, CP>(p, acc, lane_e, row0, colw, eo, slab);
+            }
+        } else {
+            load_epi_ops(lane_e);
+            if constexpr (SWI) epi_swiglu<LN, AUX, CP>(p, acc, lane_e, row0, tn, wn, eo);
+            else epi_bf16<epi_act(EPI), LN, CP>(p, acc, lane_e, row0, colw, eo);
+        }
     }
 #undef ISSUE_A
 #undef ISSUE_B
 }
 
-template <int EPI, bool LN, bool AUX, int CP>
-int launch_stream_cp(const GemmArgs& a, unsigned grid, hipStream_t stream) {
+template <int EPI, bool LN, bool AUX, bool SLAB>
+int launch_stream_v(const GemmArgs& a, unsigned grid, hipStream_t stream) {
     constexpr size_t lds = 160 * 1024;
-    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, LN, AUX, CP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, LN, AUX, SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
-    hipLaunchKernelGGL((gemm_stream_kernel<EPI, LN, AUX, CP>), dim3(grid), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((gemm_stream_kernel<EPI, LN, AUX, SLAB>), dim3(grid), dim3(512), lds, stream, a);
     CS_LAUNCH_CHECK();
     return 0;
 }
 
-// flags bits 12-13 (a.dbg & 3): cache policy of the epilogue's streaming accesses, A/B switch of tools/gemm_bench.py
+// fp32 residual epilogues: always through the LDS slab (measured 6-25 % faster than quarter-line register stores).  bf16 / SwiGLU:
+// straight from registers by default, through the slab with flags bit 12 (a.dbg & 1) -- a tie on the tower shapes, A/B switch.
 template <int EPI, bool LN, bool AUX>
 int launch_stream_t(const GemmArgs& a, unsigned grid, hipStream_t stream) {
-    switch (a.dbg & 3) {
-        case 1: return launch_stream_cp<EPI, LN, AUX, 2>(a, grid, stream);        // nt
-        case 2: return launch_stream_cp<EPI, LN, AUX, 16>(a, grid, stream);       // sc1
-        case 3: return launch_stream_cp<EPI, LN, AUX, 17>(a, grid, stream);       // sc0 sc1
-        default: return launch_stream_cp<EPI, LN, AUX, 0>(a, grid, stream);
-    }
+    if constexpr (EPI == EPI_RESID_F32) return launch_stream_v<EPI, LN, AUX, true>(a, grid, stream);
+    else return (a.dbg & 1) ? launch_stream_v<EPI, LN, AUX, true>(a, grid, stream) : launch_stream_v<EPI, LN, AUX, false>(a, grid, stream);
 }
 
 template <int EPI>

@@ -164,3 +164,39 @@ def test_cfg4_l14_336_regionclip_real_config(monkeypatch):
     assert bs == 32 and torch.isfinite(out["loss"]).item() and torch.isfinite(g).all().item() and float(g.abs().sum()) > 0
     after = student.visual.engine.master
     assert torch.isfinite(after).all().item() and not torch.equal(after, before)
+
+
+def test_recipe_shape_1024px_student_4097_tokens():
+    """SURVEY section 8(f) N1 at the shape the shipped recipe trains (scripts/train_clipself_coco_image_patches_eva_vitb16.sh:
+    --det-image-size 1024, --batch-size 2): the B/16 student on 1024^2 images = 64 x 64 + 1 = 4097 tokens (bicubic pos-embed rescale,
+    regenerated RoPE tables, 19 key chunks in the attention kernels).  One image against the CPU oracle (forward), then one full
+    recipe-shaped step (2 images, 20 grid boxes each) with finite loss / gradients, timed."""
+    import time
+    from oracle import eva_ref
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.train import train_step
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    student, teacher = _pair(cfg, 0)
+    sd = seeded_visual_state(cfg, 0)
+    images, boxes, _ = synthetic_batch(1, 6, 1024, 224, seed=17)
+    rois = [b[:, :4] for b in boxes]
+    with torch.no_grad():
+        want = eva_ref.encode_pseudo_boxes(sd, cfg, images, rois)
+        got = student.encode_pseudo_boxes(images.cuda(), [r.cuda() for r in rois])
+    r, c = rel(got, want), one_minus_cos(got, want)
+    _log(f"N1 recipe shape: B/16 student at 1024^2 (4097 tokens) RoI features vs oracle: rel-L2 {r:.3e}, max 1-cos {c:.2e}")
+    assert r < 2e-2 and c < 5e-4
+    batch = tuple(t.cuda() for t in synthetic_batch(2, 20, 1024, 224, seed=18))
+    opt = FlatAdamW(student, lr=1e-5, weight_decay=0.1)
+    method, args = CLIPSelf(), _args(skip_scheduler=True)
+    out, _, _ = train_step(student, method, batch, opt, None, 0, teacher, args)          # warm-up (allocations, table builds)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for step in range(3):
+        out, _, _ = train_step(student, method, batch, opt, None, step + 1, teacher, args)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    g = student.visual.engine.grad
+    _log(f"N1 recipe shape: step of 2 images x 1024^2 + 40 teacher crops: {ms:.1f} ms/step ({2e3 / ms:.1f} images/s), loss {float(out['loss']):.5f}")
+    assert torch.isfinite(out["loss"]).item() and torch.isfinite(g).all().item() and float(g.abs().sum()) > 0

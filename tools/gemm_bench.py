@@ -294,7 +294,7 @@ def stream_ab():
     for name, flops, out, run in cases:
         line = f"{name} M={M}: "
         for rep in range(2):
-            for tag, f in (("cfg9", 0x90), ("cfg9 nt", 0x1090), ("cfg11", 0xB0), ("cfg11 nt", 0x10B0), ("cfg11 sc1", 0x20B0), ("cfg11 sc0sc1", 0x30B0), ("cfg11 no epilogue", 0x40B0)):
+            for tag, f in (("cfg9", 0x90), ("cfg11", 0xB0), ("cfg11 slab", 0x10B0), ("cfg11 no epilogue", 0x40B0), ("cfg11 stores masked", 0x80B0)):
                 for _ in range(2):
                     run(f)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -307,7 +307,7 @@ def stream_ab():
                 line += f"{tag} {us:7.1f} us ({flops / us / 1e6:4.0f} TF/s) | "
         print(line, flush=True)
         if "resid" not in name:            # race screen: every run of the streaming kernel must reproduce its own first result bit for bit
-            for f in (0xB0,):
+            for f in (0xB0, 0x10B0):
                 run(f)
                 ref = out.clone()
                 bad = 0
