@@ -45,6 +45,7 @@ struct GemmArgs {
 // gemm_stream.hip: streaming persistent kernel with register-level epilogues.  Returns 1 when the problem is outside what it covers
 // (the caller falls back to gemm_persist_kernel), 0 on launch, < 0 on error.
 int cs_gemm_stream_launch(GemmArgs a, int epi, int reserve, hipStream_t stream);
+int cs_gemm_stream_launch_f8(GemmArgs a, int epi, int reserve, hipStream_t stream);
 
 namespace {
 

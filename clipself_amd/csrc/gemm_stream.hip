@@ -162,13 +162,13 @@ __device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc
 }
 
 // ---------------------------------------------------------------------------------------------------------------- bf16 (+activation)
-template <int ACT, bool LN, int CP>
+template <int ACT, bool LN, int CP, bool F8 = false>
 __device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, const EpiOps& eo) {
     const int l31 = lane & 31, hf = lane >> 5;
     float nm[4], rs[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        rs[i] = LN ? eo.rstd[i] : 1.f;
+        rs[i] = (LN || F8) ? eo.rstd[i] : 1.f;            // F8: the row scale of the quantised A operand
         nm[i] = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
     }
     const __amdgpu_buffer_rsrc_t rc = make_rsrc((const __bf16*)p.C + (size_t)row0 * p.ldc + colw);
@@ -183,11 +183,11 @@ __device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[
             for (int r = 0; r < 4; ++r) {
                 const int sl = sl0 + ((j * 32 + 8 * q + r) << 2);
                 const float b = lane_bcast(sl, eo.cb);
-                const float c = LN ? lane_bcast(sl, eo.cc) : 0.f;
+                const float c = (LN || F8) ? lane_bcast(sl, eo.cc) : 0.f;       // LN: folded column sum; F8: column scale of the B operand
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float a = acc[i][j][q * 4 + r];
-                    ov[i][r] = activate_s<ACT>(LN ? fmaf(rs[i], a, fmaf(nm[i], c, b)) : a + b);
+                    ov[i][r] = activate_s<ACT>(F8 ? fmaf(rs[i] * c, a, b) : LN ? fmaf(rs[i], a, fmaf(nm[i], c, b)) : a + b);
                 }
             }
 #pragma unroll
@@ -348,7 +348,7 @@ __device__ __forceinline__ void epi_swiglu_slab(const GemmArgs& p, const f32x16 
 // fp32 residual through the slab: acc (+ folded LayerNorm + bias, applied while the lane still owns a whole row) of one 32-row block goes
 // [32 rows][256 bytes] (16-byte slot s of row r at r*256 + (s ^ (r & 15)) * 16) and comes back 16 lanes per row; residual rows, outputs
 // and the bf16 copy are whole-line accesses.
-template <bool LN, bool AUX, int CP>
+template <bool LN, bool AUX, int CP, bool F8 = false>
 __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, int tn, int wn,
                                                const EpiOps& eo, char* slab) {
     const int l31 = lane & 31, hf = lane >> 5;
@@ -370,7 +370,7 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
             const bool ok = colok && row0 + rrel < p.M && !(p.dbg & 8);
             xin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(rrel * p.ldc + piece * 4) * 4u : OOB, 0, CP));
         }
-        const float rs = LN ? eo.rstd[i] : 1.f, nm = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
+        const float rs = (LN || F8) ? eo.rstd[i] : 1.f, nm = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -381,7 +381,7 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
                     const int sl = sl0 + ((j * 32 + 8 * q + r) << 2);
                     const float b = lane_bcast(sl, eo.cb);
                     const float a = acc[i][j][q * 4 + r];
-                    t[r] = LN ? fmaf(rs, a, fmaf(nm, lane_bcast(sl, eo.cc), b)) : a + b;
+                    t[r] = F8 ? fmaf(rs * lane_bcast(sl, eo.cc), a, b) : LN ? fmaf(rs, a, fmaf(nm, lane_bcast(sl, eo.cc), b)) : a + b;
                 }
                 const int s16 = (j * 8 + 2 * q + hf) ^ (l31 & 15);
                 *(f32x4*)(slab + l31 * 256 + s16 * 16) = t;
@@ -428,9 +428,14 @@ constexpr int epi_stores() {
 #define CS_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 // EPI: EPI_BF16 / EPI_GELU_BF16 / EPI_QGELU_BF16 / EPI_SWIGLU_BF16 / EPI_RESID_F32 (the latter with LN = folded LayerNorm, i.e. epilogue 6)
-template <int EPI, bool LN, bool AUX, bool SLAB>
+// F8: A and B hold e4m3 bytes (K = bytes per row, a multiple of 128: one K tile = 128 contraction steps in the same 128-byte LDS rows),
+// contracted with the block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 at unit block scales (2x the bf16 MFMA rate at half the operand
+// bytes); the per-row scale of A (p.ln_rstd) and per-row scale of B (p.ln_colsum) are applied in the epilogue.
+template <int EPI, bool LN, bool AUX, bool SLAB, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     static_assert(SLAB || EPI != EPI_RESID_F32, "the fp32 residual epilogue exists in the slab form only (whole-line traffic)");
+    static_assert(!F8 || (!LN && !AUX && (EPI == EPI_BF16 || EPI == EPI_RESID_F32)), "fp8 operands: bf16 and fp32-residual outputs");
+    constexpr int ES = F8 ? 1 : 2;               // operand element size in bytes
     constexpr int CP = 0;                      // default cache policy: the L2 must merge partial-line stores (nt / sc1 measured slower)
     constexpr bool SWI = EPI == EPI_SWIGLU_BF16, RES = EPI == EPI_RESID_F32;
     static_assert(SWI || RES || epi_is_bf16(EPI), "register epilogues");
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     const int wm = wave / WN, wn = wave - wm * WN;
     const int hf = lane >> 5, l31 = lane & 31;
     char* const b_ring = smem + 3 * A_BYTES;
-    const int ntiles = p.tiles_m * p.tiles_n, ktiles = p.K / BK;
+    const int ntiles = p.tiles_m * p.tiles_n, ktiles = p.K / (F8 ? 128 : BK);
     const int a_base = ((wm * TM + l31) >> 1) << 8, b_base = ((wn * TN + l31) >> 1) << 8;
     const int par8 = (l31 & 1) << 3, sw = l31 >> 1;
     const int G = gridDim.x;
@@ -458,21 +463,21 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     auto set_a = [&](int tile) {
         int tm, tn;
         tile_of_id(p, tile, ntiles, tm, tn);
-        a_src = (const char*)(p.A + (size_t)tm * BM * p.lda);
+        a_src = (const char*)p.A + (size_t)tm * BM * p.lda * ES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int tr, chk;
             lane_source(wave * 4 + i, lane, tr, chk);
-            avoff[i] = (unsigned)(min(tr, p.M - 1 - tm * BM) * p.lda + chk * 8) * 2u;
+            avoff[i] = (unsigned)(min(tr, p.M - 1 - tm * BM) * p.lda * ES + chk * 16);
         }
     };
     auto set_b = [&](int tile) {
         int tm, tn;
         tile_of_id(p, tile, ntiles, tm, tn);
         if (SWI) {         // tile rows [w*64 + jj*32 + t] <- weight row jj*Hd + (tn*128 + w*32 + t): x1 | x2 of one hidden unit share lane and register
-            b_src = (const char*)(p.B + (size_t)tn * (BN / 2) * p.ldb);
+            b_src = (const char*)p.B + (size_t)tn * (BN / 2) * p.ldb * ES;
         } else {
-            b_src = (const char*)(p.B + (size_t)tn * BN * p.ldb);
+            b_src = (const char*)p.B + (size_t)tn * BN * p.ldb * ES;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             } else {
                 rel = min(tr, p.N - 1 - tn * BN);
             }
-            bvoff[i] = (unsigned)(rel * p.ldb + chk * 8) * 2u;
+            bvoff[i] = (unsigned)(rel * p.ldb * ES + chk * 16);
         }
     };
     auto adv_a = [&]() {
@@ -546,11 +551,11 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) eo.mean[i] = eo.rstd[i] = 0.f;
             eo.cb = eo.cc = 0.f;
-            if (LN) {
+            if (LN || F8) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = min(row0 + i * 32 + l31, p.M - 1);
-                    eo.mean[i] = p.ln_mean[r];
+                    if (LN) eo.mean[i] = p.ln_mean[r];
                     eo.rstd[i] = p.ln_rstd[r];
                 }
             }
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             if (SWI) co = hf * p.group + min(tn * 128 + wn * 32 + l31, p.group - 1);
             else co = min(colw + lane, p.N - 1);
             if (p.bias) eo.cb = p.bias[co];
-            if (LN) eo.cc = p.ln_colsum[co];
+            if (LN || F8) eo.cc = p.ln_colsum[co];
         };
 
         auto ktile = [&]() {
@@ -576,6 +581,43 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             const char* lb = b_ring + gpar * B_BYTES + b_base;
             const int slot_a2 = curA == 0 ? 2 : curA - 1, slot_b1 = gpar ^ 1;
             bool a_iss = false, b_iss = false;
+            if constexpr (F8) {
+                typedef __attribute__((ext_vector_type(8))) int i32x8;
+                typedef __attribute__((ext_vector_type(4))) int i32x4;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {               // 64 contraction steps each: 32 bytes per lane and operand row
+                    const int c0 = 4 * s2 + 2 * hf;
+                    const int off0 = ((par8 | c0) ^ sw) << 4, off1 = ((par8 | (c0 + 1)) ^ sw) << 4;
+                    i32x8 a8[FM], b8[FN];
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) {
+                        const i32x4 lo = *(const i32x4*)(la + i * (16 * 256) + off0), hi = *(const i32x4*)(la + i * (16 * 256) + off1);
+                        a8[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const i32x4 lo = *(const i32x4*)(lb + j * (16 * 256) + off0), hi = *(const i32x4*)(lb + j * (16 * 256) + off1);
+                        b8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+                    if (s2 == 0) {
+                        if (b_ok) { ISSUE_B(0, slot_b1); ISSUE_B(1, slot_b1); ISSUE_B(2, slot_b1); ISSUE_B(3, slot_b1); }
+                    } else if (a_ok) {
+                        ISSUE_A(0, slot_a2); ISSUE_A(1, slot_a2); ISSUE_A(2, slot_a2); ISSUE_A(3, slot_a2);
+                    }
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)       // e4m3 x e4m3, unit (2^0) block scales
+                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                    if (s2 == 0) {
+                        b_iss = b_ok;
+                        if (b_ok) adv_b();
+                    } else {
+                        a_iss = a_ok;
+                        if (a_ok) adv_a();
+                    }
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int off = ((par8 | (ks * 2 + hf)) ^ sw) << 4;
@@ -604,6 +646,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                     if (a_ok) adv_a();
                 }
             }
+            }
             pendA = a_iss;
             curA = curA == 2 ? 0 : curA + 1;
             gpar ^= 1;
@@ -624,7 +667,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             char* const slab = wave < 4 ? smem + (curA == 0 ? 2 : curA - 1) * A_BYTES + wave * 8192 : b_ring + (gpar ^ 1) * B_BYTES + (wave - 4) * 8192;
             load_epi_ops(lane_e);
             if constexpr (RES) {
-                epi_resid_slab<LN, AUX, CP>(p, acc, lane_e, row0, colw, tn, wn, eo, slab);
+                epi_resid_slab<LN, AUX, CP, F8>(p, acc, lane_e, row0, colw, tn, wn, eo, slab);
             } else {
                 if constexpr (SWI) epi_swiglu_slab<LN, AUX, CP>(p, acc, lane_e, row0, tn, wn, eo, slab);
                 else epi_bf16_slab<epi_act(EPI), LN, CP>(p, acc, lane_e, row0, colw, eo, slab);
@@ -632,7 +675,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         } else {
             load_epi_ops(lane_e);
             if constexpr (SWI) epi_swiglu<LN, AUX, CP>(p, acc, lane_e, row0, tn, wn, eo);
-            else epi_bf16<epi_act(EPI), LN, CP>(p, acc, lane_e, row0, colw, eo);
+            else epi_bf16<epi_act(EPI), LN, CP, F8>(p, acc, lane_e, row0, colw, eo);
         }
     }
 #undef ISSUE_A
@@ -662,7 +705,29 @@ int launch_stream_bf16(const GemmArgs& a, unsigned grid, hipStream_t stream) {
     return a.ln_mean ? launch_stream_t<EPI, true, false>(a, grid, stream) : launch_stream_t<EPI, false, false>(a, grid, stream);
 }
 
+template <int EPI, bool SLAB>
+int launch_stream_f8(const GemmArgs& a, unsigned grid, hipStream_t stream) {
+    constexpr size_t lds = 160 * 1024;
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, false, false, SLAB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL((gemm_stream_kernel<EPI, false, false, SLAB, true>), dim3(grid), dim3(512), lds, stream, a);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
+
+// fp8 (e4m3) operands with per-row scales: C = row_scale[m] * col_scale[n] * (A8 . B8^T) + bias (+ extra), epi 0 = bf16 out, 2 = fp32
+// residual (in place allowed).  K = bytes per operand row = contraction length padded to a multiple of 128 with zeros.
+int cs_gemm_stream_launch_f8(GemmArgs a, int epi, int reserve, hipStream_t stream) {
+    a.tiles_m = (a.M + 255) / 256;
+    a.tiles_n = (a.N + 255) / 256;
+    const long ntiles = (long)a.tiles_m * a.tiles_n;
+    const long cap = 256 - (reserve > 0 && reserve < 200 ? reserve : 0);
+    const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
+    if (epi == EPI_BF16) return launch_stream_f8<EPI_BF16, false>(a, grid, stream);
+    return launch_stream_f8<EPI_RESID_F32, true>(a, grid, stream);
+}
 
 // Returns 1 when the problem is outside what the register epilogues cover (the caller falls back to gemm_persist_kernel), 0 on launch,
 // < 0 on error.  `a` arrives with M/N/K, leading dimensions, operands and epilogue operands set (gemm_nt_impl); reserve = CUs to leave free.
@@ -696,4 +761,28 @@ int cs_gemm_stream_launch(GemmArgs a, int epi, int reserve, hipStream_t stream) 
     }
     if (epi == EPI_BF16) return launch_stream_bf16<EPI_BF16>(a, grid, stream);
     return launch_stream_bf16<EPI_QGELU_BF16>(a, grid, stream);
+}
+
+// C ABI: fp8 (OCP e4m3) operands quantised row-wise by cs_quant_rows_fp8 -- BASELINE configs[4] "fp8 MFMA weights".
+//   C[m, n] = row_scale[m] * col_scale[n] * sum_k A8[m, k] * B8[n, k] + bias[n]  (+ extra[m, n] for epi 2)
+//   epi 0: C bf16 [M, ldc];  epi 2: C fp32 [M, ldc] = extra + ..., in place allowed.  K8 = bytes per operand row (contraction length padded
+//   to a multiple of 128 with zero bytes), lda / ldb = row strides in bytes.  flags bits 20-26 as cs_gemm_nt (compute units left free).
+extern "C" int cs_gemm_nt_f8(const void* A8, const void* B8, void* C, const float* bias, const float* extra, const float* row_scale,
+                             const float* col_scale, int M, int N, int K8, int lda, int ldb, int ldc, int epi, int flags, hipStream_t stream) {
+    CS_CHECK_ARG(M > 0 && N > 0 && K8 > 0 && K8 % 128 == 0, "cs_gemm_nt_f8: K8=%d must be a positive multiple of 128 (M=%d N=%d)", K8, M, N);
+    CS_CHECK_ARG(epi == EPI_BF16 || epi == EPI_RESID_F32, "cs_gemm_nt_f8: epilogue %d (0 = bf16 out, 2 = fp32 residual)", epi);
+    CS_CHECK_ARG(N % 32 == 0 && ldc % 4 == 0 && lda >= K8 && ldb >= K8 && lda % 16 == 0 && ldb % 16 == 0,
+                 "cs_gemm_nt_f8: N %% 32, ldc %% 4, lda/ldb >= K8 and multiples of 16 bytes");
+    CS_CHECK_ARG(((uintptr_t)A8 % 16) == 0 && ((uintptr_t)B8 % 16) == 0 && ((uintptr_t)C % 16) == 0, "cs_gemm_nt_f8: operands must be 16-byte aligned");
+    CS_CHECK_ARG(row_scale && col_scale, "cs_gemm_nt_f8: row and column scales are required");
+    CS_CHECK_ARG(epi != EPI_RESID_F32 || (extra && ((uintptr_t)extra % 16) == 0), "cs_gemm_nt_f8: epilogue 2 needs 16-byte aligned extra");
+    CS_CHECK_ARG((long)ldc * 128 * 4 < 0x70000000L, "cs_gemm_nt_f8: ldc too large");
+    GemmArgs a;
+    a.A = (const __bf16*)A8; a.B = (const __bf16*)B8; a.C = C; a.bias = bias; a.extra = extra;
+    a.M = M; a.N = N; a.K = K8; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.group = 0;
+    a.tiles_m = a.tiles_n = 0; a.ktiles_per_split = K8 / 128; a.split_stride = 0; a.gm = 8; a.rm = 0; a.nsplit = 1;
+    a.ln_mean = nullptr; a.ln_rstd = row_scale; a.ln_colsum = col_scale; a.stats_part = nullptr; a.xb_out = nullptr; a.ldxb = 0;
+    a.reserve = (flags >> 20) & 127;
+    a.dbg = (flags >> 12) & 15;
+    return cs_gemm_stream_launch_f8(a, epi, a.reserve, stream);
 }

@@ -148,6 +148,11 @@ class EvaEngine:
         # stream and its row statistics, the q|k|v and W1|W2 GEMMs apply the normalisation in their epilogues (_teacher_block_folded)
         self.fold_block_ln = not trainable
         self.fold = {}
+        # BASELINE configs[4] "fp8 MFMA weights": the forward linears of the non-folded (training / dense) schedule run on e4m3 operands --
+        # weight shadows quantised per output row (refreshed after every AdamW step), activations per token row by cs_quant_rows_fp8,
+        # contraction by the block-scaled fp8 MFMA, fp32 accumulate; backward (dgrad / wgrad) keeps the bf16 operands.  enable_fp8_forward().
+        self.fp8_forward = False
+        self.w8 = {}
         if trainable:
             self.grad = ops.zeros((self.numel,), F32)
             self.exp_avg = ops.zeros((self.numel,), F32)
@@ -202,6 +207,8 @@ class EvaEngine:
             self.sync_transposed()
         if self.fold_sub_ln:
             self._build_folds()
+        if self.fp8_forward:
+            self.sync_fp8()
 
     def _build_folds(self):
         """gamma (.) W in bf16, its row sums, and W.beta + b for proj and w3 of every block (one-time, after a weight load)."""
@@ -249,6 +256,45 @@ class EvaEngine:
             self.ops.transpose_bf16(self.shadow[o:o + 2 * Hd * C].view(2 * Hd, C), self._wt_alloc((i, "w12"), 2 * Hd, C))
             self.ops.transpose_bf16(self.storage_of(self.shadow, b + "mlp.w3.weight"), self._wt_alloc((i, "w3"), C, Hd))
         self.ops.transpose_bf16(self.w[self.prefix + "head.weight"], self._wt_alloc("head", self.cfg.embed_dim, C))
+
+    # ------------------------------------------------------------------------------------------ fp8 forward operands
+    def _fp8_rows(self, X):
+        """bf16 [M,K] -> (e4m3 bytes [M, K padded to 128], fp32 row scales [M])."""
+        M, K = X.shape
+        q = self.ops.empty((M, _round_up(K, 128)), torch.uint8)
+        sc = self.ops.empty((M,), F32)
+        self.ops.quant_rows_fp8(X, q, sc)
+        return q, sc
+
+    def sync_fp8(self, blocks=None):
+        """e4m3 shadows (+ per-output-row scales) of the four weight matrices of every block, from the bf16 shadows."""
+        cfg, C, Hd = self.cfg, self.cfg.width, self.Hp
+        for i in (range(cfg.layers) if blocks is None else blocks):
+            b = f"{self.prefix}blocks.{i}."
+            o = self.offsets[b + "attn.q_proj.weight"][0]
+            self.w8[(i, "qkv")] = self._fp8_rows(self.shadow[o:o + 3 * C * C].view(3 * C, C))
+            self.w8[(i, "proj")] = self._fp8_rows(self.w[b + "attn.proj.weight"])
+            o = self.offsets[b + "mlp.w1.weight"][0]
+            self.w8[(i, "w12")] = self._fp8_rows(self.shadow[o:o + 2 * Hd * C].view(2 * Hd, C))
+            self.w8[(i, "w3")] = self._fp8_rows(self.storage_of(self.shadow, b + "mlp.w3.weight"))
+
+    def enable_fp8_forward(self, on: bool = True):
+        self.fp8_forward = bool(on)
+        self.w8 = {}
+        if on:
+            self.sync_fp8()
+
+    def _linear(self, i, key, X, W, out, bias, extra=None, epi=EPI_BF16, rows=None):
+        """out = X . W^T + bias (+ extra): the bf16 MFMA GEMM, or -- fp8_forward -- the e4m3 GEMM on the quantised copy of X and the weight's
+        e4m3 shadow (`rows` = row range of the stacked weight that W is a slice of)."""
+        if not self.fp8_forward:
+            self.ops.gemm_nt(X, W, out, bias=bias, extra=extra, epi=epi)
+            return
+        xq, sx = self._fp8_rows(X)
+        w8, sw = self.w8[(i, key)]
+        if rows is not None:
+            w8, sw = w8[rows[0]:rows[1]], sw[rows[0]:rows[1]]
+        self.ops.gemm_nt_f8(xq, w8, out, sx, sw, bias=bias, extra=extra, epi=epi)
 
     def set_trainable_blocks(self, unlocked_groups: int):
         """visual.lock(unlocked_groups) (eva_vit_model.py:500-516): only the last n blocks train
@@ -350,19 +396,19 @@ class EvaEngine:
             return self._block_post_folded(i, b, x, att, part, M)
         if with_attn:
             qkv = ops.empty((M, 3 * C), BF16)
-            ops.gemm_nt(ln1, wqkv, qkv, bias=bqkv, epi=EPI_BF16)
+            self._linear(i, "qkv", ln1, wqkv, qkv, bqkv)
             att = ops.empty((M, C), BF16)
             lse = ops.empty((B * H, N), F32) if keep else None
             ops.attn_fwd(qkv, cos, sin, att, lse, B, N, H, cfg.head_width ** -0.5)
         else:
             att = ops.empty((M, C), BF16)      # v only: every token "attends" to itself (proj_without_attn)
-            ops.gemm_nt(ln1, wqkv[2 * C:], att, bias=bqkv[2 * C:], epi=EPI_BF16)
-        x2 = self._block_post(b, x, att, M, st, save, inplace)
+            self._linear(i, "qkv", ln1, wqkv[2 * C:], att, bqkv[2 * C:], rows=(2 * C, 3 * C))
+        x2 = self._block_post(i, b, x, att, M, st, save, inplace)
         if keep:
             save.update(x0=x, ln1=ln1, st1=(m1, r1), qkv=qkv, lse=lse, att=att, with_attn=with_attn)
         return x2
 
-    def _block_post(self, b, x, att, M, st, save, inplace):
+    def _block_post(self, i, b, x, att, M, st, save, inplace):
         """Everything after the attention core: inner_attn_ln -> proj (+x) -> norm2 -> SwiGLU -> ffn_ln -> w3 (+x1)."""
         ops, cfg = self.ops, self.cfg
         C, Hd, Hl, eps = cfg.width, self.Hp, cfg.hidden, cfg.ln_eps
@@ -372,7 +418,7 @@ class EvaEngine:
         m2, r2 = st()
         ops.layernorm_fwd(att, self.p[b + "attn.inner_attn_ln.weight"], self.p[b + "attn.inner_attn_ln.bias"], iln, m2, r2, eps)
         x1 = x if inplace else ops.empty((M, C), F32)
-        ops.gemm_nt(iln, self.w[b + "attn.proj.weight"], x1, bias=self.p[b + "attn.proj.bias"], extra=x, epi=EPI_RESID_F32)
+        self._linear(i, "proj", iln, self.w[b + "attn.proj.weight"], x1, self.p[b + "attn.proj.bias"], extra=x, epi=EPI_RESID_F32)
 
         ln2 = ops.empty((M, C), BF16)
         m3, r3 = st()
@@ -380,9 +426,9 @@ class EvaEngine:
         w12, b12 = self._w12(b)
         hid = ops.empty((M, Hd), BF16)
         x12 = None
-        if keep:
+        if keep or self.fp8_forward:
             x12 = ops.empty((M, 2 * Hd), BF16)
-            ops.gemm_nt(ln2, w12, x12, bias=b12, epi=EPI_BF16)
+            self._linear(i, "w12", ln2, w12, x12, b12)
             ops.swiglu_fwd(x12, hid)
         else:
             ops.gemm_nt(ln2, w12, hid, bias=b12, epi=EPI_SWIGLU_BF16, group=Hd)
@@ -390,8 +436,8 @@ class EvaEngine:
         m4, r4 = st()
         ops.layernorm_fwd(hid[:, :Hl], self.p[b + "mlp.ffn_ln.weight"], self.p[b + "mlp.ffn_ln.bias"], fln[:, :Hl], m4, r4, eps)
         x2 = x1 if inplace else ops.empty((M, C), F32)
-        ops.gemm_nt(fln, self.storage_of(self.shadow, b + "mlp.w3.weight"), x2, bias=self.p[b + "mlp.w3.bias"], extra=x1,
-                    epi=EPI_RESID_F32)
+        self._linear(i, "w3", fln, self.storage_of(self.shadow, b + "mlp.w3.weight"), x2, self.p[b + "mlp.w3.bias"], extra=x1,
+                     epi=EPI_RESID_F32)
         if keep:
             save.update(iln=iln, st2=(m2, r2), x1=x1, ln2=ln2, st3=(m3, r3), x12=x12, hid=hid, fln=fln, st4=(m4, r4))
         return x2
@@ -480,7 +526,7 @@ class EvaEngine:
         att = ops.empty((B, C), BF16)
         ops.attn_cls_fwd(q, kv, cos, sin, att, B, N, H, cfg.head_width ** -0.5)
         xc = x.view(B, N, C)[:, 0, :].contiguous()
-        return self._block_post(b, xc, att, B, lambda: (None, None), None, True)
+        return self._block_post(i, b, xc, att, B, lambda: (None, None), None, True)
 
     # ------------------------------------------------------------------------------------------ teacher
     def encode_image(self, images, chunk: int = 256):
@@ -658,3 +704,5 @@ class EvaEngine:
         self.ops.adamw_step(self.master, self.grad, self.exp_avg, self.exp_avg_sq, self.shadow, self.flags,
                             lr, beta1, beta2, eps, wd, step, grad_scale)
         self.sync_transposed()
+        if self.fp8_forward:
+            self.sync_fp8(range(self.first_trainable, self.cfg.layers))

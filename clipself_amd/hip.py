@@ -27,6 +27,8 @@ SIGNATURES = {
     "cs_gemm_nt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_crop_resize_workspace": (_sz, [_i, _i, _i]),
     "cs_crop_resize_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "cs_quant_rows_fp8": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _vp]),
+    "cs_gemm_nt_f8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_gemm_wgrad_workspace": (_sz, [_i, _i, _i]),
     "cs_gemm_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_gemm_nt_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -170,6 +172,24 @@ class HipOps:
         self._ok(self.lib.cs_gemm_nt_ln(_p(A), _p(B), _p(C), _p(bias), _p(extra), _p(ln_mean), _p(ln_rstd), _p(ln_colsum), _p(stats_part),
                                         _p(xb_out), xb_out.stride(0) if xb_out is not None else 0, M, N, K, A.stride(0), B.stride(0),
                                         C.stride(0), epi, 1, group, flags | self.gemm_flags, self._stream()), "cs_gemm_nt_ln")
+
+    def quant_rows_fp8(self, x, q, scale):
+        """bf16 [M,K] -> e4m3 bytes q [M,Kp] (uint8 / float8 storage, Kp = K rounded up to 128, padding zeroed) + fp32 row scales [M]."""
+        self._chk(x, q, scale)
+        M, K = x.shape
+        assert x.dtype == torch.bfloat16 and x.stride(1) == 1 and q.element_size() == 1 and q.stride(1) == 1 and q.shape[1] == (K + 127) // 128 * 128
+        self._ok(self.lib.cs_quant_rows_fp8(_p(x), x.stride(0), _p(q), q.stride(0), _p(scale), M, K, self._stream()), "cs_quant_rows_fp8")
+
+    def gemm_nt_f8(self, A8, B8, C, row_scale, col_scale, bias=None, extra=None, epi=EPI_BF16, flags=0):
+        """C = row_scale[m] * col_scale[n] * (A8 . B8^T) + bias (+ extra): e4m3 operands [M,Kp] / [N,Kp] from quant_rows_fp8."""
+        self._chk(A8, B8, C, row_scale, col_scale, bias, extra)
+        M, K8 = A8.shape
+        N = B8.shape[0]
+        assert B8.shape[1] == K8 and A8.element_size() == 1 and B8.element_size() == 1 and C.stride(-1) == 1
+        if extra is not None:
+            assert extra.stride(0) == C.stride(0), "extra must share C's row stride"
+        self._ok(self.lib.cs_gemm_nt_f8(_p(A8), _p(B8), _p(C), _p(bias), _p(extra), _p(row_scale), _p(col_scale), M, N, K8, A8.stride(0), B8.stride(0),
+                                        C.stride(0), epi, flags | self.gemm_flags, self._stream()), "cs_gemm_nt_f8")
 
     def crop_resize(self, image_u8, boxes, size, pad_center=True, mean=(0.48145466, 0.4578275, 0.40821073),
                     std=(0.26862954, 0.26130258, 0.27577711), out=None):

@@ -78,14 +78,19 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
                  ops=None, trainable: bool = True):
     """Returns a CustomCLIP whose vision tower runs on the HIP engine.
 
-    `precision` is accepted for CLI compatibility; the hot path always computes with bf16 MFMA operands,
-    fp32 accumulation/statistics and fp32 master weights.  `device` must be a ROCm device.
+    `precision`: every reference value (amp, amp_bf16, bf16, fp16, fp32) maps to the one numerics of the HIP engine -- bf16 MFMA
+    operands, fp32 accumulation / statistics / master weights; "amp_fp8" (or "fp8") additionally runs the forward
+    linears of the training schedule on e4m3 operands (BASELINE configs[4] "fp8 MFMA weights", EvaEngine.enable_fp8_forward).
+    `device` must be a ROCm device.
     """
     model_name = model_name.replace("/", "-")
     if jit:
         raise NotImplementedError("torchscript is not supported by the HIP engine")
     cfg = get_tower_cfg(model_name)
+    fp8 = precision in ("fp8", "amp_fp8")
     if cfg.arch == "openai":
+        if fp8:
+            raise NotImplementedError("precision='amp_fp8' exists for the EVA02 towers (RegionCLIP configuration) only")
         return _create_openai_vit(cfg, model_name, pretrained, force_quick_gelu, cache_dir, require_pretrained, ops, trainable)
     if pretrained not in ("eva", None, ""):
         raise NotImplementedError(f"pretrained={pretrained!r}: the EVA towers load with pretrained='eva' (checkpoint path in cache_dir)")
@@ -100,6 +105,8 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
         from ..init import seeded_visual_state
         logging.info(f"No checkpoint at {cache_dir!r}: {model_name} starts from the seeded random initialisation")
         model.visual.engine.load_state(seeded_visual_state(cfg, seed=0))
+    if fp8:
+        model.visual.engine.enable_fp8_forward()
     return model
 
 

@@ -38,6 +38,14 @@ const char* cs_last_error(void);
 int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
                int lda, int ldb, int ldc, int epi, int splits, int group, int flags, cs_stream_t stream);
 
+/* fp8 operands (BASELINE configs[4] "fp8 MFMA weights"; reference call sites: the F.linear calls of eva_vit_model.py:99-103,177-179,218-219 under
+ * src/training/region_clip.py:28-67).  cs_quant_rows_fp8: bf16 [M,K] -> OCP e4m3 [M,Kp] (Kp = K rounded up to 128, padding zero; ldq bytes per
+ * row) with one fp32 scale per row (amax/448).  cs_gemm_nt_f8: C = row_scale[m] * col_scale[n] * (A8 . B8^T) + bias (+ extra), contracted
+ * with the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales), fp32 accumulate; epi 0 = bf16 out, 2 = fp32 residual. */
+int cs_quant_rows_fp8(const void* x_bf16, long ldx, void* q_e4m3, long ldq, float* scale, int M, int K, cs_stream_t stream);
+int cs_gemm_nt_f8(const void* A8, const void* B8, void* C, const float* bias, const float* extra, const float* row_scale, const float* col_scale,
+                  int M, int N, int K8, int lda, int ldb, int ldc, int epi, int flags, cs_stream_t stream);
+
 /* Weight gradient of a Linear (autograd of F.linear at the call sites above): dW[M,N] (f32, row stride ldc) += A[M,K] . B[N,K]^T with
  * A = dY^T, B = X^T (bf16, contraction = tokens, zero padded to K % 64 == 0).  The K range is split into slices whose partial
  * products go through `workspace` (>= cs_gemm_wgrad_workspace bytes, 16-byte aligned) and one pass adds them into dW. */

@@ -81,6 +81,33 @@ class RefOps:
         else:
             raise ValueError(epi)
 
+    def quant_rows_fp8(self, x, q, scale):
+        """cs_quant_rows_fp8: per-row amax/448 scaling, round-to-nearest-even to OCP e4m3 (torch.float8_e4m3fn), K padded to 128 with zeros.
+        q is a uint8 / float8 byte buffer [M, Kp]."""
+        M, K = x.shape
+        xf = x.float()
+        amax = xf.abs().amax(dim=1)
+        inv = torch.where(amax > 0, 448.0 / amax, torch.zeros_like(amax))
+        scale.copy_(torch.where(amax > 0, amax / 448.0, torch.ones_like(amax)))
+        q8 = (xf * inv[:, None]).to(torch.float8_e4m3fn)
+        out = q.view(torch.uint8)
+        out.zero_()
+        out[:, :K] = q8.view(torch.uint8)
+
+    def gemm_nt_f8(self, A8, B8, C, row_scale, col_scale, bias=None, extra=None, epi=EPI_BF16, flags=0):
+        """cs_gemm_nt_f8: exact products of the e4m3 values, fp32 accumulation, scales and bias in the epilogue."""
+        a = A8.view(torch.float8_e4m3fn).float()
+        b = B8.view(torch.float8_e4m3fn).float()
+        acc = (a @ b.T) * row_scale[:, None] * col_scale[None, :]
+        if bias is not None:
+            acc = acc + bias
+        if epi == EPI_BF16:
+            C.copy_(acc.to(torch.bfloat16))
+        elif epi == EPI_RESID_F32:
+            C.copy_(extra + acc)
+        else:
+            raise ValueError(epi)
+
     def gemm_nt_ln(self, A, B, C, bias=None, extra=None, ln_mean=None, ln_rstd=None, ln_colsum=None, stats_part=None, xb_out=None,
                    epi=EPI_RESID_LN_F32, group=0, flags=0):
         acc = A.float() @ B.float().T

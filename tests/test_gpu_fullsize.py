@@ -200,3 +200,78 @@ def test_recipe_shape_1024px_student_4097_tokens():
     g = student.visual.engine.grad
     _log(f"N1 recipe shape: step of 2 images x 1024^2 + 40 teacher crops: {ms:.1f} ms/step ({2e3 / ms:.1f} images/s), loss {float(out['loss']):.5f}")
     assert torch.isfinite(out["loss"]).item() and torch.isfinite(g).all().item() and float(g.abs().sum()) > 0
+
+
+def test_cfg4_l14_336_regionclip_fp8_forward(monkeypatch):
+    """BASELINE configs[4] with "fp8 MFMA weights": the same L/14-336 RegionCLIP step with precision 'amp_fp8' (forward linears on e4m3
+    operands through the block-scaled fp8 MFMA, EvaEngine.enable_fp8_forward).  (a) the HIP fp8 schedule equals the CPU statement of the
+    same schedule (oracle/ops_ref.py, torch.float8_e4m3fn) on a tiny tower; (b) at the real configuration the fp8 loss stays within
+    3e-2 of the bf16 loss and of the fp32 oracle, gradients are finite, and both step times are logged."""
+    import time
+    from oracle import eva_ref
+    from oracle.ops_ref import RefOps
+    from clipself_amd.config import tiny_cfg
+    from clipself_amd.open_clip.model import CustomCLIP
+    from clipself_amd.training import region_clip as rc
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.train import train_step
+    from test_regionclip_cpu import regionclip_inputs
+    # (a) kernel path == reference path of the same fp8 schedule
+    tcfg = tiny_cfg()
+    images, bx, nouns = regionclip_inputs(tcfg)
+    rois = [b[b[:, -1] > 0.5][:, :4] for b in bx]
+    feats = {}
+    for tag, ops, dev in (("ref", RefOps(), "cpu"), ("hip", None, "cuda")):
+        m = CustomCLIP(tcfg, ops=ops, trainable=True)
+        m.visual.engine.load_state(seeded_visual_state(tcfg, 2))
+        m.visual.engine.enable_fp8_forward()
+        with torch.no_grad():
+            feats[tag] = m.encode_pseudo_boxes(images.to(dev), [r.to(dev) for r in rois], normalize=True)
+    r = rel(feats["hip"], feats["ref"])
+    _log(f"fp8 forward schedule, tiny tower: HIP kernels vs CPU reference ops: rel-L2 {r:.3e}")
+    assert r < 2e-2
+    # (b) the real configuration
+    cfg = get_tower_cfg("EVA02-CLIP-L-14-336")
+    sd0 = seeded_visual_state(cfg, 3)
+    images, bx, nouns = _regionclip_batch(cfg, 2)
+    labels = torch.cat([b[b[:, -1] > 0.5][:, 4].long() for b in bx])
+    appeared = torch.unique(labels)
+    appeared = torch.cat([appeared, torch.from_numpy(np.setdiff1d(np.arange(4764), appeared.numpy())[: 100 - len(appeared)])])
+    monkeypatch.setattr(rc, "get_fed_loss_inds", lambda gt, n, C: appeared.to(gt.device))
+    a = SimpleNamespace(extract_type="v2", contrast_weight=1.0)
+    with torch.no_grad():
+        want = float(eva_ref.regionclip_loss(dict(sd0), cfg, images, bx, nouns, appeared=appeared))
+    losses, models = {}, {}
+    for tag in ("bf16", "fp8"):
+        m = CustomCLIP(cfg, trainable=True)
+        m.visual.engine.load_state(sd0)
+        m.lock_image_tower(unlocked_groups=cfg.layers)
+        m.train()
+        if tag == "fp8":
+            m.visual.engine.enable_fp8_forward()
+        out, _, _ = rc.RegionCLIP(SimpleNamespace(), noun_embeddings=nouns)((images, bx), m, None, None, "cuda", None, False, a)
+        total = sum(out.values())
+        total.backward()
+        assert torch.isfinite(m.visual.engine.grad).all().item()
+        losses[tag], models[tag] = float(total.detach()), m
+    _log(f"cfg4 L/14-336 RegionCLIP fp8 forward (2 images): loss fp8 {losses['fp8']:.4f} bf16 {losses['bf16']:.4f} oracle {want:.4f}; "
+         f"grad rel fp8-vs-bf16 {rel(models['fp8'].visual.engine.grad, models['bf16'].visual.engine.grad):.3e}")
+    assert abs(losses["fp8"] - losses["bf16"]) / losses["bf16"] < 3e-2 and abs(losses["fp8"] - want) / want < 3e-2
+    monkeypatch.undo()
+    # step time at the full per-GPU batch (32 images x <= 20 boxes), bf16 vs fp8 forward
+    images, bx, nouns = _regionclip_batch(cfg, 32, seed=78)
+    batch = (images.cuda(), bx.cuda())
+    for tag in ("bf16", "fp8"):
+        m = models[tag]
+        method = rc.RegionCLIP(SimpleNamespace(), noun_embeddings=nouns)
+        opt = FlatAdamW(m, lr=1e-5, weight_decay=0.1)
+        args = _args(skip_scheduler=True, contrast_weight=1.0)
+        train_step(m, method, batch, opt, None, 0, None, args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for step in range(3):
+            out, _, _ = train_step(m, method, batch, opt, None, step + 1, None, args)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        _log(f"cfg4 L/14-336 RegionCLIP step, 32 images x <=20 boxes, {tag} forward: {ms:.1f} ms/step ({32e3 / ms:.1f} images/s), loss {float(out['loss']):.3f}")
+        assert torch.isfinite(out["loss"]).item()

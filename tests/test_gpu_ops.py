@@ -689,3 +689,38 @@ def test_factory_transforms_run_the_crop_kernel_and_equal_pillow(hip):
         assert det.is_cuda and tuple(det.shape) == (3, size, size)
         assert np.array_equal(det.cpu().numpy(), pil_crops(arr, whole, size, pad_center=False)[0]), (H, W, size, "det")
         assert np.array_equal(crop.cpu().numpy(), pil_crops(arr, whole, size, pad_center=True)[0]), (H, W, size, "crop")
+
+
+@pytest.mark.parametrize("M,N,K", [(394, 768, 768), (130, 3072, 1024), (1000, 1024, 2752), (70000, 2304, 768), (64, 512, 128)])
+@pytest.mark.parametrize("epi", [0, 2])
+def test_fp8_quantisation_and_gemm(hip, ref, M, N, K, epi):
+    """BASELINE configs[4] "fp8 MFMA weights": cs_quant_rows_fp8 (row-wise e4m3, amax/448 scales, K padded to 128) is bit-identical to the
+    torch.float8_e4m3fn statement, and cs_gemm_nt_f8 (block-scaled fp8 MFMA at unit block scales, fp32 accumulate, row x column scales +
+    bias [+ residual] in the epilogue) equals the exact product of the quantised operands."""
+    x, w = rnd((M, K), BF, seed=90), rnd((N, K), BF, 0.05, seed=91)
+    bias, res = rnd((N,), F32, seed=92), rnd((M, N), F32, seed=93)
+    Kp = (K + 127) // 128 * 128
+    q = {}
+    for tag, ops, dev in (("ref", ref, "cpu"), ("hip", hip, "cuda")):
+        xq, wq = torch.full((M, Kp), 0x55, dtype=torch.uint8, device=dev), torch.full((N, Kp), 0x55, dtype=torch.uint8, device=dev)
+        sx, sw = torch.empty(M, device=dev), torch.empty(N, device=dev)
+        ops.quant_rows_fp8(x.to(dev), xq, sx)
+        ops.quant_rows_fp8(w.to(dev), wq, sw)
+        q[tag] = (xq, wq, sx, sw)
+    for a, b in zip(q["ref"], q["hip"]):
+        assert torch.equal(a, b.cpu()), "quantised bytes / scales differ from the e4m3 reference"
+    xq, wq, sx, sw = q["hip"]
+    if epi == 0:
+        Cd, Cr = torch.full((M, N), float("nan"), dtype=BF, device="cuda"), torch.empty(M, N, dtype=BF)
+        hip.gemm_nt_f8(xq, wq, Cd, sx, sw, bias=bias.cuda(), epi=0)
+        ref.gemm_nt_f8(*q["ref"][:2], Cr, *q["ref"][2:], bias=bias, epi=0)
+        check(f"gemm_f8_bf16[{M},{N},{K}]", Cd, Cr, TOL_BF)
+    else:
+        Cd, Cr = res.cuda().clone(), torch.empty(M, N)
+        hip.gemm_nt_f8(xq, wq, Cd, sx, sw, bias=bias.cuda(), extra=Cd, epi=2)
+        ref.gemm_nt_f8(*q["ref"][:2], Cr, *q["ref"][2:], bias=bias, extra=res, epi=2)
+        check(f"gemm_f8_resid[{M},{N},{K}]", Cd, Cr, 2e-5)
+    # and the quantised product is a faithful GEMM: within fp8 rounding of the bf16 product
+    exact = x.float() @ w.float().T + bias + (res if epi == 2 else 0)
+    got = Cd.float().cpu()
+    assert float((got - exact).norm() / exact.norm()) < 6e-2
