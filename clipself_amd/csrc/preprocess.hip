@@ -152,3 +152,34 @@ extern "C" int cs_crop_resize_u8(const void* src, int H, int W, const float* box
     CS_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ --multiscale
+// Bilinear resize of fp32 planes, the arithmetic of torch's F.interpolate(mode='bilinear', align_corners=False) that the reference applies
+// to the student images under --multiscale (src/training/clipself.py:17-27): src = scale * (dst + 0.5) - 0.5 clamped at 0, scale = in / out.
+namespace {
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int H, int W,
+                                                              int Ho, int Wo, float sh, float sw) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= Wo || y >= Ho) return;
+    const float fy = fmaxf(sh * ((float)y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sw * ((float)x + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int yp = y0 < H - 1 ? 1 : 0, xp = x0 < W - 1 ? 1 : 0;
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+    for (int p = blockIdx.z; p < planes; p += gridDim.z) {
+        const float* s = in + (size_t)p * H * W + (size_t)y0 * W + x0;
+        const float top = lx0 * s[0] + lx1 * s[xp], bot = lx0 * s[(size_t)yp * W] + lx1 * s[(size_t)yp * W + xp];
+        out[(size_t)p * Ho * Wo + (size_t)y * Wo + x] = ly0 * top + ly1 * bot;
+    }
+}
+
+}  // namespace
+
+// in [planes, H, W] f32 -> out [planes, Ho, Wo] f32 (planes = batch * channels), both contiguous
+extern "C" int cs_resize_bilinear_f32(const float* in, float* out, int planes, int H, int W, int Ho, int Wo, hipStream_t stream) {
+    CS_CHECK_ARG(in && out && planes > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "cs_resize_bilinear_f32: bad arguments");
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((Wo + 63) / 64, (Ho + 3) / 4, planes < 1024 ? planes : 1024), dim3(256), 0, stream, in, out,
+                       planes, H, W, Ho, Wo, (float)H / (float)Ho, (float)W / (float)Wo);
+    CS_LAUNCH_CHECK();
+    return 0;
+}

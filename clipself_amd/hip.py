@@ -29,6 +29,7 @@ SIGNATURES = {
     "cs_crop_resize_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "cs_quant_rows_fp8": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _vp]),
     "cs_gemm_nt_f8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cs_resize_bilinear_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cs_gemm_wgrad_workspace": (_sz, [_i, _i, _i]),
     "cs_gemm_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_gemm_nt_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -208,6 +209,16 @@ class HipOps:
         m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
         self._ok(self.lib.cs_crop_resize_u8(_p(image_u8), H, W, _p(boxes), K, size, int(bool(pad_center)), m3, s3, _p(out), _p(ws),
                                             self._stream()), "cs_crop_resize_u8")
+        return out
+
+    def resize_bilinear(self, x, size):
+        """x fp32 [B,C,H,W] -> [B,C,size,size], torch's bilinear / align_corners=False arithmetic (the --multiscale resize)."""
+        self._chk(x)
+        assert x.dtype == torch.float32 and x.dim() == 4
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty((B, C, size, size), dtype=torch.float32, device=x.device)
+        self._ok(self.lib.cs_resize_bilinear_f32(_p(x), _p(out), B * C, H, W, size, size, self._stream()), "cs_resize_bilinear_f32")
         return out
 
     def gemm_wgrad_workspace(self, M, N, K) -> int:

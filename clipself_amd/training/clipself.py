@@ -123,7 +123,7 @@ class CLIPSelf:
             if choices is None:
                 raise NotImplementedError
             tar = random.choice(choices)
-            images = F.interpolate(images, size=(tar, tar), mode="bilinear")
+            images = model.visual.engine.ops.resize_bilinear(images.float(), tar)      # F.interpolate(..., mode="bilinear") as one kernel
 
         valid, dense, crops = self._valid_crops(normed_boxes, image_crops, _known_all_valid(batch[1]))
         if dense:

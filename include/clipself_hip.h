@@ -157,6 +157,10 @@ size_t cs_crop_resize_workspace(int H, int K, int S);
 int cs_crop_resize_u8(const void* src, int H, int W, const float* boxes, int K, int S, int pad_center, const float* mean3,
                       const float* std3, float* out, void* workspace, cs_stream_t stream);
 
+/* --multiscale (src/training/clipself.py:17-27): F.interpolate(images, size=(t, t), mode='bilinear') of the student batch.
+ * in [planes,H,W] f32 -> out [planes,Ho,Wo] f32, align_corners=False arithmetic of torch. */
+int cs_resize_bilinear_f32(const float* in, float* out, int planes, int H, int W, int Ho, int Wo, cs_stream_t stream);
+
 /* --- optimizer: torch.optim.AdamW built at src/training/main.py:198-213, stepped at src/training/train.py:115.
  * Flat fp32 master/grad/moment buffers; flags[n/64]: bit0 = tensor has a gradient this step, bit1 = weight decay applies. */
 int cs_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, const uint8_t* flags, long n, float lr,

@@ -151,6 +151,9 @@ class RefOps:
             return out
         return res
 
+    def resize_bilinear(self, x, size):
+        return F.interpolate(x.float(), size=(size, size), mode="bilinear")
+
     def gemm_wgrad_workspace(self, M, N, K):
         return 16
 

@@ -40,7 +40,7 @@ def test_every_entry_point_has_a_tensor_level_wrapper_and_a_reference_op():
     otherwise only surface on the GPU box."""
     from clipself_amd import hip
     from oracle.ops_ref import RefOps
-    renamed = {"cs_crop_resize_u8": "crop_resize"}
+    renamed = {"cs_crop_resize_u8": "crop_resize", "cs_resize_bilinear_f32": "resize_bilinear"}
     for sym in hip.SIGNATURES:
         if sym == "cs_last_error" or sym == "cs_crop_resize_workspace":
             continue

@@ -275,3 +275,26 @@ def test_cfg4_l14_336_regionclip_fp8_forward(monkeypatch):
         ms = (time.perf_counter() - t0) / 3 * 1e3
         _log(f"cfg4 L/14-336 RegionCLIP step, 32 images x <=20 boxes, {tag} forward: {ms:.1f} ms/step ({32e3 / ms:.1f} images/s), loss {float(out['loss']):.3f}")
         assert torch.isfinite(out["loss"]).item()
+
+
+def test_multiscale_step_matches_the_oracle_at_the_drawn_size(monkeypatch):
+    """--multiscale (src/training/clipself.py:17-27): an 896^2 student batch is resized to one of [336, 448, 672, 896] per step
+    (cs_resize_bilinear_f32 = F.interpolate bilinear) before the dense forward.  With the draw pinned to 672 (42 x 42 + 1 = 1765 tokens) the
+    step's loss must equal the oracle's loss on the identically resized images."""
+    import random
+    import torch.nn.functional as F
+    from oracle import eva_ref
+    from clipself_amd.training.clipself import CLIPSelf
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    student, teacher = _pair(cfg, 0)
+    batch = synthetic_batch(1, 5, 896, 224, seed=31)
+    monkeypatch.setattr(random, "choice", lambda seq: 672)
+    out, bs, _ = CLIPSelf()(tuple(t.cuda() for t in batch), student, teacher, None, "cuda", None, False, _args(multiscale=True))
+    images, boxes, crops = batch
+    sd = seeded_visual_state(cfg, 0)
+    with torch.no_grad():
+        small = F.interpolate(images, size=(672, 672), mode="bilinear")
+        want = float(eva_ref.clipself_loss(dict(sd), dict(sd), cfg, (small, boxes, crops))[0])
+    got = float(out["loss_cosine"].detach())
+    _log(f"N1 --multiscale: 896^2 -> 672^2 (1765 tokens) step loss {got:.6f} vs oracle {want:.6f} (rel {abs(got - want) / want:.2e})")
+    assert abs(got - want) / want < 1e-3

@@ -737,3 +737,12 @@ def test_fp8_quantisation_and_gemm(hip, ref, M, N, K, epi):
     exact = x.float() @ w.float().T + bias + (res if epi == 2 else 0)
     got = Cd.float().cpu()
     assert float((got - exact).norm() / exact.norm()) < 6e-2
+
+
+@pytest.mark.parametrize("shape,size", [((2, 3, 1024, 1024), 640), ((3, 3, 896, 896), 336), ((1, 3, 64, 64), 96), ((2, 3, 224, 224), 224)])
+def test_multiscale_bilinear_resize_matches_torch(hip, ref, shape, size):
+    """--multiscale (src/training/clipself.py:17-27): F.interpolate(images, size, mode='bilinear') as cs_resize_bilinear_f32."""
+    x = rnd(shape, F32, seed=123)
+    got = hip.resize_bilinear(x.cuda(), size)
+    want = ref.resize_bilinear(x, size)
+    check(f"resize_bilinear{list(shape)}->{size}", got, want, 1e-6)
