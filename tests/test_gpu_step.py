@@ -69,10 +69,11 @@ def test_tiny_step_matches_reference_goldens(golden_dir):
         r64 = student.encode_pseudo_boxes(im64.cuda(), [b[:, :4].cuda() for b in bx64])
     _log(f"tiny teacher rel={rel(t, g['teacher']):.3e} 1-cos={one_minus_cos(t, g['teacher']):.2e}; roi rel={rel(s, g['student_roi']):.3e} "
          f"1-cos={one_minus_cos(s, g['student_roi']):.2e}; dense rel={rel(d, g['dense']):.3e}; roi64 rel={rel(r64, g['roi64']):.3e}")
-    assert rel(t, g["teacher"]) < 2e-2 and one_minus_cos(t, g["teacher"]) < 1e-3
-    assert rel(s, g["student_roi"]) < 2e-2 and one_minus_cos(s, g["student_roi"]) < 1e-3
-    assert rel(d, g["dense"]) < 2e-2
-    assert rel(r64, g["roi64"]) < 2e-2                      # rescaled pos-embed + regenerated RoPE tables (8x8 grid)
+    # bounds = 2x the errors measured on MI355X (profiles/r02_parity.md)
+    assert rel(t, g["teacher"]) < 1.6e-2 and one_minus_cos(t, g["teacher"]) < 1e-4
+    assert rel(s, g["student_roi"]) < 1.1e-2 and one_minus_cos(s, g["student_roi"]) < 6e-5
+    assert rel(d, g["dense"]) < 1.1e-2
+    assert rel(r64, g["roi64"]) < 1.1e-2                      # rescaled pos-embed + regenerated RoPE tables (8x8 grid)
     opt = FlatAdamW(student, lr=rec["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=rec["wd"])
     sched = cosine_lr(opt, rec["lr"], rec["warmup"], rec["total"])
     losses = []
@@ -91,10 +92,10 @@ def test_tiny_step_matches_reference_goldens(golden_dir):
                     continue
                 r = rel(p.grad, g["grad/" + n])
                 worst = max(worst, r)
-                assert r < 6e-2, f"{n}: {r:.3e}"
+                assert r < 3e-2, f"{n}: {r:.3e}"            # measured worst 1.4e-2 (EVA02) / 6.6e-3 (OpenAI ViT)
             _log(f"tiny worst grad rel={worst:.3e}")
     _log(f"tiny losses {losses} vs {g['losses'].tolist()}")
-    assert np.allclose(losses, g["losses"], atol=1e-2)
+    assert np.allclose(losses, g["losses"], atol=1e-3)               # measured 4e-4
     w = dict(student.named_parameters())["visual.blocks.0.mlp.w1.weight"]
     assert rel(w, g["final/visual.blocks.0.mlp.w1.weight"]) < 2e-2
 
@@ -123,9 +124,9 @@ def test_b16_cfg1_matches_reference_goldens(golden_dir):
             _log(f"b16 teacher_slice rel={rel(t[:4, :16], g['teacher_slice']):.3e} roi_slice rel={rel(s[:4, :16], g['student_roi_slice']):.3e} "
                  f"rownorm rel t={rel(t.norm(dim=-1), g['teacher_rownorm']):.3e} s={rel(s.norm(dim=-1), g['student_rownorm']):.3e} "
                  f"cos maxabs={float((cos - torch.from_numpy(g['cos'])).abs().max()):.3e}")
-            assert rel(t[:4, :16], g["teacher_slice"]) < 3e-2 and rel(s[:4, :16], g["student_roi_slice"]) < 3e-2
-            assert rel(t.norm(dim=-1), g["teacher_rownorm"]) < 1e-2 and rel(s.norm(dim=-1), g["student_rownorm"]) < 1e-2
-            assert float((cos - torch.from_numpy(g["cos"])).abs().max()) < 5e-3
+            assert rel(t[:4, :16], g["teacher_slice"]) < 2.8e-2 and rel(s[:4, :16], g["student_roi_slice"]) < 1.3e-2     # measured 1.4e-2 / 6.3e-3
+            assert rel(t.norm(dim=-1), g["teacher_rownorm"]) < 1e-3 and rel(s.norm(dim=-1), g["student_rownorm"]) < 4e-4     # 4.7e-4 / 1.8e-4
+            assert float((cos - torch.from_numpy(g["cos"])).abs().max()) < 3.4e-3                                       # 1.7e-3
         out, bs, _ = train_step(student, CLIPSelf(), batch, opt, sched, step, teacher, _args())
         losses.append(float(out["loss"]))
         if step == 0:
@@ -141,11 +142,11 @@ def test_b16_cfg1_matches_reference_goldens(golden_dir):
                 r = abs(float(p.grad.double().norm()) - norms[n]) / norms[n]
                 if r > worst[1]:
                     worst = (n, r)
-                assert r < 5e-2, f"{n}: grad-norm rel {r:.3e}"
+                assert r < 3.2e-3, f"{n}: grad-norm rel {r:.3e}"        # measured worst 1.6e-3
             for n in ("visual.blocks.11.mlp.w3.bias", "visual.blocks.0.norm1.weight", "visual.blocks.5.attn.q_bias", "visual.blocks.11.attn.v_bias"):
                 r = rel(dict(student.named_parameters())[n].grad, g["grad/" + n])
                 _log(f"b16 grad {n} rel={r:.3e}")
-                assert r < 6e-2, n
+                assert r < 3e-2, n                                  # measured worst 1.41e-2
             _log(f"b16 worst grad-norm rel {worst}")
     _log(f"b16 losses {losses} vs {g['losses'].tolist()}")
     assert abs(losses[0] - g["losses"][0]) / g["losses"][0] < 1e-3          # north-star tolerance on the loss
@@ -195,7 +196,7 @@ def test_non_native_grid_multichunk_attention_matches_oracle():
         want = eva_ref.encode_pseudo_boxes(sd, cfg, images, rois)
     got = student.encode_pseudo_boxes(images.cuda(), [r.cuda() for r in rois])
     _log(f"b16@448 roi rel={rel(got, want):.3e} 1-cos={one_minus_cos(got, want):.2e}")
-    assert rel(got, want) < 2e-2 and one_minus_cos(got, want) < 1e-3
+    assert rel(got, want) < 1e-2 and one_minus_cos(got, want) < 3e-5                  # measured 4.6e-3 / 1.2e-5
     # gradient of sum(roi feats * w) w.r.t. one early and one late parameter
     w = torch.randn(want.shape, generator=torch.Generator().manual_seed(0))
     (got * w.cuda()).sum().backward()
@@ -204,7 +205,7 @@ def test_non_native_grid_multichunk_attention_matches_oracle():
     for n in ("visual.blocks.0.attn.q_bias", "visual.blocks.10.mlp.w3.bias"):
         r = rel(dict(student.named_parameters())[n].grad, ref[n].grad)
         _log(f"b16@448 grad {n} rel={r:.3e}")
-        assert r < 6e-2, (n, r)
+        assert r < 1.5e-2, (n, r)                         # measured 7.5e-3 / 1.9e-3
 
 
 def test_l14_shaped_tower_with_padded_storage_on_gpu(golden_dir):
@@ -233,8 +234,8 @@ def test_eva02_l14_336_real_config():
         got_t = teacher.encode_image(crops[0].cuda())
         got_s = student.encode_pseudo_boxes(images.cuda(), [boxes[0][:, :4].cuda()])
     _log(f"l14 teacher rel={rel(got_t, want_t):.3e} 1-cos={one_minus_cos(got_t, want_t):.2e}; roi rel={rel(got_s, want_s):.3e} 1-cos={one_minus_cos(got_s, want_s):.2e}")
-    assert rel(got_t, want_t) < 3e-2 and one_minus_cos(got_t, want_t) < 1e-3
-    assert rel(got_s, want_s) < 3e-2 and one_minus_cos(got_s, want_s) < 1e-3
+    assert rel(got_t, want_t) < 1.9e-2 and one_minus_cos(got_t, want_t) < 1e-4         # measured 9.4e-3 / 4.7e-5
+    assert rel(got_s, want_s) < 1.3e-2 and one_minus_cos(got_s, want_s) < 4e-5         # measured 6.2e-3 / 1.9e-5
     opt = FlatAdamW(student, lr=1e-5, weight_decay=0.1)
     out, bs, _ = train_step(student, CLIPSelf(), batch, opt, None, 0, teacher, _args(skip_scheduler=True))
     assert torch.isfinite(out["loss"]).item()
@@ -479,9 +480,9 @@ def test_tiny_openai_vit_step_matches_reference_goldens(golden_dir, quick):
         d = student.encode_dense(images.cuda(), keep_shape=False)
     _log(f"tiny-openai quick={quick} teacher rel={rel(t, g[tag + 'teacher']):.3e} 1-cos={one_minus_cos(t, g[tag + 'teacher']):.2e}; "
          f"roi rel={rel(s, g[tag + 'student_roi']):.3e} 1-cos={one_minus_cos(s, g[tag + 'student_roi']):.2e}; dense rel={rel(d, g[tag + 'dense']):.3e}")
-    assert rel(t, g[tag + "teacher"]) < 2e-2 and one_minus_cos(t, g[tag + "teacher"]) < 1e-3
-    assert rel(s, g[tag + "student_roi"]) < 2e-2 and one_minus_cos(s, g[tag + "student_roi"]) < 1e-3
-    assert rel(d, g[tag + "dense"]) < 2e-2
+    assert rel(t, g[tag + "teacher"]) < 5e-3 and one_minus_cos(t, g[tag + "teacher"]) < 1e-5          # measured 2.3e-3 / 3e-6
+    assert rel(s, g[tag + "student_roi"]) < 7e-3 and one_minus_cos(s, g[tag + "student_roi"]) < 2e-5  # measured 3.4e-3 / 7e-6
+    assert rel(d, g[tag + "dense"]) < 7e-3
     if not quick:
         im64, bx64, _ = synthetic_batch(2, 3, 64, cfg.image_size, seed=78)
         with torch.no_grad():
@@ -501,11 +502,11 @@ def test_tiny_openai_vit_step_matches_reference_goldens(golden_dir, quick):
                     continue
                 r = rel(p.grad, g[tag + "grad/" + n])
                 worst, checked = max(worst, r), checked + 1
-                assert r < 6e-2, f"{n}: {r:.3e}"
+                assert r < 3e-2, f"{n}: {r:.3e}"            # measured worst 1.4e-2 (EVA02) / 6.6e-3 (OpenAI ViT)
             assert checked == (2 if quick else 12) * cfg.layers
             _log(f"tiny-openai quick={quick} worst grad rel={worst:.3e}")
     _log(f"tiny-openai quick={quick} losses {losses} vs {g[tag + 'losses'].tolist()}")
-    assert np.allclose(losses, g[tag + "losses"], atol=1e-2)
+    assert np.allclose(losses, g[tag + "losses"], atol=1e-3)         # measured 3e-4
     if not quick:
         last = f"visual.transformer.resblocks.{cfg.layers - 1}.attn.in_proj_weight"
         w = dict(student.named_parameters())
@@ -543,9 +544,9 @@ def test_vitb16_openai_cfg1_matches_reference_goldens(golden_dir):
             cos = torch.nn.functional.cosine_similarity(t, s, dim=-1).cpu()
             _log(f"vitb16 teacher_slice rel={rel(t[:4, :16], g['teacher_slice']):.3e} roi_slice rel={rel(s[:4, :16], g['student_roi_slice']):.3e} "
                  f"cos maxabs={float((cos - torch.from_numpy(g['cos'])).abs().max()):.3e}")
-            assert rel(t[:4, :16], g["teacher_slice"]) < 3e-2 and rel(s[:4, :16], g["student_roi_slice"]) < 3e-2
-            assert rel(t.norm(dim=-1), g["teacher_rownorm"]) < 1e-2 and rel(s.norm(dim=-1), g["student_rownorm"]) < 1e-2
-            assert float((cos - torch.from_numpy(g["cos"])).abs().max()) < 5e-3
+            assert rel(t[:4, :16], g["teacher_slice"]) < 2.8e-2 and rel(s[:4, :16], g["student_roi_slice"]) < 1.3e-2     # measured 1.4e-2 / 6.3e-3
+            assert rel(t.norm(dim=-1), g["teacher_rownorm"]) < 1e-3 and rel(s.norm(dim=-1), g["student_rownorm"]) < 4e-4     # 4.7e-4 / 1.8e-4
+            assert float((cos - torch.from_numpy(g["cos"])).abs().max()) < 3.4e-3                                       # 1.7e-3
         out, bs, _ = train_step(student, CLIPSelf(), batch, opt, sched, step, teacher, _args())
         losses.append(float(out["loss"]))
         if step == 0:
@@ -556,12 +557,12 @@ def test_vitb16_openai_cfg1_matches_reference_goldens(golden_dir):
                     continue
                 r = abs(float(p.grad.double().norm()) - norms[n]) / norms[n]
                 worst = max(worst, (n, r), key=lambda x: x[1])
-                assert r < 5e-2, f"{n}: grad-norm rel {r:.3e}"
+                assert r < 3.2e-3, f"{n}: grad-norm rel {r:.3e}"        # measured worst 1.6e-3
             for n in ("visual.transformer.resblocks.11.mlp.c_proj.bias", "visual.transformer.resblocks.0.ln_1.weight",
                       "visual.transformer.resblocks.5.attn.in_proj_bias", "visual.transformer.resblocks.11.attn.in_proj_bias"):
                 r = rel(dict(student.named_parameters())[n].grad, g["grad/" + n])
                 _log(f"vitb16 grad {n} rel={r:.3e}")
-                assert r < 6e-2, n
+                assert r < 3e-2, n                                  # measured worst 1.41e-2
             _log(f"vitb16 worst grad-norm rel {worst}")
     _log(f"vitb16 losses {losses} vs {g['losses'].tolist()}")
     assert abs(losses[0] - g["losses"][0]) / g["losses"][0] < 1e-3
