@@ -1345,6 +1345,101 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *d = make_float4(o.x + acc.x, o.y + acc.y, o.z + acc.z, o.w + acc.w);
 }
 
+// ------------------------------------------------------------------------------------------------ wgrad without transposes ("TN")
+// dW[N, K] = sum_m dY[m, n] * X[m, k] with BOTH operands token-major as the forward / backward kernels left them (rows = tokens,
+// contraction = the row index): the MFMA operand of lane (n, half) is 8 consecutive tokens of ONE column -- a strided access that
+// ds_read_b64_tr_b16 performs in hardware (within a 16-lane group lane i hands in the address of four contiguous bf16 = row i>>2,
+// segment i&3 of a [4 tokens][16 columns] block and receives column i of the four rows).  Tiles: 256 (n) x 256 (k) outputs, K tiles of
+// 64 tokens; LDS image of an operand tile = [64 tokens][256 columns] bf16 (512-byte rows) staged by the 16-byte LDS-DMA, the 32-byte
+// column groups of row r XOR-permuted by (r & 7) on the SOURCE side so that the four rows of a transposing read hit four different bank
+// groups.  Same split rings (A x3, B x2), counted waits and split-K-through-partials epilogue as the NT kernel; replaces the explicit
+// bf16 transposes of dY and X (2 x 4 per block and step).  Requires tokens % 64 == 0, N % 256 == 0, K % 256 == 0.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int tok, int colbyte) {
+    // rows tok .. tok+3 and tok+4 .. tok+7 of the lane's column; colbyte = logical byte offset of the lane's 8-byte segment in the row
+    const int a0 = tok * 512 + (colbyte ^ ((tok & 7) << 5)), a1 = (tok + 4) * 512 + (colbyte ^ (((tok + 4) & 7) << 5));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + a1));
+    union { short s[8]; bf16x8 v; } u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { u.s[e] = lo[e]; u.s[4 + e] = hi[e]; }
+    return u.v;
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256, WN = 4, TM = 128, TN = 64, FM = 4, FN = 2;
+    constexpr int T_BYTES = 64 * 512;                     // one operand tile: 64 tokens x 256 columns
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 15, grp = lane >> 4, hf = grp >> 1, g1 = grp & 1;
+    int tm, tn;
+    tile_of_block(p, tm, tn);
+    const int n0 = tm * BM, k0 = tn * BN;
+    char* const b_ring = smem + 3 * T_BYTES;
+    // DMA: instruction x of this wave fills LDS rows 2*(wave*4+x), +1; lane l lands at row + (l >> 5), physical 16-byte chunk l & 31
+    const int drow = lane >> 5, pc = lane & 31;
+    unsigned aoff[4], boff[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const int row = 2 * (wave * 4 + x) + drow;
+        const int lc = ((((pc >> 1) ^ (row & 7)) << 1) | (pc & 1));          // logical 16-byte chunk this LDS position holds
+        aoff[x] = (unsigned)(row * p.lda + n0 + lc * 8) * 2u;
+        boff[x] = (unsigned)(row * p.ldb + k0 + lc * 8) * 2u;
+    }
+    const int kt_begin = blockIdx.y * p.ktiles_per_split, kt_end = min(kt_begin + p.ktiles_per_split, p.K / 64);
+    auto issue = [&](const __bf16* base, int ld, const unsigned (&off)[4], int kt, char* dst) {
+        const char* src = (const char*)base + (size_t)kt * 64 * ld * 2;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off[x]),
+                                             (__attribute__((address_space(3))) void*)(dst + (wave * 4 + x) * 1024), 16, 0, 0);
+    };
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (kt_begin < kt_end) {
+        issue(p.A, p.lda, aoff, kt_begin, smem);
+        issue(p.B, p.ldb, boff, kt_begin, b_ring);
+    }
+    if (kt_begin + 1 < kt_end) issue(p.A, p.lda, aoff, kt_begin + 1, smem + T_BYTES);
+    // lane's 8-byte segment inside a 32-column block: column 16*g1 + 4*(li&3); tokens of its 16-lane group: 8*hf + (li>>2)
+    const int segbyte = (16 * g1 + 4 * (li & 3)) * 2, trow = 8 * hf + (li >> 2);
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int i0 = kt - kt_begin;
+        if (kt + 1 < kt_end) issue(p.B, p.ldb, boff, kt + 1, b_ring + ((i0 + 1) & 1) * T_BYTES);
+        if (kt + 2 < kt_end) issue(p.A, p.lda, aoff, kt + 2, smem + ((i0 + 2) % 3) * T_BYTES);
+        const char* ta = smem + cur * T_BYTES;
+        const char* tb = b_ring + (i0 & 1) * T_BYTES;
+#pragma unroll
+        for (int ts = 0; ts < 4; ++ts) {
+            bf16x8 a[FM], b[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = tr_frag(ta, 16 * ts + trow, (wm * TM + i * 32) * 2 + segbyte);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[j] = tr_frag(tb, 16 * ts + trow, (wn * TN + j * 32) * 2 + segbyte);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    __syncthreads();
+    epilogue<EPI_F32, FM, FN, BN>(p, acc, smem, wave, lane, n0 + wm * TM, k0, tn, wn);
+}
+
 // tile schedule (1 = 128x128 two per CU, 2 = 256x128, 7 = 256x256) and slice count minimising MFMA rounds + partial traffic
 void choose_wgrad(int M, int N, int K, int& cfg, int& splits) {
     const int ktiles = K / BK;
@@ -1365,6 +1460,58 @@ void choose_wgrad(int M, int N, int K, int& cfg, int& splits) {
 }
 
 }  // namespace
+
+namespace {
+int choose_tn_splits(int N, int K, int tokens) {
+    const long tiles = (long)(N / 256) * (K / 256);
+    const int ktiles = tokens / 64;
+    double best = 1e30;
+    int splits = 1;
+    for (int sp = 1; sp <= 64 && sp <= ktiles; ++sp) {
+        const long rounds = (tiles * sp + 255) / 256;
+        const double t = rounds * (((ktiles + sp - 1) / sp) * 2.2 + 6.0) + (sp + 2) * (4.0 * N * K / 1e6) / 5.0;
+        if (t < best) { best = t; splits = sp; }
+    }
+    return splits;
+}
+}  // namespace
+
+// Token-major wgrad: dW[N,K] (f32, row stride ldc) += dY[tokens,N]^T . X[tokens,K], bf16 operands as the step's kernels left them (no
+// transposed copies).  Returns 1 (nothing launched) when the shape is outside the kernel's coverage -- tokens % 64, N % 256, K % 256 --
+// so that the caller can take the transposing path (cs_transpose_bf16 + cs_gemm_wgrad).  Workspace: cs_gemm_wgrad_tn_workspace bytes.
+extern "C" size_t cs_gemm_wgrad_tn_workspace(int N, int K, int tokens) {
+    if (tokens % 64 != 0 || N % 256 != 0 || K % 256 != 0 || tokens <= 0) return 0;
+    return (size_t)choose_tn_splits(N, K, tokens) * N * K * sizeof(float);
+}
+
+extern "C" int cs_gemm_wgrad_tn(const void* dY, const void* X, float* dW, void* workspace, int N, int K, int tokens, int ldy, int ldx, int ldc,
+                                hipStream_t stream) {
+    if (tokens % 64 != 0 || N % 256 != 0 || K % 256 != 0 || tokens <= 0) return 1;
+    CS_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace % 16) == 0 && dW != nullptr && ((uintptr_t)dW % 16) == 0 && ldc % 4 == 0,
+                 "cs_gemm_wgrad_tn: workspace / dW must be 16-byte aligned buffers");
+    CS_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0 && ldy >= N && ldx >= K,
+                 "cs_gemm_wgrad_tn: operand rows must be 16-byte aligned");
+    CS_CHECK_ARG((long)64 * ldy * 2 < 0x7fffffffL && (long)64 * ldx * 2 < 0x7fffffffL, "cs_gemm_wgrad_tn: row stride too large");
+    const int splits = choose_tn_splits(N, K, tokens);
+    GemmArgs a;
+    a.A = (const __bf16*)dY; a.B = (const __bf16*)X; a.C = workspace; a.bias = nullptr; a.extra = nullptr;
+    a.M = N; a.N = K; a.K = tokens; a.lda = ldy; a.ldb = ldx; a.ldc = K; a.group = 0;
+    a.split_stride = (long)N * K;
+    a.ln_mean = a.ln_rstd = a.ln_colsum = nullptr; a.stats_part = nullptr; a.xb_out = nullptr; a.ldxb = 0;
+    a.tiles_m = N / 256; a.tiles_n = K / 256; a.gm = 8; a.dbg = 0; a.rm = 0; a.nsplit = 1; a.reserve = 0;
+    const int ktiles = tokens / 64;
+    a.ktiles_per_split = (ktiles + splits - 1) / splits;
+    constexpr size_t lds = 160 * 1024;
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
+    CS_LAUNCH_CHECK();
+    const long n = (long)N * (K >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, splits,
+                       (long)N * K, dW, N, K, ldc);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" size_t cs_gemm_wgrad_workspace(int M, int N, int K) {
     int cfg, splits;

@@ -153,6 +153,7 @@ class EvaEngine:
         # contraction by the block-scaled fp8 MFMA, fp32 accumulate; backward (dgrad / wgrad) keeps the bf16 operands.  enable_fp8_forward().
         self.fp8_forward = False
         self.w8 = {}
+        self.wgrad_tn = True                   # weight gradients from the token-major operands (no transposed copies) where the shape allows
         if trainable:
             self.grad = ops.zeros((self.numel,), F32)
             self.exp_avg = ops.zeros((self.numel,), F32)
@@ -597,10 +598,19 @@ class EvaEngine:
     def zero_grad(self):
         self.grad.zero_()
 
-    def _wgrad(self, dY, Xt, dW):
-        """dW[N,K] += dY^T X with X^T [K, Mp] already materialised (contraction dim contiguous, zero padded)."""
+    def _wgrad(self, dY, X, dW):
+        """dW[N,K] += dY^T X, dY [M,N] and X [M,K] token-major bf16.  cs_gemm_wgrad_tn contracts them as they are (transposing LDS
+        reads); shapes it does not cover (tokens % 64, N or K % 256) go through explicit transposes + the NT split-K kernel."""
         ops = self.ops
         M, N = dY.shape
+        K = X.shape[1]
+        need = ops.gemm_wgrad_tn_workspace(N, K, M) if self.wgrad_tn else 0
+        if need:
+            if self._wgrad_ws is None or self._wgrad_ws.numel() < need:
+                self._wgrad_ws = ops.empty((need,), torch.uint8)
+            ops.gemm_wgrad_tn(dY, X, dW, self._wgrad_ws)
+            return
+        Xt = self._transposed(X)
         Mp = Xt.shape[1]
         dYt = ops.empty((N, Mp), BF16)
         ops.transpose_bf16(dY, dYt)
@@ -627,7 +637,7 @@ class EvaEngine:
         gb = ops.empty((M, C), BF16)
         ops.cast_f32_bf16(g, gb)
         ops.colsum_bf16(gb, G[b + "mlp.w3.bias"])
-        self._wgrad(gb, self._transposed(s["fln"]), self.storage_of(self.grad, b + "mlp.w3.weight"))
+        self._wgrad(gb, s["fln"], self.storage_of(self.grad, b + "mlp.w3.weight"))
         d_fln = ops.empty((M, Hd), BF16)
         ops.gemm_nt(gb, self.wt[(i, "w3")][:, :C], d_fln, epi=EPI_BF16)                     # [M,C] . W3[C,Hd]
         d_hid = (ops.zeros if padded else ops.empty)((M, Hd), BF16)
@@ -638,7 +648,7 @@ class EvaEngine:
         ob = self.offsets[b + "mlp.w1.bias"][0]
         ops.colsum_bf16(d_x12, self.grad[ob:ob + 2 * Hd])
         ow = self.offsets[b + "mlp.w1.weight"][0]
-        self._wgrad(d_x12, self._transposed(s["ln2"]), self.grad[ow:ow + 2 * Hd * C].view(2 * Hd, C))
+        self._wgrad(d_x12, s["ln2"], self.grad[ow:ow + 2 * Hd * C].view(2 * Hd, C))
         d_ln2 = ops.empty((M, C), BF16)
         ops.gemm_nt(d_x12, self.wt[(i, "w12")][:, :2 * Hd], d_ln2, epi=EPI_BF16)            # [M,2Hd] . W12[2Hd,C]
         ops.layernorm_bwd(d_ln2, s["x1"], self.p[b + "norm2.weight"], *s["st3"], g, DX_F32_ACCUM,
@@ -646,13 +656,12 @@ class EvaEngine:
         # ---- attention branch: x1 = x0 + proj(inner_ln(att)) -------------------------------------
         ops.cast_f32_bf16(g, gb)
         ops.colsum_bf16(gb, G[b + "attn.proj.bias"])
-        self._wgrad(gb, self._transposed(s["iln"]), G[b + "attn.proj.weight"])
+        self._wgrad(gb, s["iln"], G[b + "attn.proj.weight"])
         d_iln = ops.empty((M, C), BF16)
         ops.gemm_nt(gb, self.wt[(i, "proj")][:, :C], d_iln, epi=EPI_BF16)
         d_att = ops.empty((M, C), BF16)
         ops.layernorm_bwd(d_iln, s["att"], self.p[b + "attn.inner_attn_ln.weight"], *s["st2"], d_att, DX_BF16,
                           G[b + "attn.inner_attn_ln.weight"], G[b + "attn.inner_attn_ln.bias"], True, ws)
-        ln1_t = self._transposed(s["ln1"])
         oq = self.offsets[b + "attn.q_proj.weight"][0]
         d_ln1 = ops.empty((M, C), BF16)
         if s["with_attn"]:
@@ -660,11 +669,11 @@ class EvaEngine:
             ops.attn_bwd(s["qkv"], s["att"], d_att, s["lse"], cos, sin, d_qkv, ws, B, N, H, cfg.head_width ** -0.5)
             ops.colsum_bf16(d_qkv[:, :C], G[b + "attn.q_bias"])        # K has no bias (eva_vit_model.py:178)
             ops.colsum_bf16(d_qkv[:, 2 * C:], G[b + "attn.v_bias"])
-            self._wgrad(d_qkv, ln1_t, self.grad[oq:oq + 3 * C * C].view(3 * C, C))
+            self._wgrad(d_qkv, s["ln1"], self.grad[oq:oq + 3 * C * C].view(3 * C, C))
             ops.gemm_nt(d_qkv, self.wt[(i, "qkv")][:, :3 * C], d_ln1, epi=EPI_BF16)
         else:
             ops.colsum_bf16(d_att, G[b + "attn.v_bias"])
-            self._wgrad(d_att, ln1_t, G[b + "attn.v_proj.weight"])
+            self._wgrad(d_att, s["ln1"], G[b + "attn.v_proj.weight"])
             ops.gemm_nt(d_att, self.wt[(i, "qkv")][:, 2 * C:3 * C], d_ln1, epi=EPI_BF16)
         ops.layernorm_bwd(d_ln1, s["x0"], self.p[b + "norm1.weight"], *s["st1"], g, DX_F32_ACCUM,
                           G[b + "norm1.weight"], G[b + "norm1.bias"], True, ws)

@@ -326,13 +326,13 @@ class ClipVitEngine(EvaEngine):
         gb = ops.empty((M, C), BF16)
         ops.cast_f32_bf16(g, gb)
         ops.colsum_bf16(gb, G[b + "mlp.c_proj.bias"])
-        self._wgrad(gb, self._transposed(s["hid"]), G[b + "mlp.c_proj.weight"])
+        self._wgrad(gb, s["hid"], G[b + "mlp.c_proj.weight"])
         d_hid = ops.empty((M, Hd), BF16)
         ops.gemm_nt(gb, self.wt[(i, "cproj")][:, :C], d_hid, epi=EPI_BF16)                   # [M,C] . c_proj[C,Hd]
         d_fc = ops.empty((M, Hd), BF16)
         ops.gelu_bwd(d_hid, s["fc"], d_fc, cfg.quick_gelu)
         ops.colsum_bf16(d_fc, G[b + "mlp.c_fc.bias"])
-        self._wgrad(d_fc, self._transposed(s["ln2"]), G[b + "mlp.c_fc.weight"])
+        self._wgrad(d_fc, s["ln2"], G[b + "mlp.c_fc.weight"])
         d_ln2 = ops.empty((M, C), BF16)
         ops.gemm_nt(d_fc, self.wt[(i, "fc")][:, :Hd], d_ln2, epi=EPI_BF16)                   # [M,Hd] . c_fc[Hd,C]
         ops.layernorm_bwd(d_ln2, s["x1"], self.p[b + "ln_2.weight"], *s["st2"], g, DX_F32_ACCUM,
@@ -340,21 +340,20 @@ class ClipVitEngine(EvaEngine):
         # ---- attention branch: x1 = x0 + out_proj(att) ------------------------------------------
         ops.cast_f32_bf16(g, gb)
         ops.colsum_bf16(gb, G[b + "attn.out_proj.bias"])
-        self._wgrad(gb, self._transposed(s["att"]), G[b + "attn.out_proj.weight"])
+        self._wgrad(gb, s["att"], G[b + "attn.out_proj.weight"])
         d_att = ops.empty((M, C), BF16)
         ops.gemm_nt(gb, self.wt[(i, "proj")][:, :C], d_att, epi=EPI_BF16)
-        ln1_t = self._transposed(s["ln1"])
         d_ln1 = ops.empty((M, C), BF16)
         Gw, Gb = G[b + "attn.in_proj_weight"], G[b + "attn.in_proj_bias"]
         if s["with_attn"]:
             d_qkv = ops.empty((M, 3 * C), BF16)
             ops.attn_bwd(s["qkv"], s["att"], d_att, s["lse"], cos, sin, d_qkv, ws, B, N, H, cfg.head_width ** -0.5)
             ops.colsum_bf16(d_qkv, Gb)                                                       # q, k and v all carry a bias here
-            self._wgrad(d_qkv, ln1_t, Gw)
+            self._wgrad(d_qkv, s["ln1"], Gw)
             ops.gemm_nt(d_qkv, self.wt[(i, "qkv")][:, :3 * C], d_ln1, epi=EPI_BF16)
         else:
             ops.colsum_bf16(d_att, Gb[2 * C:])                                               # q/k rows keep their zero gradient
-            self._wgrad(d_att, ln1_t, Gw[2 * C:])
+            self._wgrad(d_att, s["ln1"], Gw[2 * C:])
             ops.gemm_nt(d_att, self.wt[(i, "qkv")][:, 2 * C:3 * C], d_ln1, epi=EPI_BF16)
         ops.layernorm_bwd(d_ln1, s["x0"], self.p[b + "ln_1.weight"], *s["st1"], g, DX_F32_ACCUM,
                           G[b + "ln_1.weight"], G[b + "ln_1.bias"], True, ws)

@@ -32,6 +32,8 @@ SIGNATURES = {
     "cs_resize_bilinear_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "cs_gemm_wgrad_workspace": (_sz, [_i, _i, _i]),
     "cs_gemm_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cs_gemm_wgrad_tn_workspace": (_sz, [_i, _i, _i]),
+    "cs_gemm_wgrad_tn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_gemm_nt_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_ln_stats_finalize": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "cs_attn_fwd_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
@@ -233,6 +235,22 @@ class HipOps:
         assert workspace.numel() * workspace.element_size() >= self.gemm_wgrad_workspace(M, N, K)
         self._ok(self.lib.cs_gemm_wgrad(_p(A), _p(B), _p(dW), _p(workspace), M, N, K, A.stride(0), B.stride(0), dW.stride(0),
                                         self._stream()), "cs_gemm_wgrad")
+
+    def gemm_wgrad_tn_workspace(self, N, K, tokens) -> int:
+        """Bytes of workspace for gemm_wgrad_tn, 0 when the shape is outside its coverage (take the transposing path then)."""
+        return int(self.lib.cs_gemm_wgrad_tn_workspace(N, K, tokens))
+
+    def gemm_wgrad_tn(self, dY, X, dW, workspace):
+        """dW[N,K] += dY[tokens,N]^T . X[tokens,K] from the token-major operands (no transposed copies)."""
+        self._chk(dY, X, dW, workspace)
+        T, N = dY.shape
+        K = X.shape[1]
+        assert X.shape[0] == T and dY.stride(1) == 1 and X.stride(1) == 1 and dW.stride(1) == 1 and dW.dtype == torch.float32
+        assert workspace.numel() * workspace.element_size() >= self.gemm_wgrad_tn_workspace(N, K, T) > 0
+        rc = self.lib.cs_gemm_wgrad_tn(_p(dY), _p(X), _p(dW), _p(workspace), N, K, T, dY.stride(0), X.stride(0), dW.stride(0), self._stream())
+        if rc == 1:
+            raise RuntimeError("cs_gemm_wgrad_tn: shape outside the kernel's coverage (check gemm_wgrad_tn_workspace first)")
+        self._ok(rc, "cs_gemm_wgrad_tn")
 
     def ln_stats_finalize(self, part, npp, C, mean, rstd, eps=1e-6):
         self._chk(part, mean, rstd)

@@ -53,6 +53,14 @@ size_t cs_gemm_wgrad_workspace(int M, int N, int K);
 int cs_gemm_wgrad(const void* A, const void* B, float* dW, void* workspace, int M, int N, int K, int lda, int ldb, int ldc,
                   cs_stream_t stream);
 
+/* The same weight gradient without transposed copies: dW[N,K] (f32) += dY[tokens,N]^T . X[tokens,K], both operands token-major as the
+ * backward left them (MFMA operands through the transposing LDS read ds_read_b64_tr_b16).  Covers tokens % 64 == 0, N % 256 == 0,
+ * K % 256 == 0: cs_gemm_wgrad_tn_workspace returns 0 and cs_gemm_wgrad_tn returns 1 (nothing launched) otherwise -- use
+ * cs_transpose_bf16 + cs_gemm_wgrad then. */
+size_t cs_gemm_wgrad_tn_workspace(int N, int K, int tokens);
+int cs_gemm_wgrad_tn(const void* dY, const void* X, float* dW, void* workspace, int N, int K, int tokens, int ldy, int ldx, int ldc,
+                     cs_stream_t stream);
+
 /* cs_gemm_nt with a LayerNorm folded in (frozen teacher): the GEMM reads the *un-normalised* bf16 rows, B = gamma (.) W,
  * ln_colsum[n] = sum_k B[n,k], bias = W.beta + b, and the epilogue applies rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]:
  *   epi 6: residual form, C = extra + that value                  (SwiGLU.ffn_ln -> w3 eva_vit_model.py:102-103, inner_attn_ln -> proj :218-219)

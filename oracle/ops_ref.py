@@ -160,6 +160,12 @@ class RefOps:
     def gemm_wgrad(self, A, B, dW, workspace):
         dW.add_(A.float() @ B.float().T)
 
+    def gemm_wgrad_tn_workspace(self, N, K, tokens):
+        return 16 if (tokens % 64 == 0 and N % 256 == 0 and K % 256 == 0 and tokens > 0) else 0
+
+    def gemm_wgrad_tn(self, dY, X, dW, workspace):
+        dW.add_(dY.float().T @ X.float())
+
     def ln_stats_finalize(self, part, npp, C, mean, rstd, eps=1e-6):
         P = part.shape[0]
         keep = [p for p in range(P) if C - p * npp > 0]

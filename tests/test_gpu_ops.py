@@ -746,3 +746,27 @@ def test_multiscale_bilinear_resize_matches_torch(hip, ref, shape, size):
     got = hip.resize_bilinear(x.cuda(), size)
     want = ref.resize_bilinear(x, size)
     check(f"resize_bilinear{list(shape)}->{size}", got, want, 1e-6)
+
+
+@pytest.mark.parametrize("N,K,T", [(768, 768, 12608), (2304, 768, 12608), (4096, 768, 12608), (768, 2048, 12608), (256, 256, 64), (1024, 3072, 1152)])
+def test_gemm_wgrad_token_major_operands(hip, ref, N, K, T):
+    """cs_gemm_wgrad_tn: dW += dY^T X straight from the token-major operands (transposing LDS reads, no transposed copies), against the
+    fp32 product; accumulates into dW; reports shapes it does not cover instead of computing them."""
+    dY, X = rnd((T, N), BF, 0.5, seed=70), rnd((T, K), BF, 0.5, seed=71)
+    base = rnd((N, K), F32, seed=72)
+    need = hip.gemm_wgrad_tn_workspace(N, K, T)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    got = base.cuda().clone()
+    hip.gemm_wgrad_tn(dY.cuda(), X.cuda(), got, ws)
+    want = base + dY.float().T @ X.float()
+    check(f"gemm_wgrad_tn[{N},{K},{T}]", got, want, 2e-5)
+    again = base.cuda().clone()
+    hip.gemm_wgrad_tn(dY.cuda(), X.cuda(), again, ws)
+    assert torch.equal(again, got), "split-K through partials must be bit-reproducible"
+    # strided operands (views into wider matrices), as the engine passes them
+    wide = rnd((T, N + 256), BF, 0.5, seed=73)
+    got2 = torch.zeros(N, K, device="cuda")
+    hip.gemm_wgrad_tn(wide.cuda()[:, 256:], X.cuda(), got2, ws)
+    check(f"gemm_wgrad_tn_strided[{N},{K},{T}]", got2, wide[:, 256:].float().T @ X.float(), 2e-5)
+    assert hip.gemm_wgrad_tn_workspace(N, K, T + 32) == 0 and hip.gemm_wgrad_tn_workspace(N + 64, K, T) == 0
