@@ -261,6 +261,29 @@ def wgrad_ab():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 20
         line += f"cs_gemm_wgrad (partials, ws {ws.numel() >> 20} MiB): {us:6.1f} ({2.0 * N * K * Mp / us / 1e6:4.0f})"
+        # the same gradient from the token-major operands: no transposed copies (old path = 2 transposes + cs_gemm_wgrad)
+        T = int(sys.argv[1]) * 197
+        dY, X = torch.randn(T, N, device="cuda").to(BF), torch.randn(T, K, device="cuda").to(BF)
+        dYt, Xt = torch.empty(N, Mp, dtype=BF, device="cuda"), torch.empty(K, Mp, dtype=BF, device="cuda")
+        need = ops.gemm_wgrad_tn_workspace(N, K, T)
+        if need:
+            ws2 = torch.empty(need, dtype=torch.uint8, device="cuda")
+
+            def old_path():
+                ops.transpose_bf16(dY, dYt)
+                ops.transpose_bf16(X, Xt)
+                ops.gemm_wgrad(dYt, Xt, C, ws)
+            for tag, fn in (("transposes + NT", old_path), ("TN", lambda: ops.gemm_wgrad_tn(dY, X, C, ws2))):
+                for _ in range(3):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 20
+                line += f" | {tag}: {us:6.1f} ({2.0 * N * K * T / us / 1e6:4.0f})"
         print(line, flush=True)
 
 
