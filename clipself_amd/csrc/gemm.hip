@@ -1356,15 +1356,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // bf16 transposes of dY and X (2 x 4 per block and step).  Requires tokens % 64 == 0, N % 256 == 0, K % 256 == 0.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int tok, int colbyte) {
+__device__ __forceinline__ int tn_swz(int tok, int alt) { return alt ? ((tok & 3) << 1) : (tok & 7); }
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int tok, int colbyte, int alt) {
     // rows tok .. tok+3 and tok+4 .. tok+7 of the lane's column; colbyte = logical byte offset of the lane's 8-byte segment in the row
-    const int a0 = tok * 512 + (colbyte ^ ((tok & 7) << 5)), a1 = (tok + 4) * 512 + (colbyte ^ (((tok + 4) & 7) << 5));
+    const int a0 = tok * 512 + (colbyte ^ (tn_swz(tok, alt) << 5)), a1 = (tok + 4) * 512 + (colbyte ^ (tn_swz(tok + 4, alt) << 5));
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + a0));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + a1));
-    union { short s[8]; bf16x8 v; } u;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { u.s[e] = lo[e]; u.s[4 + e] = hi[e]; }
-    return u.v;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
 }
 
 __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
@@ -1380,12 +1380,12 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
     const int n0 = tm * BM, k0 = tn * BN;
     char* const b_ring = smem + 3 * T_BYTES;
     // DMA: instruction x of this wave fills LDS rows 2*(wave*4+x), +1; lane l lands at row + (l >> 5), physical 16-byte chunk l & 31
-    const int drow = lane >> 5, pc = lane & 31;
+    const int drow = lane >> 5, pc = lane & 31, alt = p.dbg & 1;
     unsigned aoff[4], boff[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
         const int row = 2 * (wave * 4 + x) + drow;
-        const int lc = ((((pc >> 1) ^ (row & 7)) << 1) | (pc & 1));          // logical 16-byte chunk this LDS position holds
+        const int lc = ((((pc >> 1) ^ tn_swz(row, alt)) << 1) | (pc & 1));   // logical 16-byte chunk this LDS position holds
         aoff[x] = (unsigned)(row * p.lda + n0 + lc * 8) * 2u;
         boff[x] = (unsigned)(row * p.ldb + k0 + lc * 8) * 2u;
     }
@@ -1426,9 +1426,9 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
         for (int ts = 0; ts < 4; ++ts) {
             bf16x8 a[FM], b[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) a[i] = tr_frag(ta, 16 * ts + trow, (wm * TM + i * 32) * 2 + segbyte);
+            for (int i = 0; i < FM; ++i) a[i] = tr_frag(ta, 16 * ts + trow, (wm * TM + i * 32) * 2 + segbyte, alt);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) b[j] = tr_frag(tb, 16 * ts + trow, (wn * TN + j * 32) * 2 + segbyte);
+            for (int j = 0; j < FN; ++j) b[j] = tr_frag(tb, 16 * ts + trow, (wn * TN + j * 32) * 2 + segbyte, alt);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -1492,13 +1492,14 @@ extern "C" int cs_gemm_wgrad_tn(const void* dY, const void* X, float* dW, void* 
     CS_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0 && ldy >= N && ldx >= K,
                  "cs_gemm_wgrad_tn: operand rows must be 16-byte aligned");
     CS_CHECK_ARG((long)64 * ldy * 2 < 0x7fffffffL && (long)64 * ldx * 2 < 0x7fffffffL, "cs_gemm_wgrad_tn: row stride too large");
-    const int splits = choose_tn_splits(N, K, tokens);
+    int splits = choose_tn_splits(N, K, tokens);
     GemmArgs a;
     a.A = (const __bf16*)dY; a.B = (const __bf16*)X; a.C = workspace; a.bias = nullptr; a.extra = nullptr;
     a.M = N; a.N = K; a.K = tokens; a.lda = ldy; a.ldb = ldx; a.ldc = K; a.group = 0;
     a.split_stride = (long)N * K;
     a.ln_mean = a.ln_rstd = a.ln_colsum = nullptr; a.stats_part = nullptr; a.xb_out = nullptr; a.ldxb = 0;
     a.tiles_m = N / 256; a.tiles_n = K / 256; a.gm = 8; a.dbg = 0; a.rm = 0; a.nsplit = 1; a.reserve = 0;
+    if (const char* e = getenv("CS_TN_SWZ")) a.dbg = atoi(e);
     const int ktiles = tokens / 64;
     a.ktiles_per_split = (ktiles + splits - 1) / splits;
     constexpr size_t lds = 160 * 1024;
