@@ -1356,10 +1356,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // bf16 transposes of dY and X (2 x 4 per block and step).  Requires tokens % 64 == 0, N % 256 == 0, K % 256 == 0.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-__device__ __forceinline__ int tn_swz(int tok, int alt) { return alt ? ((tok & 3) << 1) : (tok & 7); }
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int tok, int colbyte, int alt) {
+// 32-byte column group g of token row t sits at group g ^ tn_swz(t): the two 16-lane groups of a half-wave read the same four tokens at
+// adjacent column groups, so the four tokens must land on every second group (g ^ (t & 7) leaves a 2-way conflict: measured 2-5 % slower)
+__device__ __forceinline__ int tn_swz(int tok) { return (tok & 3) << 1; }
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int tok, int colbyte) {
     // rows tok .. tok+3 and tok+4 .. tok+7 of the lane's column; colbyte = logical byte offset of the lane's 8-byte segment in the row
-    const int a0 = tok * 512 + (colbyte ^ (tn_swz(tok, alt) << 5)), a1 = (tok + 4) * 512 + (colbyte ^ (tn_swz(tok + 4, alt) << 5));
+    const int a0 = tok * 512 + (colbyte ^ (tn_swz(tok) << 5)), a1 = (tok + 4) * 512 + (colbyte ^ (tn_swz(tok + 4) << 5));
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + a0));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + a1));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -1380,12 +1382,12 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
     const int n0 = tm * BM, k0 = tn * BN;
     char* const b_ring = smem + 3 * T_BYTES;
     // DMA: instruction x of this wave fills LDS rows 2*(wave*4+x), +1; lane l lands at row + (l >> 5), physical 16-byte chunk l & 31
-    const int drow = lane >> 5, pc = lane & 31, alt = p.dbg & 1;
+    const int drow = lane >> 5, pc = lane & 31;
     unsigned aoff[4], boff[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
         const int row = 2 * (wave * 4 + x) + drow;
-        const int lc = ((((pc >> 1) ^ tn_swz(row, alt)) << 1) | (pc & 1));   // logical 16-byte chunk this LDS position holds
+        const int lc = ((((pc >> 1) ^ tn_swz(row)) << 1) | (pc & 1));   // logical 16-byte chunk this LDS position holds
         aoff[x] = (unsigned)(row * p.lda + n0 + lc * 8) * 2u;
         boff[x] = (unsigned)(row * p.ldb + k0 + lc * 8) * 2u;
     }
@@ -1418,6 +1420,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int i0 = kt - kt_begin;
+        // one burst behind the barrier: spreading the pieces over the k-steps makes hipcc drain the DMA queue (vmcnt(0)) in front of every
+        // transposing read that follows a DMA issue -- measured 115.9 -> 136.9 us on the W1|W2 shape
         if (kt + 1 < kt_end) issue(p.B, p.ldb, boff, kt + 1, b_ring + ((i0 + 1) & 1) * T_BYTES);
         if (kt + 2 < kt_end) issue(p.A, p.lda, aoff, kt + 2, smem + ((i0 + 2) % 3) * T_BYTES);
         const char* ta = smem + cur * T_BYTES;
@@ -1426,9 +1430,9 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
         for (int ts = 0; ts < 4; ++ts) {
             bf16x8 a[FM], b[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) a[i] = tr_frag(ta, 16 * ts + trow, (wm * TM + i * 32) * 2 + segbyte, alt);
+            for (int i = 0; i < FM; ++i) a[i] = tr_frag(ta, 16 * ts + trow, (wm * TM + i * 32) * 2 + segbyte);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) b[j] = tr_frag(tb, 16 * ts + trow, (wn * TN + j * 32) * 2 + segbyte, alt);
+            for (int j = 0; j < FN; ++j) b[j] = tr_frag(tb, 16 * ts + trow, (wn * TN + j * 32) * 2 + segbyte);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -1499,7 +1503,6 @@ extern "C" int cs_gemm_wgrad_tn(const void* dY, const void* X, float* dW, void* 
     a.split_stride = (long)N * K;
     a.ln_mean = a.ln_rstd = a.ln_colsum = nullptr; a.stats_part = nullptr; a.xb_out = nullptr; a.ldxb = 0;
     a.tiles_m = N / 256; a.tiles_n = K / 256; a.gm = 8; a.dbg = 0; a.rm = 0; a.nsplit = 1; a.reserve = 0;
-    if (const char* e = getenv("CS_TN_SWZ")) a.dbg = atoi(e);
     const int ktiles = tokens / 64;
     a.ktiles_per_split = (ktiles + splits - 1) / splits;
     constexpr size_t lds = 160 * 1024;
