@@ -235,7 +235,9 @@ def main():
     from clipself_amd.training.train import train_step
 
     rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    distributed = world > 1
+    # CLIPSELF_FORCE_DIST=1: take the data-parallel path (process group, bucketed all-reduce, CU reservation) even with one rank --
+    # the only way to run the RCCL calls of the N-rank path on a one-GPU box
+    distributed = world > 1 or os.environ.get("CLIPSELF_FORCE_DIST") == "1"
     # CLIPSELF_DIST_BACKEND=gloo + fewer devices than ranks is the single-GPU rehearsal of the N-rank path used by
     # tests/test_gpu_step.py (RCCL refuses two ranks on one device); the driver's runs use nccl (= RCCL), one rank per GPU.
     if torch.cuda.device_count() < 1:
@@ -246,7 +248,11 @@ def main():
     torch.cuda.set_device(local)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend=os.environ.get("CLIPSELF_DIST_BACKEND", "nccl"), init_method="env://", world_size=world, rank=rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        backend = os.environ.get("CLIPSELF_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank,
+                                device_id=torch.device(f"cuda:{local}") if backend == "nccl" else None)
     device = f"cuda:{local}"
 
     student = create_model(MODEL, "eva", precision="amp_bf16", device=device, cache_dir=None)

@@ -49,8 +49,9 @@ def init_distributed_device(args):
     if is_using_distributed():
         args.local_rank, args.rank, args.world_size = world_info_from_env()
         if not dist.is_initialized():
-            dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url,
-                                    world_size=args.world_size, rank=args.rank)
+            bound = args.dist_backend == "nccl" and torch.cuda.is_available() and not getattr(args, "no_set_device_rank", False)
+            dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url, world_size=args.world_size, rank=args.rank,
+                                    device_id=torch.device(f"cuda:{args.local_rank}") if bound else None)
         args.distributed = True
     if torch.cuda.is_available():
         device = f"cuda:{args.local_rank}" if args.distributed and not getattr(args, "no_set_device_rank", False) else "cuda:0"
@@ -82,7 +83,7 @@ def rccl_reserved_cus() -> int:
 
 def _reserve_for_collectives(module):
     ops = getattr(getattr(getattr(module, "visual", None), "engine", None), "ops", None)
-    if ops is not None and hasattr(ops, "reserve_compute_units") and dist.get_world_size() > 1:
+    if ops is not None and hasattr(ops, "reserve_compute_units") and (dist.get_world_size() > 1 or os.environ.get("CLIPSELF_FORCE_DIST") == "1"):
         ops.reserve_compute_units(rccl_reserved_cus())
 
 

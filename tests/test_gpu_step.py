@@ -311,6 +311,29 @@ def test_bench_two_rank_rehearsal():
     assert out["value"] > 0 and 0.0 < out["config"]["loss_last_step"] < 2.0
 
 
+def test_bench_rccl_single_rank_path():
+    """The N-rank code path of bench.py on the RCCL backend with one rank (CLIPSELF_FORCE_DIST=1: RCCL refuses two ranks on one
+    device): process group on `nccl`, parameter broadcast, per-block asynchronous all-reduce from the grad-ready hook, CU reservation,
+    barrier + max-over-ranks timing.  The loss after 3 steps equals the plain single-process run's (same seeds; SUM over one rank / 1)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    outs = []
+    for force in ("1", "0"):
+        env = dict(os.environ, CLIPSELF_FORCE_DIST=force, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        env.pop("WORLD_SIZE", None)
+        r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-overlap"],
+                           cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    a, b = outs
+    _log(f"bench RCCL single-rank path: {a['value']:.1f} img/s (plain {b['value']:.1f}), loss {a['config']['loss_last_step']:.6f} vs {b['config']['loss_last_step']:.6f}")
+    assert a["n_gpus"] == 1 and a["config"]["parallelism"] == "dp1"
+    assert abs(a["config"]["loss_last_step"] - b["config"]["loss_last_step"]) < 2e-4
+
+
 def test_teacher_prefetch_on_side_stream_equals_inline():
     """train_step(next_batch=...) runs the frozen teacher one batch ahead on a side stream (overlapping the student's backward and
     AdamW); the training trajectory must be the one of the inline schedule."""
