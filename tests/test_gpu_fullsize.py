@@ -298,3 +298,81 @@ def test_multiscale_step_matches_the_oracle_at_the_drawn_size(monkeypatch):
     got = float(out["loss_cosine"].detach())
     _log(f"N1 --multiscale: 896^2 -> 672^2 (1765 tokens) step loss {got:.6f} vs oracle {want:.6f} (rel {abs(got - want) / want:.2e})")
     assert abs(got - want) / want < 1e-3
+
+
+def _loss_from_features(student, teacher, batch):
+    """fp64 cosine loss over the valid boxes, from the towers' own features (clipself.py:29-47)."""
+    images, boxes, crops = batch
+    valid = boxes[..., 4] > 0.5
+    rois = [b[v][:, :4] for b, v in zip(boxes, valid)]
+    with torch.no_grad():
+        t = teacher.encode_image(crops[valid]).double()
+        s = student.encode_pseudo_boxes(images, rois).double()
+    return float(1 - torch.nn.functional.cosine_similarity(s, t, dim=-1).mean()), int(valid.sum()), s, t
+
+
+def test_cfg2_region_proposals_full_batch_with_ragged_validity():
+    """BASELINE configs[2] per-GPU shape (B/16, 64 images x 20 proposal slots, ~70 % valid, every image keeps >= 1 box;
+    data.py:41,84-132 + clipself.py:29-36): the step's loss equals the fp64 loss over exactly the valid boxes, gradients are finite and
+    non-zero, and the features of the first two images' valid boxes match the oracle."""
+    from oracle import eva_ref
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.train import train_step
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    batch = synthetic_batch(64, 20, 224, 224, seed=4321, valid_prob=0.7)
+    dev = tuple(t.cuda() for t in batch)
+    student, teacher = _pair(cfg, 0)
+    want, n_valid, s, _ = _loss_from_features(student, teacher, dev)
+    assert 64 <= n_valid < 64 * 20
+    opt = FlatAdamW(student, lr=1e-5, weight_decay=0.1)
+    out, bs, _ = train_step(student, CLIPSelf(), dev, opt, None, 0, teacher, _args(skip_scheduler=True))
+    loss = float(out["loss"].detach())
+    g = student.visual.engine.grad
+    _log(f"cfg2 proposals full batch (64 images x 20 slots, {n_valid} valid): loss {loss:.6f} vs fp64 on the valid boxes {want:.6f}, "
+         f"|grad| {float(g.double().norm()):.4e}")
+    assert bs == 64 and abs(loss - want) < 2e-5
+    assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    images, boxes, _ = batch
+    keep = [b[b[:, 4] > 0.5][:, :4] for b in boxes[:2]]
+    ref = eva_ref.encode_pseudo_boxes(seeded_visual_state(cfg, 0), cfg, images[:2], keep)
+    got = s[: ref.shape[0]]
+    r, c = rel(got, ref), one_minus_cos(got, ref)
+    _log(f"cfg2 proposals: RoI features of the first 2 images ({ref.shape[0]} valid boxes) vs oracle: rel-L2 {r:.3e}, max 1-cos {c:.2e}")
+    assert r < 1.5e-2 and c < 2e-4
+
+
+def test_cfg3_l14_336_clipself_full_batch():
+    """BASELINE configs[3] per-GPU shape (EVA02-CLIP-L-14-336, 16 images x 32 crops at 336^2: 512 crops x 577 tokens = 295 424 GEMM rows,
+    24 layers, hidden 2730 padded to 2752): the step's loss equals the fp64 loss from the towers' own features, six teacher crops sampled
+    over the batch match the oracle, the gradient is finite, and a second step lowers nothing to NaN."""
+    from oracle import eva_ref
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.train import train_step
+    cfg = get_tower_cfg("EVA02-CLIP-L-14-336")
+    batch = synthetic_batch(16, 32, 336, 336, seed=99)
+    dev = tuple(t.cuda() for t in batch)
+    student, teacher = _pair(cfg, 0)
+    want, n_valid, _, t = _loss_from_features(student, teacher, dev)
+    assert n_valid == 512
+    opt = FlatAdamW(student, lr=1e-5, weight_decay=0.1)
+    method = CLIPSelf()
+    out, bs, _ = train_step(student, method, dev, opt, None, 0, teacher, _args(skip_scheduler=True))
+    loss = float(out["loss"].detach())
+    g = student.visual.engine.grad
+    gn = float(g.double().norm())
+    assert torch.isfinite(g).all() and gn > 0
+    out2, _, _ = train_step(student, method, dev, opt, None, 1, teacher, _args(skip_scheduler=True))
+    loss2 = float(out2["loss"].detach())
+    _log(f"cfg3 L/14-336 CLIPSelf full batch (16 images x 32 crops): loss {loss:.6f} vs fp64 on the same features {want:.6f}; "
+         f"|grad| {gn:.4e}; loss after one AdamW step {loss2:.6f}")
+    assert bs == 16 and abs(loss - want) < 2e-5
+    assert np.isfinite(loss2) and loss2 < loss + 1e-3
+    idx = torch.tensor([0, 1, 100, 255, 300, 511])
+    crops = batch[2].flatten(0, 1)[idx]
+    ref = eva_ref.encode_image(seeded_visual_state(cfg, 0), cfg, crops)
+    got = t[idx.cuda()]
+    r, c = rel(got, ref), one_minus_cos(got, ref)
+    _log(f"cfg3 L/14-336 teacher, 6 crops sampled from the 512-crop pass vs oracle: rel-L2 {r:.3e}, max 1-cos {c:.2e}")
+    assert r < 1.9e-2 and c < 1e-4

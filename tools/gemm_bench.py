@@ -169,7 +169,7 @@ def student_shapes():
         C = torch.randn(M, N, device="cuda") if epi in (1, 2) else torch.empty(M, N, dtype=BF, device="cuda")
         extra = C if epi == 2 else None
         line = f"{name} M={M}: "
-        for cfg in (0, 1, 2, 4, 3, 7, 9, 8):
+        for cfg in (0, 1, 2, 4, 3, 7, 9, 8, 11):
             flags = cfg << 4
             for _ in range(3):
                 ops.gemm_nt(A, B, C, bias, extra, epi=epi, flags=flags)
