@@ -195,6 +195,8 @@ def main():
                     help="run the teacher's last block over every token instead of the CLS query only (same outputs, more work)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the teacher inline on the main stream instead of one batch ahead on a side stream (A/B switch)")
+    ap.add_argument("--no-split-stream", action="store_true",
+                    help="A/B: keep the teacher's residual stream in fp32 + bf16 copy (10 B / element / residual GEMM) instead of the two 16-bit planes (8 B)")
     ap.add_argument("--no-block-ln-fold", action="store_true",
                     help="keep norm1 / norm2 of the teacher as LayerNorm kernels (only the two sub-LayerNorms folded; A/B switch)")
     ap.add_argument("--dry-run", action="store_true",
@@ -260,6 +262,7 @@ def main():
     teacher.visual.teacher_chunk = a.teacher_chunk
     teacher.visual.engine.cls_only_last_block = not a.full_last_block
     teacher.visual.engine.fold_block_ln = not a.no_block_ln_fold
+    teacher.visual.engine.split_stream = not a.no_split_stream
     cfg = student.visual.cfg
     student.lock_image_tower(unlocked_groups=cfg.layers)
     student.train()

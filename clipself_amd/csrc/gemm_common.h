@@ -38,6 +38,12 @@ struct GemmArgs {
                           // the rounded bf16 values, residual epilogues 64-column slices of the fp32 values
     __bf16* xb_out;       // residual epilogues: optional bf16 copy of the fp32 output (operand of the next LN-folded GEMM)
     int ldxb;
+    // "split stream" (cs_gemm_nt_ln_split): the fp32 residual stream kept as two 16-bit planes of the word y = bits(x) + 0x8000 --
+    // xb_out holds y >> 16 (= x rounded to bf16, halves away from zero: the next folded GEMM's operand), lo holds y & 0xffff -- so that a
+    // residual GEMM moves 8 bytes per element (read 4, write 4) instead of 10 (fp32 in, fp32 out, bf16 copy) and loses nothing.
+    // split bit 0: the stream comes in as (xb_out, lo) instead of extra; bit 1: it leaves as (xb_out, lo) instead of C.  Row stride ldxb.
+    unsigned short* lo = nullptr;
+    int split = 0;
     int reserve;          // persistent kernels: compute units to leave free (grid = 256 - reserve), e.g. for RCCL kernels running beside the step
     int dbg;              // ablation switches for tools/gemm_bench.py: bit0 skip the in-loop operand DMA, bit1 skip ds_read+MFMA
 };

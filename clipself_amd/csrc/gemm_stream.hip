@@ -348,15 +348,18 @@ __device__ __forceinline__ void epi_swiglu_slab(const GemmArgs& p, const f32x16 
 // fp32 residual through the slab: acc (+ folded LayerNorm + bias, applied while the lane still owns a whole row) of one 32-row block goes
 // [32 rows][256 bytes] (16-byte slot s of row r at r*256 + (s ^ (r & 15)) * 16) and comes back 16 lanes per row; residual rows, outputs
 // and the bf16 copy are whole-line accesses.
-template <bool LN, bool AUX, int CP, bool F8 = false>
+// SPLIT bit 0 / bit 1: the stream arrives / leaves as the two 16-bit planes (p.xb_out, p.lo) of y = bits(x) + 0x8000 (GemmArgs::split).
+template <bool LN, bool AUX, int CP, bool F8 = false, int SPLIT = 0>
 __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, int tn, int wn,
                                                const EpiOps& eo, char* slab) {
+    static_assert(!(SPLIT & 2) || AUX, "a split stream leaves together with the row statistics");
     const int l31 = lane & 31, hf = lane >> 5;
     const int rrow = lane >> 4, piece = lane & 15, col = colw + piece * 4;
     const bool colok = col < p.N;
-    const __amdgpu_buffer_rsrc_t rc = make_rsrc((const float*)p.C + (size_t)row0 * p.ldc + colw);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.extra + (size_t)row0 * p.ldc + colw);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(AUX ? (const void*)(p.xb_out + (size_t)row0 * p.ldxb + colw) : (const void*)p.C);
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc((SPLIT & 2) ? (const void*)p.xb_out : (const void*)((const float*)p.C + (size_t)row0 * p.ldc + colw));
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((SPLIT & 1) ? (const void*)p.xb_out : (const void*)(p.extra + (size_t)row0 * p.ldc + colw));
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc((AUX || SPLIT) ? (const void*)(p.xb_out + (size_t)row0 * p.ldxb + colw) : (const void*)p.C);
+    const __amdgpu_buffer_rsrc_t rl = make_rsrc(SPLIT ? (const void*)(p.lo + (size_t)row0 * p.ldxb + colw) : (const void*)p.A);
     const size_t slice = (size_t)tn * 4 + wn;
     const __amdgpu_buffer_rsrc_t rst = make_rsrc(AUX ? (const void*)(p.stats_part + (slice * p.M + row0) * 2) : (const void*)p.C);
     const int sl0 = hf << 4;
@@ -368,7 +371,18 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
         for (int it = 0; it < 8; ++it) {
             const int rrel = i * 32 + rrow + 4 * it;
             const bool ok = colok && row0 + rrel < p.M && !(p.dbg & 8);
-            xin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(rrel * p.ldc + piece * 4) * 4u : OOB, 0, CP));
+            if constexpr (SPLIT & 1) {
+                const unsigned off = ok ? (unsigned)(rrel * p.ldxb + piece * 4) * 2u : OOB;
+                const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rb, off, 0, CP));
+                const u32x2 l = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rl, off, 0, CP));
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    xin[it][2 * w] = __uint_as_float(__builtin_amdgcn_perm(h[w], l[w], 0x05040100u) - 0x8000u);
+                    xin[it][2 * w + 1] = __uint_as_float(__builtin_amdgcn_perm(h[w], l[w], 0x07060302u) - 0x8000u);
+                }
+            } else {
+                xin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(rrel * p.ldc + piece * 4) * 4u : OOB, 0, CP));
+            }
         }
         const float rs = (LN || F8) ? eo.rstd[i] : 1.f, nm = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
 #pragma unroll
@@ -394,9 +408,19 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
             const f32x4 sv = *(const f32x4*)(slab + lrow * 256 + ((piece ^ (lrow & 15)) << 4));
             const bool ok = colok && row0 + rrel < p.M && !(p.dbg & 8);
             const f32x4 o = xin[it] + sv;
-            store16<CP>(__builtin_bit_cast(u32x4, o), rc, ok ? (unsigned)(rrel * p.ldc + piece * 4) * 4u : OOB);
+            if constexpr (SPLIT & 2) {
+                const unsigned off = ok ? (unsigned)(rrel * p.ldxb + piece * 4) * 2u : OOB;
+                unsigned y[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) y[t] = __float_as_uint(o[t]) + 0x8000u;
+                store8<CP>(u32x2{__builtin_amdgcn_perm(y[1], y[0], 0x07060302u), __builtin_amdgcn_perm(y[3], y[2], 0x07060302u)}, rb, off);
+                store8<CP>(u32x2{__builtin_amdgcn_perm(y[1], y[0], 0x05040100u), __builtin_amdgcn_perm(y[3], y[2], 0x05040100u)}, rl, off);
+            } else {
+                store16<CP>(__builtin_bit_cast(u32x4, o), rc, ok ? (unsigned)(rrel * p.ldc + piece * 4) * 4u : OOB);
+            }
             if (AUX) {
-                store8<CP>(u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])}, rb, ok ? (unsigned)(rrel * p.ldxb + piece * 4) * 2u : OOB);
+                if constexpr (!(SPLIT & 2))
+                    store8<CP>(u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])}, rb, ok ? (unsigned)(rrel * p.ldxb + piece * 4) * 2u : OOB);
                 // a row's 64 columns sit in 16 adjacent lanes (DPP butterfly); lane (lane & 15) == it keeps iteration it's row, so the
                 // 32 rows of the block leave in one 256-byte store below
                 float ps = 0.f, pq = 0.f;
@@ -431,8 +455,9 @@ constexpr int epi_stores() {
 // F8: A and B hold e4m3 bytes (K = bytes per row, a multiple of 128: one K tile = 128 contraction steps in the same 128-byte LDS rows),
 // contracted with the block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 at unit block scales (2x the bf16 MFMA rate at half the operand
 // bytes); the per-row scale of A (p.ln_rstd) and per-row scale of B (p.ln_colsum) are applied in the epilogue.
-template <int EPI, bool LN, bool AUX, bool SLAB, bool F8 = false>
+template <int EPI, bool LN, bool AUX, bool SLAB, bool F8 = false, int SPLIT = 0>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
+    static_assert(SPLIT == 0 || (EPI == EPI_RESID_F32 && LN && !F8), "the split stream belongs to the folded-LayerNorm residual epilogue");
     static_assert(SLAB || EPI != EPI_RESID_F32, "the fp32 residual epilogue exists in the slab form only (whole-line traffic)");
     static_assert(!F8 || (!LN && !AUX && (EPI == EPI_BF16 || EPI == EPI_RESID_F32)), "fp8 operands: bf16 and fp32-residual outputs");
     constexpr int ES = F8 ? 1 : 2;               // operand element size in bytes
@@ -667,7 +692,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             char* const slab = wave < 4 ? smem + (curA == 0 ? 2 : curA - 1) * A_BYTES + wave * 8192 : b_ring + (gpar ^ 1) * B_BYTES + (wave - 4) * 8192;
             load_epi_ops(lane_e);
             if constexpr (RES) {
-                epi_resid_slab<LN, AUX, CP, F8>(p, acc, lane_e, row0, colw, tn, wn, eo, slab);
+                epi_resid_slab<LN, AUX, CP, F8, SPLIT>(p, acc, lane_e, row0, colw, tn, wn, eo, slab);
             } else {
                 if constexpr (SWI) epi_swiglu_slab<LN, AUX, CP>(p, acc, lane_e, row0, tn, wn, eo, slab);
                 else epi_bf16_slab<epi_act(EPI), LN, CP>(p, acc, lane_e, row0, colw, eo, slab);
@@ -698,6 +723,17 @@ template <int EPI, bool LN, bool AUX>
 int launch_stream_t(const GemmArgs& a, unsigned grid, hipStream_t stream) {
     if constexpr (EPI == EPI_RESID_F32) return launch_stream_v<EPI, LN, AUX, true>(a, grid, stream);
     else return (a.dbg & 1) ? launch_stream_v<EPI, LN, AUX, true>(a, grid, stream) : launch_stream_v<EPI, LN, AUX, false>(a, grid, stream);
+}
+
+template <bool AUX, int SPLIT>
+int launch_stream_split(const GemmArgs& a, unsigned grid, hipStream_t stream) {
+    constexpr size_t lds = 160 * 1024;
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI_RESID_F32, true, AUX, true, false, SPLIT>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL((gemm_stream_kernel<EPI_RESID_F32, true, AUX, true, false, SPLIT>), dim3(grid), dim3(512), lds, stream, a);
+    CS_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int EPI>
@@ -761,6 +797,43 @@ int cs_gemm_stream_launch(GemmArgs a, int epi, int reserve, hipStream_t stream) 
     }
     if (epi == EPI_BF16) return launch_stream_bf16<EPI_BF16>(a, grid, stream);
     return launch_stream_bf16<EPI_QGELU_BF16>(a, grid, stream);
+}
+
+// C ABI: the folded-LayerNorm residual GEMM (cs_gemm_nt_ln epilogue 6) on the split stream -- see include/clipself_hip.h.
+//   x_in != NULL: the stream is read as fp32 [M, ldc];  NULL: as the planes (hi, lo)
+//   x_out != NULL: it is written as fp32 [M, ldc] (stats_part optional: no bf16 copy is made, hi is only read);  NULL: as (hi, lo), with
+//   stats_part required (the consumer of a split stream is a folded GEMM, which needs the row statistics).
+extern "C" int cs_gemm_nt_ln_split(const void* A, const void* B, const float* bias, const float* ln_mean, const float* ln_rstd,
+                                   const float* ln_colsum, const float* x_in, float* x_out, void* hi, void* lo, int ldxb, float* stats_part,
+                                   int M, int N, int K, int lda, int ldb, int ldc, int flags, hipStream_t stream) {
+    CS_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 32 == 0, "cs_gemm_nt_ln_split: M=%d N=%d (%% 32) K=%d (%% 64)", M, N, K);
+    CS_CHECK_ARG((lda % 8) == 0 && (ldb % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "cs_gemm_nt_ln_split: operands must be 16-byte aligned rows");
+    CS_CHECK_ARG(ln_mean && ln_rstd && ln_colsum && bias && ((uintptr_t)ln_colsum % 16) == 0 && ((uintptr_t)bias % 16) == 0,
+                 "cs_gemm_nt_ln_split: mean, rstd, column sums and bias are required (16-byte aligned vectors)");
+    CS_CHECK_ARG(x_in == nullptr || x_out == nullptr, "cs_gemm_nt_ln_split: fp32 in and fp32 out is cs_gemm_nt_ln");
+    CS_CHECK_ARG(hi && lo && ((uintptr_t)hi % 8) == 0 && ((uintptr_t)lo % 8) == 0 && ldxb % 4 == 0 && ldxb >= N, "cs_gemm_nt_ln_split: hi / lo planes: 8-byte aligned, ldxb %% 4 == 0");
+    CS_CHECK_ARG((x_in == nullptr || (((uintptr_t)x_in % 16) == 0 && ldc % 4 == 0)) && (x_out == nullptr || (((uintptr_t)x_out % 16) == 0 && ldc % 4 == 0)),
+                 "cs_gemm_nt_ln_split: the fp32 stream must be 16-byte aligned with ldc %% 4 == 0");
+    CS_CHECK_ARG(x_out != nullptr || stats_part != nullptr, "cs_gemm_nt_ln_split: a stream that leaves split leaves with its row statistics");
+    CS_CHECK_ARG(!(x_in != nullptr && stats_part == nullptr), "cs_gemm_nt_ln_split: fp32 in -> split out needs stats_part");
+    CS_CHECK_ARG((long)ldc * 128 * 4 < 0x70000000L && (long)ldxb * 128 * 2 < 0x70000000L, "cs_gemm_nt_ln_split: row stride too large");
+    GemmArgs a;
+    a.A = (const __bf16*)A; a.B = (const __bf16*)B; a.C = x_out; a.bias = bias; a.extra = x_in;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.group = 0;
+    a.ktiles_per_split = K / BK; a.split_stride = 0; a.gm = 8; a.rm = 0; a.nsplit = 1;
+    a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_colsum = ln_colsum; a.stats_part = stats_part; a.xb_out = (__bf16*)hi; a.ldxb = ldxb;
+    a.lo = (unsigned short*)lo;
+    a.split = (x_in == nullptr ? 1 : 0) | (x_out == nullptr ? 2 : 0);
+    a.reserve = (flags >> 20) & 127;
+    a.dbg = (flags >> 12) & 15;
+    a.tiles_m = (M + 255) / 256;
+    a.tiles_n = (N + 255) / 256;
+    const long ntiles = (long)a.tiles_m * a.tiles_n;
+    const long cap = 256 - (a.reserve > 0 && a.reserve < 200 ? a.reserve : 0);
+    const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
+    if (a.split == 3) return launch_stream_split<true, 3>(a, grid, stream);
+    if (a.split == 2) return launch_stream_split<true, 2>(a, grid, stream);
+    return stats_part ? launch_stream_split<true, 1>(a, grid, stream) : launch_stream_split<false, 1>(a, grid, stream);
 }
 
 // C ABI: fp8 (OCP e4m3) operands quantised row-wise by cs_quant_rows_fp8 -- BASELINE configs[4] "fp8 MFMA weights".

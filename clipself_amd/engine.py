@@ -147,6 +147,9 @@ class EvaEngine:
         # ... and, in encode_image(), the block LayerNorms norm1 / norm2 as well: the residual GEMMs also emit a bf16 copy of the new
         # stream and its row statistics, the q|k|v and W1|W2 GEMMs apply the normalisation in their epilogues (_teacher_block_folded)
         self.fold_block_ln = not trainable
+        # ... with the residual stream between those GEMMs held as two 16-bit planes (bf16 view + remainder, exact; cs_gemm_nt_ln_split):
+        # 8 instead of 10 bytes of HBM traffic per stream element and residual GEMM
+        self.split_stream = not trainable
         self.fold = {}
         # BASELINE configs[4] "fp8 MFMA weights": the forward linears of the non-folded (training / dense) schedule run on e4m3 operands --
         # weight shadows quantised per output row (refreshed after every AdamW step), activations per token row by cs_quant_rows_fp8,
@@ -464,17 +467,19 @@ class EvaEngine:
         ops.gemm_nt_ln(hid, W3, x, bias=d3, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=c3, epi=EPI_RESID_LN_F32)
         return x
 
-    def _teacher_block_folded(self, i, x, xb, st, B, N, cos, sin, emit_next):
+    def _teacher_block_folded(self, i, x, xb, st, B, N, cos, sin, emit_next, lo=None):
         """One frozen-tower block with all four LayerNorms folded into the GEMMs (in place on x).  xb / st = bf16 copy and (mean, rstd)
         of x for norm1 as left by the previous block's w3 GEMM, or None (first block: plain norm1 kernel).  Returns (xb, st) for the
-        next block when emit_next."""
+        next block when emit_next.  With lo (int16 [M, C]) the stream lives in the planes (xb, lo) between the first residual GEMM of the
+        tower, which reads fp32 x, and the last one (emit_next False), which writes fp32 x again (cs_gemm_nt_ln_split)."""
         ops, cfg = self.ops, self.cfg
         C, Hd, Hl, H, eps = cfg.width, self.Hp, cfg.hidden, cfg.heads, cfg.ln_eps
         b = f"{self.prefix}blocks.{i}."
         M = B * N
         f = self.fold[i]
         qkv = ops.empty((M, 3 * C), BF16)
-        if xb is None:
+        first = xb is None
+        if first:
             ln1 = ops.empty((M, C), BF16)
             ops.layernorm_fwd(x, self.p[b + "norm1.weight"], self.p[b + "norm1.bias"], ln1, None, None, eps)
             wqkv, bqkv = self._qkv_w(b)
@@ -489,9 +494,12 @@ class EvaEngine:
         ops.ln_stats_finalize(part_a, 64, C, mean, rstd, eps)
         Wp, cp, dp = f["proj"]
         part_x = ops.empty(((C + 63) // 64, M, 2), F32)
-        xb2 = ops.empty((M, C), BF16)
-        ops.gemm_nt_ln(att, Wp, x, bias=dp, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=cp, stats_part=part_x, xb_out=xb2,
-                       epi=EPI_RESID_LN_F32)
+        xb2 = xb if (lo is not None and not first) else ops.empty((M, C), BF16)
+        if lo is not None:
+            ops.gemm_nt_ln_split(att, Wp, xb2, lo, dp, mean, rstd, cp, x_in=x if first else None, stats_part=part_x)
+        else:
+            ops.gemm_nt_ln(att, Wp, x, bias=dp, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=cp, stats_part=part_x, xb_out=xb2,
+                           epi=EPI_RESID_LN_F32)
         mean2, rstd2 = ops.empty((M,), F32), ops.empty((M,), F32)
         ops.ln_stats_finalize(part_x, 64, C, mean2, rstd2, eps)
         W12, c12, d12 = f["w12"]
@@ -501,11 +509,17 @@ class EvaEngine:
                        group=Hd)
         ops.ln_stats_finalize(part_h, 32, Hl, mean, rstd, eps)
         W3, c3, d3 = f["w3"]
-        if not emit_next:
-            ops.gemm_nt_ln(hid, W3, x, bias=d3, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=c3, epi=EPI_RESID_LN_F32)
-            return None, None
-        ops.gemm_nt_ln(hid, W3, x, bias=d3, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=c3, stats_part=part_x, xb_out=xb2,
-                       epi=EPI_RESID_LN_F32)
+        if lo is not None:
+            if not emit_next:
+                ops.gemm_nt_ln_split(hid, W3, xb2, lo, d3, mean, rstd, c3, x_out=x)
+                return None, None
+            ops.gemm_nt_ln_split(hid, W3, xb2, lo, d3, mean, rstd, c3, stats_part=part_x)
+        else:
+            if not emit_next:
+                ops.gemm_nt_ln(hid, W3, x, bias=d3, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=c3, epi=EPI_RESID_LN_F32)
+                return None, None
+            ops.gemm_nt_ln(hid, W3, x, bias=d3, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=c3, stats_part=part_x, xb_out=xb2,
+                           epi=EPI_RESID_LN_F32)
         ops.ln_stats_finalize(part_x, 64, C, mean2, rstd2, eps)
         return xb2, (mean2, rstd2)
 
@@ -545,9 +559,11 @@ class EvaEngine:
             xf = x.view(B * N, cfg.width)
             last = cfg.layers - 1 if self.cls_only_last_block else cfg.layers
             xb = st = None
+            folded = self.fold_sub_ln and self.fold_block_ln
+            lo = ops.empty((B * N, cfg.width), torch.int16) if folded and self.split_stream and last > 0 else None
             for i in range(last):
-                if self.fold_sub_ln and self.fold_block_ln:
-                    xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last)
+                if folded:
+                    xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last, lo=lo)
                 else:
                     self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
             xc = self._block_fwd_cls(last, xf, B, N, cos, sin) if last < cfg.layers else x[:, 0, :]

@@ -35,6 +35,7 @@ SIGNATURES = {
     "cs_gemm_wgrad_tn_workspace": (_sz, [_i, _i, _i]),
     "cs_gemm_wgrad_tn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_gemm_nt_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "cs_gemm_nt_ln_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_ln_stats_finalize": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "cs_attn_fwd_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_layernorm_fwd": (_i, [_vp, _i, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _vp]),
@@ -175,6 +176,21 @@ class HipOps:
         self._ok(self.lib.cs_gemm_nt_ln(_p(A), _p(B), _p(C), _p(bias), _p(extra), _p(ln_mean), _p(ln_rstd), _p(ln_colsum), _p(stats_part),
                                         _p(xb_out), xb_out.stride(0) if xb_out is not None else 0, M, N, K, A.stride(0), B.stride(0),
                                         C.stride(0), epi, 1, group, flags | self.gemm_flags, self._stream()), "cs_gemm_nt_ln")
+
+    def gemm_nt_ln_split(self, A, B, hi, lo, bias, ln_mean, ln_rstd, ln_colsum, x_in=None, x_out=None, stats_part=None, flags=0):
+        """Folded-LayerNorm residual GEMM on the split stream (cs_gemm_nt_ln_split): x += rstd * (A.B^T - mean * colsum) + bias with x held as
+        the 16-bit planes hi (bf16 view of x, the next folded GEMM's operand) and lo (int16) -- or read from x_in / written to x_out (fp32)
+        at the two ends of the tower."""
+        self._chk(A, B, hi, lo, bias, ln_mean, ln_rstd, ln_colsum, x_in, x_out, stats_part)
+        M, K = A.shape
+        N = B.shape[0]
+        assert hi.dtype == torch.bfloat16 and lo.dtype == torch.int16 and hi.shape == (M, N) and lo.shape == (M, N)
+        assert hi.stride(1) == 1 and lo.stride(1) == 1 and hi.stride(0) == lo.stride(0)
+        x = x_in if x_in is not None else x_out
+        assert x is None or (x.dtype == torch.float32 and x.shape == (M, N) and x.stride(1) == 1)
+        self._ok(self.lib.cs_gemm_nt_ln_split(_p(A), _p(B), _p(bias), _p(ln_mean), _p(ln_rstd), _p(ln_colsum), _p(x_in), _p(x_out), _p(hi), _p(lo),
+                                              hi.stride(0), _p(stats_part), M, N, K, A.stride(0), B.stride(0), x.stride(0) if x is not None else N,
+                                              flags | self.gemm_flags, self._stream()), "cs_gemm_nt_ln_split")
 
     def quant_rows_fp8(self, x, q, scale):
         """bf16 [M,K] -> e4m3 bytes q [M,Kp] (uint8 / float8 storage, Kp = K rounded up to 128, padding zeroed) + fp32 row scales [M]."""

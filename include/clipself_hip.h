@@ -75,6 +75,20 @@ int cs_gemm_nt_ln(const void* A, const void* B, void* C, const float* bias, cons
                   const float* ln_rstd, const float* ln_colsum, float* stats_part, void* xb_out, int ldxb, int M, int N, int K, int lda,
                   int ldb, int ldc, int epi, int splits, int group, int flags, cs_stream_t stream);
 
+/* Epilogue 6 of cs_gemm_nt_ln on the "split stream": the frozen tower's fp32 residual stream x (Block.forward, eva_vit_model.py:306-307:
+ * x = x + attn(norm1(x)); x = x + mlp(norm2(x))) kept as two 16-bit planes of the word y = bits(x) + 0x8000:
+ *   hi[m, n] = y >> 16     -- x rounded to bf16 (halves away from zero), i.e. the operand the next folded GEMM (norm1 -> q|k|v,
+ *                             norm2 -> w1|w2) reads as A, row stride ldxb elements;
+ *   lo[m, n] = y & 0xffff  -- the rest; x = bits^-1(((hi << 16) | lo) - 0x8000) exactly.
+ * A residual GEMM then moves 8 bytes per stream element (4 in, 4 out) instead of 10 (fp32 in, fp32 out, bf16 copy) and nothing is lost.
+ *   x_in  != NULL: the stream is read as fp32 [M, ldc] (first block, after the stem);  NULL: as (hi, lo)
+ *   x_out != NULL: it is written as fp32 [M, ldc] (last folded block; hi / lo are only read);  NULL: back to (hi, lo), in place
+ *   stats_part: per 64-column slice (sum, sum of squares) of the fp32 outputs as in cs_gemm_nt_ln; required unless x_out != NULL.
+ * out = x + rstd[m] * (A.B^T - mean[m] * ln_colsum[n]) + bias[n];  N % 32 == 0, K % 64 == 0; flags bits 20-26 as cs_gemm_nt. */
+int cs_gemm_nt_ln_split(const void* A, const void* B, const float* bias, const float* ln_mean, const float* ln_rstd,
+                        const float* ln_colsum, const float* x_in, float* x_out, void* hi, void* lo, int ldxb, float* stats_part,
+                        int M, int N, int K, int lda, int ldb, int ldc, int flags, cs_stream_t stream);
+
 /* --- LayerNorm(eps, biased var): src/open_clip/eva_clip/transformer.py:52-58 used at eva_vit_model.py:306-307 (norm1/2),
  *     :218 (inner_attn_ln), :102 (ffn_ln), :565/:616 (final norm); replaces apex FusedLayerNorm / F.layer_norm.
  * x_dtype 0=f32 1=bf16; y bf16 (NULL = statistics only); mean/rstd [M] f32 (nullable when no backward is needed). */

@@ -142,6 +142,36 @@ class RefOps:
                 stats_part[s, :, 0] = blk.sum(-1)
                 stats_part[s, :, 1] = (blk * blk).sum(-1)
 
+    @staticmethod
+    def split_planes(x):
+        """fp32 -> (hi bf16, lo int16): the two halves of y = bits(x) + 0x8000 (include/clipself_hip.h, cs_gemm_nt_ln_split)."""
+        y = x.contiguous().view(torch.int32) + 0x8000
+        hi = (y >> 16).to(torch.int16).view(torch.bfloat16)
+        lo = (y & 0xFFFF).to(torch.int16)                          # wraps to the signed view of the low 16 bits
+        return hi, lo
+
+    @staticmethod
+    def join_planes(hi, lo):
+        y = (hi.contiguous().view(torch.int16).to(torch.int32) << 16) | (lo.to(torch.int32) & 0xFFFF)
+        return (y - 0x8000).view(torch.float32)
+
+    def gemm_nt_ln_split(self, A, B, hi, lo, bias, ln_mean, ln_rstd, ln_colsum, x_in=None, x_out=None, stats_part=None, flags=0):
+        assert x_in is None or x_out is None
+        acc = A.float() @ B.float().T
+        acc = ln_rstd[:, None] * (acc - ln_mean[:, None] * ln_colsum[None, :]) + bias
+        o = (x_in if x_in is not None else self.join_planes(hi, lo)) + acc
+        if x_out is not None:
+            x_out.copy_(o)
+        else:
+            h, l = self.split_planes(o)
+            hi.copy_(h)
+            lo.copy_(l)
+        if stats_part is not None:
+            for s in range((o.shape[1] + 63) // 64):
+                blk = o[:, 64 * s:64 * s + 64]
+                stats_part[s, :, 0] = blk.sum(-1)
+                stats_part[s, :, 1] = (blk * blk).sum(-1)
+
     def crop_resize(self, image_u8, boxes, size, pad_center=True, mean=None, std=None, out=None):
         """cs_crop_resize_u8 through Pillow itself (oracle/pil_crops_ref.py)."""
         from .pil_crops_ref import OPENAI_MEAN, OPENAI_STD, pil_crops

@@ -770,3 +770,44 @@ def test_gemm_wgrad_token_major_operands(hip, ref, N, K, T):
     hip.gemm_wgrad_tn(wide.cuda()[:, 256:], X.cuda(), got2, ws)
     check(f"gemm_wgrad_tn_strided[{N},{K},{T}]", got2, wide[:, 256:].float().T @ X.float(), 2e-5)
     assert hip.gemm_wgrad_tn_workspace(N, K, T + 32) == 0 and hip.gemm_wgrad_tn_workspace(N + 64, K, T) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (2 * 197 * 7, 768, 2048), (300, 64, 64), (50432, 1024, 1024)])
+def test_split_stream_residual_gemm_is_the_fp32_one_bit_for_bit(hip, ref, M, N, K):
+    """cs_gemm_nt_ln_split: the residual stream as two 16-bit planes of bits(x) + 0x8000.  All three forms (fp32 in -> planes out, planes
+    in -> planes out, planes in -> fp32 out) must reproduce the fp32 stream of cs_gemm_nt_ln (epilogue 6) bit for bit, statistics included;
+    the hi plane is the bf16 operand of the next folded GEMM and equals the RNE copy except on exact ties; against the fp32 reference."""
+    A = rnd((M, K), BF, seed=1).cuda()
+    B = rnd((N, K), BF, 0.05, seed=2).cuda()
+    bias, colsum = rnd((N,), seed=3).cuda(), rnd((N,), seed=4).cuda()
+    mean, rstd = rnd((M,), seed=5, scale=0.1).cuda(), (rnd((M,), seed=6).abs() + 0.5).cuda()
+    x0 = rnd((M, N), seed=7, scale=3.0).cuda()
+    S = (N + 63) // 64
+
+    def fp32_form(x_in, stats=True):
+        x = x_in.clone()
+        part = torch.zeros(S, M, 2, device="cuda") if stats else None
+        xb = torch.zeros(M, N, dtype=BF, device="cuda") if stats else None
+        hip.gemm_nt_ln(A, B, x, bias=bias, extra=x, ln_mean=mean, ln_rstd=rstd, ln_colsum=colsum, stats_part=part, xb_out=xb, epi=6, flags=0xB0)
+        return x, part, xb
+
+    x1, part1, xb1 = fp32_form(x0)
+    x2, part2, _ = fp32_form(x1)
+    x3, _, _ = fp32_form(x2, stats=False)
+    hi = torch.zeros(M, N, dtype=BF, device="cuda")
+    lo = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+    p1, p2 = torch.zeros(S, M, 2, device="cuda"), torch.zeros(S, M, 2, device="cuda")
+    hip.gemm_nt_ln_split(A, B, hi, lo, bias, mean, rstd, colsum, x_in=x0, stats_part=p1)
+    assert torch.equal(RefOps.join_planes(hi, lo).view(torch.int32), x1.view(torch.int32)) and torch.equal(p1, part1)
+    ties = int((hi != xb1).sum())
+    assert ties <= max(4, M * N // 10000) and float((hi.float() - x1).abs().max()) <= float((xb1.float() - x1).abs().max()) * 1.0001
+    hip.gemm_nt_ln_split(A, B, hi, lo, bias, mean, rstd, colsum, stats_part=p2)
+    assert torch.equal(RefOps.join_planes(hi, lo).view(torch.int32), x2.view(torch.int32)) and torch.equal(p2, part2)
+    out = torch.zeros(M, N, device="cuda")
+    hip.gemm_nt_ln_split(A, B, hi, lo, bias, mean, rstd, colsum, x_out=out)
+    assert torch.equal(out.view(torch.int32), x3.view(torch.int32))
+    want = x0.cpu()
+    acc = rstd.cpu()[:, None] * (A.cpu().float() @ B.cpu().float().T - mean.cpu()[:, None] * colsum.cpu()[None, :]) + bias.cpu()
+    with open(_LOG, "a") as f:
+        f.write(f"split stream M={M} N={N} K={K}: bit-equal to the fp32 stream in all three forms; hi plane differs from the RNE copy at {ties} ties\n")
+    check("split stream vs reference", x1.cpu(), want + acc, 2e-3)
