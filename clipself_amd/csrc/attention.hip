@@ -67,6 +67,34 @@ __device__ __forceinline__ void load_rope_tables(float* rt, const float* __restr
     }
 }
 
+// The same in two halves, so that the table reads are the OLDEST loads of the wave (vmcnt retires in order: waiting for them then does
+// not wait for the K / V / Q rows issued behind them) -- g * 32 <= 2 * NT entries per table.
+struct RopeRegs { float v[2][4]; };
+template <int NT>
+__device__ __forceinline__ void fetch_rope_tables(RopeRegs& t, const float* __restrict__ cos_t, const float* __restrict__ sin_t, int g, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = min(tid + it * NT, g * 32 - 1), r = i >> 5, d = i & 31;
+        t.v[it][0] = cos_t[(size_t)(r * g) * HD + d];
+        t.v[it][1] = sin_t[(size_t)(r * g) * HD + d];
+        t.v[it][2] = cos_t[(size_t)r * HD + 32 + d];
+        t.v[it][3] = sin_t[(size_t)r * HD + 32 + d];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void commit_rope_tables(const RopeRegs& t, float* rt, int g, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = tid + it * NT;
+        if (i < g * 32) {
+            rt[i] = t.v[it][0];
+            rt[(g << 5) + i] = t.v[it][1];
+            rt[(2 * g << 5) + i] = t.v[it][2];
+            rt[(3 * g << 5) + i] = t.v[it][3];
+        }
+    }
+}
+
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int c2) {
     bf16x8 r;
 #pragma unroll
@@ -92,6 +120,7 @@ struct AttnArgs {
     const float* sin_t;
     const float* lse_in;   // bwd: [B*H, N]
     const float* dsum;     // bwd: rowsum(dO*O) [B*H, N]
+    int prefetch;          // fwd: units ahead whose q/k/v lines this workgroup pulls into the memory-side cache (0 = off), see attn_fwd_kernel
     int dbg;               // timing ablations (env CS_ATTN_DBG, results wrong): 1 = no MFMA/softmax phase, 2 = no RoPE, 4 = no output stores
     int grid;              // fwd: token grid side g (Ntok = g*g + 1)
     float inv_grid;
@@ -145,9 +174,8 @@ __device__ __forceinline__ void stage_k(const __bf16* __restrict__ src, size_t r
     U128 v[ITEMS];
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {                      // all loads in flight before the first use
-        const int idx = tid + it * NT, tok = tok0 + (idx >> 3);
-        if (idx < CHK * 8 && tok < Ntok) v[it].u = *(const uint4*)(src + (rowbase + tok) * ld + coloff + (idx & 7) * 8);
-        else v[it].u = make_uint4(0, 0, 0, 0);
+        const int idx = min(tid + it * NT, CHK * 8 - 1), tok = min(tok0 + (idx >> 3), Ntok - 1);   // branch-free: padding rows repeat the last row
+        v[it].u = *(const uint4*)(src + (rowbase + tok) * ld + coloff + (idx & 7) * 8);
     }
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
@@ -167,9 +195,8 @@ __device__ __forceinline__ void stage_vt(const __bf16* __restrict__ src, size_t 
         U128 in[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int tok = tok0 + kb * 8 + i;
-            if (tok < Ntok) in[i].u = *(const uint4*)(src + (rowbase + tok) * ld + coloff + c * 8);
-            else in[i].u = make_uint4(0, 0, 0, 0);
+            const int tok = min(tok0 + kb * 8 + i, Ntok - 1);        // branch-free (see attn_fwd_kernel): padding keys carry p = 0
+            in[i].u = *(const uint4*)(src + (rowbase + tok) * ld + coloff + c * 8);
         }
         const int pos = (kb ^ c) * 8;                        // (d>>3)&7 == c for d = c*8 + j
 #pragma unroll
@@ -341,20 +368,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
         // the first dependent instruction; V's flight time then hides behind K's RoPE work, Q's behind the whole staging.
         constexpr int KI = (CHK * 8 + NT - 1) / NT;
         U128 kr[KI], vin[8], qraw[QTW][4];
+        RopeRegs tabs;
+        fetch_rope_tables<NT>(tabs, p.cos_t, p.sin_t, p.grid, tid);
+        __builtin_amdgcn_sched_barrier(0);                     // all eight table loads ahead of the K / V / Q rows
         const __bf16* kbase = p.qkv + C + h * HD;
         const __bf16* vbase = p.qkv + 2 * C + h * HD;
+        // Branch-free: rows past the sequence re-read its last row (finite; their scores are masked to -inf, so p = 0 exactly and neither
+        // K nor V of a padding key reaches the result).  Predicated loads made hipcc wrap every V load in its own exec-masked block with
+        // an `s_waitcnt vmcnt(0)` behind it -- eight serial HBM round trips per workgroup.
+        const int last = p.Ntok - 1;
 #pragma unroll
         for (int it = 0; it < KI; ++it) {
-            const int idx = tid + it * NT, tok = idx >> 3;
-            if (idx < CHK * 8 && tok < p.Ntok) kr[it].u = *(const uint4*)(kbase + (rowbase + tok) * p.ldqkv + (idx & 7) * 8);
-            else kr[it].u = make_uint4(0, 0, 0, 0);
+            const int idx = min(tid + it * NT, CHK * 8 - 1), tok = min(idx >> 3, last);
+            kr[it].u = *(const uint4*)(kbase + (rowbase + tok) * p.ldqkv + (idx & 7) * 8);
         }
         const int vkb = tid >> 3, vc = tid & 7;                // one (key block, dim chunk) item per thread (CHK <= NT)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int tok = vkb * 8 + i;
-            if (tid < CHK && tok < p.Ntok) vin[i].u = *(const uint4*)(vbase + (rowbase + tok) * p.ldqkv + vc * 8);
-            else vin[i].u = make_uint4(0, 0, 0, 0);
+            const int tok = min(vkb * 8 + i, last);
+            vin[i].u = *(const uint4*)(vbase + (rowbase + tok) * p.ldqkv + vc * 8);
         }
         int qcs[QTW];
 #pragma unroll
@@ -364,7 +396,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
             for (int ks = 0; ks < 4; ++ks)
                 qraw[j][ks].u = *(const uint4*)(p.qkv + (rowbase + qcs[j]) * p.ldqkv + h * HD + ks * 16 + hf * 8);
         }
-        load_rope_tables<NT>(rt, p.cos_t, p.sin_t, p.grid, tid);
+        commit_rope_tables<NT>(tabs, rt, p.grid, tid);
         __syncthreads();
         // K: rotate + swizzled LDS image
 #pragma unroll
@@ -387,6 +419,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
             }
         }
         __syncthreads();
+        // Workgroups of one round load together and compute together (the load phase is chip-wide HBM-bound, which keeps them in step), so
+        // HBM idles through every compute phase.  Each workgroup therefore also touches the 3 x Ntok 128-byte lines of the unit a later
+        // round will process (p.prefetch units ahead): issued here, behind its own loads, and not waited for before the end of the kernel,
+        // they stream in from HBM during the softmax / MFMA phase and leave that unit in the memory-side cache.  The three destination
+        // registers stay reserved until the final wait (the asm statements at the end), because the data lands in them whenever it lands.
+        unsigned pf0 = 0, pf1 = 0, pf2 = 0;
+        const bool do_pf = p.prefetch > 0 && bh + p.prefetch < (int)gridDim.y && tid < p.Ntok;
+        if (do_pf) {
+            const int bh2 = bh + p.prefetch, b2 = bh2 / p.H, h2 = bh2 - b2 * p.H;
+            const __bf16* t = p.qkv + ((size_t)b2 * p.Ntok + tid) * p.ldqkv + h2 * HD;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pf0) : "v"(t) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pf1) : "v"(t + C) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pf2) : "v"(t + 2 * C) : "memory");
+        }
 #pragma unroll
         for (int j = 0; j < QTW; ++j) {
             const int q0 = q_wg + (wave + j * NW) * 32;
@@ -404,6 +450,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
                 else { l = 1.f; m = 0.f; o[0][0] = bf2f(qf[0][0]); }
                 if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
             }
+        }
+        if (p.prefetch > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2));
         }
     }
 }
@@ -728,6 +778,8 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
     a.grid = g; a.inv_grid = 1.f / (float)g;
     static const int dbg_env = getenv("CS_ATTN_DBG") ? atoi(getenv("CS_ATTN_DBG")) : 0;
     a.dbg = dbg_env;
+    static const int pf_env = getenv("CS_ATTN_PF") ? atoi(getenv("CS_ATTN_PF")) : 0;
+    a.prefetch = pf_env;
     a.Ntok = Ntok; a.H = H; a.ldqkv = ldqkv; a.ldo = ldo; a.scale = scale;
     constexpr int CH = 7;
     static const size_t lds_pad = getenv("CS_ATTN_LDSPAD") ? (size_t)atoi(getenv("CS_ATTN_LDSPAD")) : 0;     // occupancy experiments

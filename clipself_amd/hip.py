@@ -8,13 +8,14 @@ There is NO fallback: if the library is missing or a tensor is not on the GPU th
 from __future__ import annotations
 
 import ctypes
+import os
 import subprocess
 from pathlib import Path
 
 import torch
 
 _CSRC = Path(__file__).resolve().parent / "csrc"
-_LIB_PATH = _CSRC / "libclipself_hip.so"
+_LIB_PATH = Path(os.environ["CLIPSELF_HIP_LIB"]) if os.environ.get("CLIPSELF_HIP_LIB") else _CSRC / "libclipself_hip.so"   # override: A/B of two builds
 
 EPI_BF16, EPI_F32, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_ATOMIC_F32, EPI_PATCH_F32, EPI_RESID_LN_F32, EPI_GELU_BF16, EPI_QGELU_BF16 = range(9)
 DX_BF16, DX_F32_ASSIGN, DX_F32_ACCUM = range(3)

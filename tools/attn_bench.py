@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """GPU micro-benchmark of cs_attn_fwd on the teacher's shape (512 crops x 12 heads x 197 tokens); see profiles/r01_n_*.
-env: CS_ATTN_DBG (ablation bits), CS_ATTN_LDSPAD, CS_ATTN_DEBUG."""
+env: CS_ATTN_DBG (ablation bits), CS_ATTN_LDSPAD, CS_ATTN_DEBUG, CS_ATTN_PF (prefetch distance in units).   usage: python tools/attn_bench.py [crops]"""
 import sys, torch
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from clipself_amd.hip import HipOps
 ops = HipOps()
-B, N, H = 512, 197, 12
+B, N, H = (int(sys.argv[1]) if len(sys.argv) > 1 else 512), 197, 12
 C = H * 64
 qkv = torch.randn(B * N, 3 * C, device="cuda").to(torch.bfloat16)
 g = 14                                                   # separable tables as rope.py:118-142 builds them
