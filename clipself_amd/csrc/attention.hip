@@ -120,7 +120,6 @@ struct AttnArgs {
     const float* sin_t;
     const float* lse_in;   // bwd: [B*H, N]
     const float* dsum;     // bwd: rowsum(dO*O) [B*H, N]
-    int prefetch;          // fwd: units ahead whose q/k/v lines this workgroup pulls into the memory-side cache (0 = off), see attn_fwd_kernel
     int dbg;               // timing ablations (env CS_ATTN_DBG, results wrong): 1 = no MFMA/softmax phase, 2 = no RoPE, 4 = no output stores
     int grid;              // fwd: token grid side g (Ntok = g*g + 1)
     float inv_grid;
@@ -237,12 +236,16 @@ __device__ __forceinline__ void load_q_frags(const AttnArgs& p, const float* rt,
 }
 
 // one key chunk against one 32-query tile: S^T = K Q^T, online-softmax update of (m, l), O^T += V^T P^T
-template <int CH>
+template <int CH, bool TAIL>
 __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, const bf16x8 (&qf)[4], int key0, int Ntok, float sl2,
                                              int lane, bool first, float& m, float& l, f32x16 (&o)[2]) {
     const int hf = lane >> 5, l31 = lane & 31;
     // fragment addressing (row = t*32 + l31): LDS row (row>>1), slot ((row&1)*8 | chunk) ^ ((row>>1)&15)
     const int k_base = (l31 >> 1) << 8, par8 = (l31 & 1) << 3, sw = l31 >> 1;
+    // Key tile t holds keys key0 + 32t ..; only the last tile of a sequence is ragged.  TAIL: the caller guarantees that tiles 0..CH-2
+    // are full (single-chunk launches with Ntok > 32(CH-1)), so the ragged-tile code exists once.  For the 14x14(+CLS) grid the last tile
+    // holds 5 keys: rows 0..7 of a 32x32 accumulator tile are registers 0..3 of the two wave halves, so a tile with <= 8 keys needs 4 of
+    // its 16 registers in the softmax (the other 12 are p = 0 by construction) and one of its two P.V steps.
     f32x16 s[CH];
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
@@ -253,10 +256,20 @@ __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, c
             s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], s[t], 0, 0, 0);
         }
     }
+    const int rem_last = Ntok - key0 - (CH - 1) * 32;          // keys in the last tile (TAIL: 1..32)
+    const bool short_tail = TAIL && rem_last <= 8;
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < CH; ++t) {
-        if (key0 + t * 32 + 32 > Ntok) {                     // wave-uniform: only the ragged last key tile needs masking
+        if (TAIL && t == CH - 1 && short_tail) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e + 4 * hf >= rem_last) s[t][e] = -INFINITY;
+                mx = fmaxf(mx, s[t][e]);
+            }
+            continue;
+        }
+        if ((!TAIL || t == CH - 1) && key0 + t * 32 + 32 > Ntok) {   // wave-uniform: only a ragged key tile needs masking
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 if (key0 + t * 32 + mfma32_row(e, lane) >= Ntok) s[t][e] = -INFINITY;
@@ -270,13 +283,25 @@ __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, c
     const float msc = m_new * sl2;
     float rs = 0.f;
 #pragma unroll
-    for (int t = 0; t < CH; ++t)
+    for (int t = 0; t < CH; ++t) {
+        if (TAIL && t == CH - 1 && short_tail) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(s[t][e] * sl2 - msc);
+                s[t][e] = pv;
+                rs += pv;
+            }
+#pragma unroll
+            for (int e = 4; e < 8; ++e) s[t][e] = 0.f;          // registers 4..7 complete the one P.V step taken below
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const float pv = __builtin_amdgcn_exp2f(s[t][e] * sl2 - msc);     // raw v_exp_f32: argument <= 0, result in [0,1]
             s[t][e] = pv;
             rs += pv;
         }
+    }
     rs += __shfl_xor(rs, 32, 64);
     l = l * alpha + rs;
     m = m_new;
@@ -288,6 +313,7 @@ __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, c
     for (int t = 0; t < CH; ++t)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
+            if (TAIL && t == CH - 1 && c2 == 1 && rem_last <= 16) continue;     // all 16 keys of this step are padding (p = 0)
             const bf16x8 pb = pack8_swapped(s[t], c2);
             const int kb = t * 4 + c2 * 2 + hf;              // key block (8 keys) this half supplies
 #pragma unroll
@@ -330,7 +356,7 @@ __device__ __forceinline__ void store_o(const AttnArgs& p, size_t rowbase, int q
 // NW waves per workgroup, QTW 32-query tiles per wave (tile = wave + j*NW).  QTW > 1 requires the whole sequence in one key
 // chunk (Ntok <= CH*32: no state is carried between chunks); it lets 4-wave workgroups stage K/V once for up to 256
 // queries while two workgroups share a CU, so one workgroup's K/V staging overlaps the other's MFMA/softmax phase.
-template <int CH, int NW, int QTW>
+template <int CH, int NW, int QTW, bool TAIL = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
     constexpr int CHK = CH * 32, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -359,13 +385,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
             stage_k<CHK, NT>(p.qkv, rowbase, p.ldqkv, C + h * HD, key0, p.Ntok, rt, p.grid, p.inv_grid, Kl, tid);
             stage_vt<CHK, NT>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0, p.Ntok, Vt, tid);
             __syncthreads();
-            if (active) attend_chunk<CH>(Kl, Vt, qf, key0, p.Ntok, sl2, lane, key0 == 0, m, l, o);
+            if (active) attend_chunk<CH, false>(Kl, Vt, qf, key0, p.Ntok, sl2, lane, key0 == 0, m, l, o);
         }
         if (active && q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
     } else {
         // The kernel is latency-bound (profile: 64 % of wave cycles parked at s_waitcnt/s_barrier), so every global load
         // of the workgroup -- K rows, the V block, and the Q fragments of BOTH query tiles of this wave -- is issued before
         // the first dependent instruction; V's flight time then hides behind K's RoPE work, Q's behind the whole staging.
+        // 7 query tiles over 4 waves leave one wave (one SIMD) with a single tile: which one rotates with the unit index, so that over
+        // the units a CU processes every SIMD carries 7/4 tiles per unit instead of SIMDs 0..2 carrying 2
+        const int wrot = (wave + bh) & (NW - 1);
         constexpr int KI = (CHK * 8 + NT - 1) / NT;
         U128 kr[KI], vin[8], qraw[QTW][4];
         RopeRegs tabs;
@@ -391,7 +420,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
         int qcs[QTW];
 #pragma unroll
         for (int j = 0; j < QTW; ++j) {
-            qcs[j] = min(q_wg + (wave + j * NW) * 32 + l31, p.Ntok - 1);
+            qcs[j] = min(q_wg + (wrot + j * NW) * 32 + l31, p.Ntok - 1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 qraw[j][ks].u = *(const uint4*)(p.qkv + (rowbase + qcs[j]) * p.ldqkv + h * HD + ks * 16 + hf * 8);
@@ -419,23 +448,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
             }
         }
         __syncthreads();
-        // Workgroups of one round load together and compute together (the load phase is chip-wide HBM-bound, which keeps them in step), so
-        // HBM idles through every compute phase.  Each workgroup therefore also touches the 3 x Ntok 128-byte lines of the unit a later
-        // round will process (p.prefetch units ahead): issued here, behind its own loads, and not waited for before the end of the kernel,
-        // they stream in from HBM during the softmax / MFMA phase and leave that unit in the memory-side cache.  The three destination
-        // registers stay reserved until the final wait (the asm statements at the end), because the data lands in them whenever it lands.
-        unsigned pf0 = 0, pf1 = 0, pf2 = 0;
-        const bool do_pf = p.prefetch > 0 && bh + p.prefetch < (int)gridDim.y && tid < p.Ntok;
-        if (do_pf) {
-            const int bh2 = bh + p.prefetch, b2 = bh2 / p.H, h2 = bh2 - b2 * p.H;
-            const __bf16* t = p.qkv + ((size_t)b2 * p.Ntok + tid) * p.ldqkv + h2 * HD;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(pf0) : "v"(t) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "=v"(pf1) : "v"(t + C) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "=v"(pf2) : "v"(t + 2 * C) : "memory");
-        }
 #pragma unroll
         for (int j = 0; j < QTW; ++j) {
-            const int q0 = q_wg + (wave + j * NW) * 32;
+            const int q0 = q_wg + (wrot + j * NW) * 32;
             if (q0 < p.Ntok) {
                 const int q = q0 + l31, qc = qcs[j];
                 bf16x8 qf[4];
@@ -446,14 +461,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
                 }
                 float m = -INFINITY, l = 0.f;
                 f32x16 o[2] = {zero16(), zero16()};
-                if (!(p.dbg & 1)) attend_chunk<CH>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o);
+                if (!(p.dbg & 1)) attend_chunk<CH, TAIL>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o);
                 else { l = 1.f; m = 0.f; o[0][0] = bf2f(qf[0][0]); }
                 if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
             }
-        }
-        if (p.prefetch > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2));
         }
     }
 }
@@ -778,23 +789,23 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
     a.grid = g; a.inv_grid = 1.f / (float)g;
     static const int dbg_env = getenv("CS_ATTN_DBG") ? atoi(getenv("CS_ATTN_DBG")) : 0;
     a.dbg = dbg_env;
-    static const int pf_env = getenv("CS_ATTN_PF") ? atoi(getenv("CS_ATTN_PF")) : 0;
-    a.prefetch = pf_env;
     a.Ntok = Ntok; a.H = H; a.ldqkv = ldqkv; a.ldo = ldo; a.scale = scale;
     constexpr int CH = 7;
     static const size_t lds_pad = getenv("CS_ATTN_LDSPAD") ? (size_t)atoi(getenv("CS_ATTN_LDSPAD")) : 0;     // occupancy experiments
     const size_t lds = (size_t)CH * 32 * 128 + (size_t)HD * VT_LD * 2 + (size_t)4 * g * 32 * sizeof(float) + lds_pad;
     CS_CHECK_ARG(lds <= 160 * 1024, "cs_attn_fwd: token grid %d too large for the LDS RoPE tables", g);
     if (Ntok <= CH * 32) {
-        // whole sequence in one key chunk: 4-wave workgroups, 2 query tiles per wave, 2 workgroups per CU
-        static bool once = (set_lds(attn_fwd_kernel<CH, 4, 2>, 160 * 1024), true);
+        // whole sequence in one key chunk: 4-wave workgroups, 2 query tiles per wave, 2 workgroups per CU; when only the last key tile is
+        // ragged (Ntok > 32 (CH - 1): the 14x14 grid), the variant whose ragged-tile code exists once
+        static bool once = (set_lds(attn_fwd_kernel<CH, 4, 2, false>, 160 * 1024), set_lds(attn_fwd_kernel<CH, 4, 2, true>, 160 * 1024), true);
         (void)once;
         if (getenv("CS_ATTN_DEBUG")) {
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_fwd_kernel<CH, 4, 2>, 256, lds);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_fwd_kernel<CH, 4, 2, true>, 256, lds);
             fprintf(stderr, "[cs_attn] fwd<7,4,2>: %d resident workgroups per CU (lds %zu)\n", nb, lds);
         }
-        hipLaunchKernelGGL((attn_fwd_kernel<CH, 4, 2>), dim3((Ntok + 255) / 256, B * H), dim3(256), lds, stream, a);
+        if (Ntok > (CH - 1) * 32) hipLaunchKernelGGL((attn_fwd_kernel<CH, 4, 2, true>), dim3((Ntok + 255) / 256, B * H), dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<CH, 4, 2, false>), dim3((Ntok + 255) / 256, B * H), dim3(256), lds, stream, a);
     } else {
         static bool once = (set_lds(attn_fwd_kernel<CH, 8, 1>, 160 * 1024), true);
         (void)once;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """GPU micro-benchmark of cs_attn_fwd on the teacher's shape (512 crops x 12 heads x 197 tokens); see profiles/r01_n_*.
-env: CS_ATTN_DBG (ablation bits), CS_ATTN_LDSPAD, CS_ATTN_DEBUG, CS_ATTN_PF (prefetch distance in units).   usage: python tools/attn_bench.py [crops]"""
+env: CS_ATTN_DBG (ablation bits), CS_ATTN_LDSPAD, CS_ATTN_DEBUG.   usage: python tools/attn_bench.py [crops]"""
 import sys, torch
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
