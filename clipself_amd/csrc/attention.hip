@@ -329,20 +329,28 @@ __device__ __forceinline__ void store_o(const AttnArgs& p, size_t rowbase, int q
     const float inv = 1.f / l;
     __bf16* orow = p.out + (rowbase + q) * p.ldo + h * HD;
     float ps = 0.f, pq = 0.f;
+    // A lane holds 4 consecutive head dims (8 bytes) per register group, its partner in the other wave half the next 4: one
+    // v_permlane32_swap per dword pairs them up, so that each lane stores 16 contiguous bytes (groups 2a | 2a+1 go to half 0 | 1) -- half
+    // the store instructions and write requests of the 8-byte form.
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt) {
+        U64 t[4];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            U64 t;
+        for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                t.e[i] = f2bf(o[dt][g4 * 4 + i] * inv);
-                const float r = bf2f(t.e[i]);
+                t[g4].e[i] = f2bf(o[dt][g4 * 4 + i] * inv);
+                const float r = bf2f(t[g4].e[i]);
                 ps += r;
                 pq += r * r;
             }
-            if (!(p.dbg & 4)) *(uint2*)(orow + dt * 32 + g4 * 8 + hf * 4) = t.u;
+#pragma unroll
+        for (int a = 0; a < 4; a += 2) {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(t[a].u.x, t[a + 1].u.x, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(t[a].u.y, t[a + 1].u.y, false, false);
+            if (!(p.dbg & 4)) *(uint4*)(orow + dt * 32 + (a + hf) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
+    }
     if (p.lse_out && hf == 0) p.lse_out[(size_t)bh * p.Ntok + q] = m * p.scale + logf(l);
     if (p.stats_part) {
         // (sum, sum of squares) of this row's 64 rounded outputs of head h: the two half-wave lanes of a query hold 32 each.
