@@ -14,16 +14,20 @@ constexpr int ROWS_PER_WG = 4;
 
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
-    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
-        const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
+    typedef float4 raw;
+    static __device__ __forceinline__ raw load_raw(const float* p) { return *(const float4*)p; }
+    static __device__ __forceinline__ void cvt(const raw& t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { cvt(load_raw(p), v); }
 };
 template <> struct Vec4<__bf16> {
-    static __device__ __forceinline__ void load(const __bf16* p, float (&v)[4]) {
-        U64 t; t.u = *(const uint2*)p;
+    typedef uint2 raw;
+    static __device__ __forceinline__ raw load_raw(const __bf16* p) { return *(const uint2*)p; }
+    static __device__ __forceinline__ void cvt(const raw& r, float (&v)[4]) {
+        U64 t; t.u = r;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = bf2f(t.e[i]);
     }
+    static __device__ __forceinline__ void load(const __bf16* p, float (&v)[4]) { cvt(load_raw(p), v); }
 };
 __device__ __forceinline__ void store_bf16x4(__bf16* p, const float (&v)[4]) {
     U64 t;
@@ -45,38 +49,52 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, l
     if (row >= M) return;
     const TX* xr = x + (size_t)row * ldx;
     const int ng = (C + 255) >> 8;
+    const int clast = (C - 1) & ~3;                  // last vector start inside the row
+    // All loads of the row are issued before the first use, from branch-free code: with the load and its use inside one `c < C` block,
+    // hipcc waits for every vector group separately (vmcnt(0) per group: C/256 serial round trips per row).  Lanes past the row end
+    // re-read its last vector and are zeroed by a select.
     float v[MAXG][4];
+    typename Vec4<TX>::raw xr_raw[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+        const int c = (g * 64 + lane) * 4;
+        xr_raw[g] = Vec4<TX>::load_raw(xr + (g < ng ? min(c, clast) : 0));          // groups past the row end re-read its first vector (L1 hit)
+    }
     float s = 0.f;
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) {
         const int c = (g * 64 + lane) * 4;
-        if (g < ng && c < C) {
-            Vec4<TX>::load(xr + c, v[g]);
-            s += (v[g][0] + v[g][1]) + (v[g][2] + v[g][3]);
-        } else {
-            v[g][0] = v[g][1] = v[g][2] = v[g][3] = 0.f;
-        }
+        Vec4<TX>::cvt(xr_raw[g], v[g]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[g][i] = (g < ng && c < C) ? v[g][i] : 0.f;
+        s += (v[g][0] + v[g][1]) + (v[g][2] + v[g][3]);
     }
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) {
         const int c = (g * 64 + lane) * 4;
-        if (g < ng && c < C) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const float d = v[g][i] - mean; if (c + i < C) q += d * d; }   // C may end inside a vector (padded rows)
-        }
+        for (int i = 0; i < 4; ++i) { const float d = v[g][i] - mean; q += (g < ng && c + i < C) ? d * d : 0.f; }   // C may end inside a vector (padded rows)
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    TY* yr = y + (size_t)row * ldy;
+    if (y != nullptr) {                              // y == null: statistics only
+        TY* yr = y + (size_t)row * ldy;
+        float4 ga[MAXG], be[MAXG];
 #pragma unroll
-    for (int g = 0; g < MAXG; ++g) {
-        const int c = (g * 64 + lane) * 4;
-        if (y != nullptr && g < ng && c < C) {       // y == null: statistics only
-            const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
-            float o[4] = {(v[g][0] - mean) * rstd * ga.x + be.x, (v[g][1] - mean) * rstd * ga.y + be.y,
-                          (v[g][2] - mean) * rstd * ga.z + be.z, (v[g][3] - mean) * rstd * ga.w + be.w};
-            store_x4(yr + c, o);
+        for (int g = 0; g < MAXG; ++g) {
+            const int c = g < ng ? min((g * 64 + lane) * 4, clast) : 0;
+            ga[g] = *(const float4*)(gamma + c);
+            be[g] = *(const float4*)(beta + c);
+        }
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            const int c = (g * 64 + lane) * 4;
+            if (g < ng && c < C) {
+                float o[4] = {(v[g][0] - mean) * rstd * ga[g].x + be[g].x, (v[g][1] - mean) * rstd * ga[g].y + be[g].y,
+                              (v[g][2] - mean) * rstd * ga[g].z + be[g].z, (v[g][3] - mean) * rstd * ga[g].w + be[g].w};
+                store_x4(yr + c, o);
+            }
         }
     }
     if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
@@ -130,6 +148,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ng = (C + 255) >> 8;
     const int Cp = (C + 3) & ~3;                   // partial rows are laid out [2][Cp] so that float4 accesses stay aligned
+    const int clast = (C - 1) & ~3;
     float dg[MAXG][4], db[MAXG][4], ga[MAXG][4];
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) {
@@ -142,25 +161,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
         const float mean = mean_in[row], rstd = rstd_in[row];
         float xh[MAXG][4], gy[MAXG][4];
         float s1 = 0.f, s2 = 0.f;
+        // loads of the whole row first, branch-free (see ln_fwd_kernel): lanes past the row end re-read the last vector and are masked
+        float xv[MAXG][4], dv[MAXG][4];
+        typename Vec4<TX>::raw x_raw[MAXG];
+        typename Vec4<__bf16>::raw d_raw[MAXG];
+#pragma unroll
+        for (int g = 0; g < MAXG; ++g) {
+            const int c = g < ng ? min((g * 64 + lane) * 4, clast) : 0;
+            x_raw[g] = Vec4<TX>::load_raw(x + (size_t)row * ldx + c);
+            d_raw[g] = Vec4<__bf16>::load_raw(dy + (size_t)row * lddy + c);
+        }
 #pragma unroll
         for (int g = 0; g < MAXG; ++g) {
             const int c = (g * 64 + lane) * 4;
-            if (g < ng && c < C) {
-                float xv[4], dv[4];
-                Vec4<TX>::load(x + (size_t)row * ldx + c, xv);
-                Vec4<__bf16>::load(dy + (size_t)row * lddy + c, dv);
+            const bool ok = g < ng && c < C;
+            Vec4<TX>::cvt(x_raw[g], xv[g]);
+            Vec4<__bf16>::cvt(d_raw[g], dv[g]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xh[g][i] = (xv[i] - mean) * rstd;
-                    gy[g][i] = dv[i] * ga[g][i];
-                    s1 += gy[g][i];
-                    s2 += gy[g][i] * xh[g][i];
-                    dg[g][i] += dv[i] * xh[g][i];
-                    db[g][i] += dv[i];
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { xh[g][i] = 0.f; gy[g][i] = 0.f; }
+            for (int i = 0; i < 4; ++i) {
+                const float d = ok ? dv[g][i] : 0.f;
+                xh[g][i] = ok ? (xv[g][i] - mean) * rstd : 0.f;
+                gy[g][i] = d * ga[g][i];
+                s1 += gy[g][i];
+                s2 += gy[g][i] * xh[g][i];
+                dg[g][i] += d * xh[g][i];
+                db[g][i] += d;
             }
         }
         const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
