@@ -24,3 +24,16 @@ for _ in range(20):
     ops.attn_fwd(qkv, cos, sin, out, None, B, N, H, 0.125)
 e1.record(); torch.cuda.synchronize()
 print("attn_fwd us:", e0.elapsed_time(e1) * 50)
+if len(sys.argv) > 2 and sys.argv[2] == "bwd":          # python tools/attn_bench.py 64 bwd : the student's backward (dsum prep + dQ + dK/dV kernels)
+    lse = torch.empty(B * H, N, device="cuda")
+    ops.attn_fwd(qkv, cos, sin, out, lse, B, N, H, 0.125)
+    dout = torch.randn_like(out)
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty(ops.attn_bwd_workspace(B, N, H), dtype=torch.uint8, device="cuda")
+    for _ in range(3):
+        ops.attn_bwd(qkv, out, dout, lse, cos, sin, dqkv, ws, B, N, H, 0.125)
+    e0.record()
+    for _ in range(20):
+        ops.attn_bwd(qkv, out, dout, lse, cos, sin, dqkv, ws, B, N, H, 0.125)
+    e1.record(); torch.cuda.synchronize()
+    print("attn_bwd us:", e0.elapsed_time(e1) * 50)
