@@ -362,9 +362,10 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(SPLIT ? (const void*)(p.lo + (size_t)row0 * p.ldxb + colw) : (const void*)p.A);
     const size_t slice = (size_t)tn * 4 + wn;
     const __amdgpu_buffer_rsrc_t rst = make_rsrc(AUX ? (const void*)(p.stats_part + (slice * p.M + row0) * 2) : (const void*)p.C);
-    // Column constants are applied AFTER the slab, where a lane owns 4 columns (two 16-byte loads per tile) -- before it a lane owns a row and
-    // every accumulator register needs its column's bias / column sum from another lane: 64 ds_bpermute per 32-row block, 256 per tile.
-    // Row terms stay in front of the slab (t = rstd * acc); the row's rstd * mean crosses over with one ds_bpermute per output row.
+    // The epilogue arithmetic runs AFTER the slab, where a lane owns 4 columns: the column constants are two 16-byte loads per tile and the
+    // row's rstd and rstd * mean cross over with one ds_bpermute each per output row (64 per tile).  In front of the slab a lane owns a row
+    // and every accumulator register needs its column's bias / column sum from another lane: 256 ds_bpermute per tile.  Same operations in
+    // the same order as gemm.hip's epilogue_at, so the two kernels agree bit for bit (tests compare batch sizes that pick different ones).
     f32x4 cb4 = {0.f, 0.f, 0.f, 0.f}, cc4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) cb4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.bias), colok ? (unsigned)col * 4u : OOB, 0, 0));
     if (LN || F8) cc4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.ln_colsum), colok ? (unsigned)col * 4u : OOB, 0, 0));
@@ -389,14 +390,14 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
                 xin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(rrel * p.ldc + piece * 4) * 4u : OOB, 0, CP));
             }
         }
-        const float rs = (LN || F8) ? eo.rstd[i] : 1.f, u_row = LN ? eo.rstd[i] * eo.mean[i] : 0.f;
+        const float rs_row = (LN || F8) ? eo.rstd[i] : 1.f, nm_row = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 t;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] = (LN || F8) ? rs * acc[i][j][q * 4 + r] : acc[i][j][q * 4 + r];
+                for (int r = 0; r < 4; ++r) t[r] = acc[i][j][q * 4 + r];
                 const int s16 = (j * 8 + 2 * q + hf) ^ (l31 & 15);
                 *(f32x4*)(slab + l31 * 256 + s16 * 16) = t;
             }
@@ -408,15 +409,16 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
             const f32x4 sv = *(const f32x4*)(slab + lrow * 256 + ((piece ^ (lrow & 15)) << 4));
             const bool ok = colok && row0 + rrel < p.M && !(p.dbg & 8);
             f32x4 o;
-            if (LN) {
-                const float ub = lane_bcast(lrow << 2, u_row);             // rstd * mean of row lrow lives in lanes lrow, lrow + 32
+            if (LN) {                                                      // rstd, -rstd * mean of row lrow live in lanes lrow, lrow + 32
+                const float rs = lane_bcast(lrow << 2, rs_row), nm = lane_bcast(lrow << 2, nm_row);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = (xin[it][t] + sv[t]) + fmaf(-ub, cc4[t], cb4[t]);
+                for (int t = 0; t < 4; ++t) o[t] = xin[it][t] + fmaf(rs, sv[t], fmaf(nm, cc4[t], cb4[t]));
             } else if (F8) {
+                const float rs = lane_bcast(lrow << 2, rs_row);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = xin[it][t] + fmaf(sv[t], cc4[t], cb4[t]);
+                for (int t = 0; t < 4; ++t) o[t] = xin[it][t] + fmaf(rs * cc4[t], sv[t], cb4[t]);
             } else {
-                o = (xin[it] + sv) + cb4;
+                o = xin[it] + (sv + cb4);
             }
             if constexpr (SPLIT & 2) {
                 const unsigned off = ok ? (unsigned)(rrel * p.ldxb + piece * 4) * 2u : OOB;
