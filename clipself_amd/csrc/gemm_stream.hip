@@ -615,7 +615,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             }
             after_epi = false;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();     // K tile g landed everywhere; A slot (g+2)%3 and B slot (g+1)&1 are free
+            if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();     // K tile g landed everywhere; A slot (g+2)%3 and B slot (g+1)&1 are free (dbg 2: timing without it)
             const char* la = smem + curA * A_BYTES + a_base;
             const char* lb = b_ring + gpar * B_BYTES + b_base;
             const int slot_a2 = curA == 0 ? 2 : curA - 1, slot_b1 = gpar ^ 1;
