@@ -615,7 +615,10 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             }
             after_epi = false;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (!(p.dbg & 2)) __builtin_amdgcn_s_barrier();     // K tile g landed everywhere; A slot (g+2)%3 and B slot (g+1)&1 are free (dbg 2: timing without it)
+#ifdef CS_ABLATION_SWITCHES                 // build with CS_EXTRA_FLAGS=-DCS_ABLATION_SWITCHES for tools/barrier_cost.py: the run-time test costs 0.35 % of the step
+            if (!(p.dbg & 2))
+#endif
+            __builtin_amdgcn_s_barrier();     // K tile g landed everywhere; A slot (g+2)%3 and B slot (g+1)&1 are free
             const char* la = smem + curA * A_BYTES + a_base;
             const char* lb = b_ring + gpar * B_BYTES + b_base;
             const int slot_a2 = curA == 0 ? 2 : curA - 1, slot_b1 = gpar ^ 1;

@@ -1,5 +1,7 @@
 """What the per-K-tile workgroup barrier of the streaming GEMM costs, and what waves drifting apart would buy: cs_gemm_nt flags bit 13
-(dbg 2) drops the s_barrier (results are wrong: the ring slots race), bit 14 (dbg 4) the epilogue.  usage: python tools/barrier_cost.py"""
+(dbg 2) drops the s_barrier (results are wrong: the ring slots race), bit 14 (dbg 4) the epilogue.  The barrier switch is compiled in
+only with `CS_EXTRA_FLAGS=-DCS_ABLATION_SWITCHES bash clipself_amd/csrc/build.sh` (after touching gemm_stream.hip): as a run-time test it
+cost 0.35 % of the step.  usage: python tools/barrier_cost.py"""
 import sys, torch
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
