@@ -1426,17 +1426,23 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
         if (kt + 2 < kt_end) issue(p.A, p.lda, aoff, kt + 2, smem + ((i0 + 2) % 3) * T_BYTES);
         const char* ta = smem + cur * T_BYTES;
         const char* tb = b_ring + (i0 & 1) * T_BYTES;
+        // fragments of k-step ts+1 are requested before the MFMAs of k-step ts (two register sets): the transposing reads otherwise sit
+        // directly in front of the MFMAs that consume them
+        bf16x8 a[2][FM], b[2][FN];
+        auto load_frags = [&](int set, int ts) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[set][i] = tr_frag(ta, 16 * ts + trow, (wm * TM + i * 32) * 2 + segbyte);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[set][j] = tr_frag(tb, 16 * ts + trow, (wn * TN + j * 32) * 2 + segbyte);
+        };
+        load_frags(0, 0);
 #pragma unroll
         for (int ts = 0; ts < 4; ++ts) {
-            bf16x8 a[FM], b[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) a[i] = tr_frag(ta, 16 * ts + trow, (wm * TM + i * 32) * 2 + segbyte);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) b[j] = tr_frag(tb, 16 * ts + trow, (wn * TN + j * 32) * 2 + segbyte);
+            if (ts < 3) load_frags((ts + 1) & 1, ts + 1);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ts & 1][i], b[ts & 1][j], acc[i][j], 0, 0, 0);
         }
         cur = cur == 2 ? 0 : cur + 1;
     }
