@@ -166,3 +166,57 @@ def test_three_steps_track_reference_losses(gold):
         assert torch.equal(eng.p[n], sd0[n].reshape(eng.p[n].shape)), n
     r = rel(eng.p["visual.blocks.0.mlp.w1.weight"], g["final/visual.blocks.0.mlp.w1.weight"])
     assert r < 2e-2, r
+
+
+def test_split_residual_stream_is_lossless_and_changes_nothing(gold):
+    """The frozen tower keeps its fp32 residual stream as two 16-bit planes of bits(x) + 0x8000 between the residual GEMMs
+    (cs_gemm_nt_ln_split; mirror: RefOps.split_planes / join_planes).  The planes rebuild every fp32 bit pattern, the upper plane is x rounded
+    to bf16 (halves away from zero), and the teacher's features are those of the fp32-stream schedule."""
+    x = torch.randn(4096, 64) * 10
+    x[0, :4] = torch.tensor([0.0, -0.0, float("inf"), -float("inf")])
+    tie = (torch.tensor([1.0]).view(torch.int32) | 0x8000).view(torch.float32)[0]           # low 16 bits exactly 0x8000
+    x[1, :2] = torch.stack([tie, -tie])
+    x[2, 0] = torch.finfo(torch.float32).tiny                                               # smallest normal
+    hi, lo = RefOps.split_planes(x)
+    assert hi.dtype == torch.bfloat16 and lo.dtype == torch.int16
+    assert torch.equal(RefOps.join_planes(hi, lo).view(torch.int32), x.view(torch.int32))
+    rne = x.to(torch.bfloat16)
+    differs = hi.view(torch.int16) != rne.view(torch.int16)
+    low16 = x.view(torch.int32) & 0xFFFF
+    assert bool((low16[differs] == 0x8000).all())                                           # only exact ties round differently from RNE
+    assert float(hi[1, 0]) > float(tie) and float(hi[1, 1]) < -float(tie)                   # ... and they round away from zero
+
+    g, rec = gold
+    cfg = tiny_cfg()
+    _, _, crops = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"])
+    eng = _engine(cfg, rec["seed_w"], False)
+    assert eng.split_stream and eng.fold_block_ln
+    for cls_only in (True, False):
+        eng.cls_only_last_block = cls_only
+        eng.split_stream = True
+        split = eng.encode_image(crops.flatten(0, 1), chunk=5)
+        eng.split_stream = False
+        fp32 = eng.encode_image(crops.flatten(0, 1), chunk=5)
+        # the two schedules differ only where an exact tie makes the upper plane round away from zero instead of to even (2^-16 of the
+        # values): at width 64 one such flip of a bf16 operand is visible, far below the bf16 noise of the path itself
+        cos = torch.nn.functional.cosine_similarity(split.double(), fp32.double(), dim=-1)
+        assert rel(split, fp32) < 3e-3 and float((1 - cos).max()) < 1e-5, (rel(split, fp32), float((1 - cos).max()))
+    assert not _engine(cfg, rec["seed_w"], True).split_stream                               # the trainable tower keeps fp32 + autograd saves
+    # one residual GEMM, both forms, same operands: the fp32 stream is bit-identical and so are the statistics
+    ops = RefOps()
+    M, N, K = 37, 64, 128
+    gen = torch.Generator().manual_seed(5)
+    A, B = torch.randn(M, K, generator=gen).to(torch.bfloat16), (torch.randn(N, K, generator=gen) * 0.1).to(torch.bfloat16)
+    bias, cs = torch.randn(N, generator=gen), torch.randn(N, generator=gen)
+    mean, rstd = torch.randn(M, generator=gen) * 0.1, torch.rand(M, generator=gen) + 0.5
+    x0 = torch.randn(M, N, generator=gen) * 3
+    xa, pa, xb = x0.clone(), torch.zeros(1, M, 2), torch.zeros(M, N, dtype=torch.bfloat16)
+    ops.gemm_nt_ln(A, B, xa, bias=bias, extra=xa, ln_mean=mean, ln_rstd=rstd, ln_colsum=cs, stats_part=pa, xb_out=xb, epi=6)
+    hi, lo, pb = torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, N, dtype=torch.int16), torch.zeros(1, M, 2)
+    ops.gemm_nt_ln_split(A, B, hi, lo, bias, mean, rstd, cs, x_in=x0, stats_part=pb)
+    assert torch.equal(RefOps.join_planes(hi, lo).view(torch.int32), xa.view(torch.int32)) and torch.equal(pa, pb)
+    out = torch.zeros(M, N)
+    ops.gemm_nt_ln_split(A, B, hi, lo, bias, mean, rstd, cs, x_out=out)
+    xa2 = xa.clone()
+    ops.gemm_nt_ln(A, B, xa2, bias=bias, extra=xa2, ln_mean=mean, ln_rstd=rstd, ln_colsum=cs, epi=6)
+    assert torch.equal(out.view(torch.int32), xa2.view(torch.int32))
