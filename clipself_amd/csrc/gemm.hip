@@ -1353,7 +1353,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // 64 tokens; LDS image of an operand tile = [64 tokens][256 columns] bf16 (512-byte rows) staged by the 16-byte LDS-DMA, the 32-byte
 // column groups of row r XOR-permuted by (r & 7) on the SOURCE side so that the four rows of a transposing read hit four different bank
 // groups.  Same split rings (A x3, B x2), counted waits and split-K-through-partials epilogue as the NT kernel; replaces the explicit
-// bf16 transposes of dY and X (2 x 4 per block and step).  Requires tokens % 64 == 0, N % 256 == 0, K % 256 == 0.
+// bf16 transposes of dY and X (2 x 4 per block and step).  Any token count, N and K multiples of 8 (ragged edges: see the kernel).
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 // 32-byte column group g of token row t sits at group g ^ tn_swz(t): the two 16-lane groups of a half-wave read the same four tokens at
@@ -1369,6 +1369,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int tok, int colbyte
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// RAGGED: the shape has partial tiles (tokens % 64, N % 256 or K % 256); the exact-tile variant carries none of that code (it costs the
+// longest shape 7 % when compiled in: one more uniform branch in the DMA issue and 19 more registers).
+template <bool RAGGED>
 __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
     constexpr int BM = 256, BN = 256, WN = 4, TM = 128, TN = 64, FM = 4, FN = 2;
     constexpr int T_BYTES = 64 * 512;                     // one operand tile: 64 tokens x 256 columns
@@ -1383,21 +1386,36 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
     char* const b_ring = smem + 3 * T_BYTES;
     // DMA: instruction x of this wave fills LDS rows 2*(wave*4+x), +1; lane l lands at row + (l >> 5), physical 16-byte chunk l & 31
     const int drow = lane >> 5, pc = lane & 31;
-    unsigned aoff[4], boff[4];
+    // Ragged edges: columns past the operand's width re-read its last 8 columns (they only reach output rows / columns the epilogue masks);
+    // token rows past the end re-read the last token, and those rows of the dY image are zeroed in LDS before they are read (last K tile only).
+    unsigned acol[4], bcol[4], aoff[4], boff[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
         const int row = 2 * (wave * 4 + x) + drow;
         const int lc = ((((pc >> 1) ^ tn_swz(row)) << 1) | (pc & 1));   // logical 16-byte chunk this LDS position holds
-        aoff[x] = (unsigned)(row * p.lda + n0 + lc * 8) * 2u;
-        boff[x] = (unsigned)(row * p.ldb + k0 + lc * 8) * 2u;
+        acol[x] = (unsigned)(RAGGED ? min(n0 + lc * 8, p.M - 8) : n0 + lc * 8) * 2u;
+        bcol[x] = (unsigned)(RAGGED ? min(k0 + lc * 8, p.N - 8) : k0 + lc * 8) * 2u;
+        aoff[x] = (unsigned)row * (unsigned)p.lda * 2u + acol[x];       // full tiles: one 32-bit offset per piece
+        boff[x] = (unsigned)row * (unsigned)p.ldb * 2u + bcol[x];
     }
-    const int kt_begin = blockIdx.y * p.ktiles_per_split, kt_end = min(kt_begin + p.ktiles_per_split, p.K / 64);
-    auto issue = [&](const __bf16* base, int ld, const unsigned (&off)[4], int kt, char* dst) {
+    const int ktiles_all = (p.K + 63) >> 6;
+    const int kt_begin = blockIdx.y * p.ktiles_per_split, kt_end = min(kt_begin + p.ktiles_per_split, ktiles_all);
+    auto issue = [&](const __bf16* base, int ld, const unsigned (&off)[4], const unsigned (&col)[4], int kt, char* dst) {
         const char* src = (const char*)base + (size_t)kt * 64 * ld * 2;
+        const int rmax = p.K - 1 - kt * 64;                     // last valid token row of this tile (wave-uniform)
+        if (!RAGGED || rmax >= 63) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off[x]),
-                                             (__attribute__((address_space(3))) void*)(dst + (wave * 4 + x) * 1024), 16, 0, 0);
+            for (int x = 0; x < 4; ++x)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off[x]),
+                                                 (__attribute__((address_space(3))) void*)(dst + (wave * 4 + x) * 1024), 16, 0, 0);
+        } else {                                                // ragged last tile
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int row = min(2 * (wave * 4 + x) + drow, rmax);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)row * ld * 2 + col[x]),
+                                                 (__attribute__((address_space(3))) void*)(dst + (wave * 4 + x) * 1024), 16, 0, 0);
+            }
+        }
     };
     f32x16 acc[FM][FN];
 #pragma unroll
@@ -1407,10 +1425,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     if (kt_begin < kt_end) {
-        issue(p.A, p.lda, aoff, kt_begin, smem);
-        issue(p.B, p.ldb, boff, kt_begin, b_ring);
+        issue(p.A, p.lda, aoff, acol, kt_begin, smem);
+        issue(p.B, p.ldb, boff, bcol, kt_begin, b_ring);
     }
-    if (kt_begin + 1 < kt_end) issue(p.A, p.lda, aoff, kt_begin + 1, smem + T_BYTES);
+    if (kt_begin + 1 < kt_end) issue(p.A, p.lda, aoff, acol, kt_begin + 1, smem + T_BYTES);
     // lane's 8-byte segment inside a 32-column block: column 16*g1 + 4*(li&3); tokens of its 16-lane group: 8*hf + (li>>2)
     const int segbyte = (16 * g1 + 4 * (li & 3)) * 2, trow = 8 * hf + (li >> 2);
     int cur = 0;
@@ -1422,10 +1440,18 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
         const int i0 = kt - kt_begin;
         // one burst behind the barrier: spreading the pieces over the k-steps makes hipcc drain the DMA queue (vmcnt(0)) in front of every
         // transposing read that follows a DMA issue -- measured 115.9 -> 136.9 us on the W1|W2 shape
-        if (kt + 1 < kt_end) issue(p.B, p.ldb, boff, kt + 1, b_ring + ((i0 + 1) & 1) * T_BYTES);
-        if (kt + 2 < kt_end) issue(p.A, p.lda, aoff, kt + 2, smem + ((i0 + 2) % 3) * T_BYTES);
+        if (kt + 1 < kt_end) issue(p.B, p.ldb, boff, bcol, kt + 1, b_ring + ((i0 + 1) & 1) * T_BYTES);
+        if (kt + 2 < kt_end) issue(p.A, p.lda, aoff, acol, kt + 2, smem + ((i0 + 2) % 3) * T_BYTES);
         const char* ta = smem + cur * T_BYTES;
         const char* tb = b_ring + (i0 & 1) * T_BYTES;
+        // ragged last token tile: the rows of the missing tokens hold copies of the last token -- zero them in the dY image (wave-uniform
+        // branch taken once per workgroup at most; the full tiles pay nothing)
+        const int tvalid = p.K - kt * 64;
+        if (RAGGED && tvalid < 64) {
+            for (int idx = tid; idx < (64 - tvalid) * 32; idx += 512)
+                *(uint4*)(smem + cur * T_BYTES + (tvalid + (idx >> 5)) * 512 + (idx & 31) * 16) = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        }
         // fragments of k-step ts+1 are requested before the MFMAs of k-step ts (two register sets): the transposing reads otherwise sit
         // directly in front of the MFMAs that consume them
         bf16x8 a[2][FM], b[2][FN];
@@ -1473,8 +1499,8 @@ void choose_wgrad(int M, int N, int K, int& cfg, int& splits) {
 
 namespace {
 int choose_tn_splits(int N, int K, int tokens) {
-    const long tiles = (long)(N / 256) * (K / 256);
-    const int ktiles = tokens / 64;
+    const long tiles = (long)((N + 255) / 256) * ((K + 255) / 256);
+    const int ktiles = (tokens + 63) / 64;
     double best = 1e30;
     int splits = 1;
     for (int sp = 1; sp <= 64 && sp <= ktiles; ++sp) {
@@ -1487,16 +1513,16 @@ int choose_tn_splits(int N, int K, int tokens) {
 }  // namespace
 
 // Token-major wgrad: dW[N,K] (f32, row stride ldc) += dY[tokens,N]^T . X[tokens,K], bf16 operands as the step's kernels left them (no
-// transposed copies).  Returns 1 (nothing launched) when the shape is outside the kernel's coverage -- tokens % 64, N % 256, K % 256 --
-// so that the caller can take the transposing path (cs_transpose_bf16 + cs_gemm_wgrad).  Workspace: cs_gemm_wgrad_tn_workspace bytes.
+// transposed copies).  Any token count; N and K multiples of 8.  Returns 1 (nothing launched) outside that coverage, so that the caller
+// can take the transposing path (cs_transpose_bf16 + cs_gemm_wgrad).  Workspace: cs_gemm_wgrad_tn_workspace bytes.
 extern "C" size_t cs_gemm_wgrad_tn_workspace(int N, int K, int tokens) {
-    if (tokens % 64 != 0 || N % 256 != 0 || K % 256 != 0 || tokens <= 0) return 0;
+    if (tokens <= 0 || N < 8 || K < 8 || N % 8 != 0 || K % 8 != 0) return 0;
     return (size_t)choose_tn_splits(N, K, tokens) * N * K * sizeof(float);
 }
 
 extern "C" int cs_gemm_wgrad_tn(const void* dY, const void* X, float* dW, void* workspace, int N, int K, int tokens, int ldy, int ldx, int ldc,
                                 hipStream_t stream) {
-    if (tokens % 64 != 0 || N % 256 != 0 || K % 256 != 0 || tokens <= 0) return 1;
+    if (tokens <= 0 || N < 8 || K < 8 || N % 8 != 0 || K % 8 != 0) return 1;
     CS_CHECK_ARG(workspace != nullptr && ((uintptr_t)workspace % 16) == 0 && dW != nullptr && ((uintptr_t)dW % 16) == 0 && ldc % 4 == 0,
                  "cs_gemm_wgrad_tn: workspace / dW must be 16-byte aligned buffers");
     CS_CHECK_ARG(ldy % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0 && ldy >= N && ldx >= K,
@@ -1508,13 +1534,15 @@ extern "C" int cs_gemm_wgrad_tn(const void* dY, const void* X, float* dW, void* 
     a.M = N; a.N = K; a.K = tokens; a.lda = ldy; a.ldb = ldx; a.ldc = K; a.group = 0;
     a.split_stride = (long)N * K;
     a.ln_mean = a.ln_rstd = a.ln_colsum = nullptr; a.stats_part = nullptr; a.xb_out = nullptr; a.ldxb = 0;
-    a.tiles_m = N / 256; a.tiles_n = K / 256; a.gm = 8; a.dbg = 0; a.rm = 0; a.nsplit = 1; a.reserve = 0;
-    const int ktiles = tokens / 64;
+    a.tiles_m = (N + 255) / 256; a.tiles_n = (K + 255) / 256; a.gm = 8; a.dbg = 0; a.rm = 0; a.nsplit = 1; a.reserve = 0;
+    const int ktiles = (tokens + 63) / 64;
     a.ktiles_per_split = (ktiles + splits - 1) / splits;
     constexpr size_t lds = 160 * 1024;
-    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
+    if (tokens % 64 == 0 && N % 256 == 0 && K % 256 == 0) hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
     CS_LAUNCH_CHECK();
     const long n = (long)N * (K >> 2);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, splits,

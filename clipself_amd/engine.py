@@ -616,7 +616,7 @@ class EvaEngine:
 
     def _wgrad(self, dY, X, dW):
         """dW[N,K] += dY^T X, dY [M,N] and X [M,K] token-major bf16.  cs_gemm_wgrad_tn contracts them as they are (transposing LDS
-        reads); shapes it does not cover (tokens % 64, N or K % 256) go through explicit transposes + the NT split-K kernel."""
+        reads); shapes it does not cover (N or K not a multiple of 8) go through explicit transposes + the NT split-K kernel."""
         ops = self.ops
         M, N = dY.shape
         K = X.shape[1]

@@ -54,9 +54,9 @@ int cs_gemm_wgrad(const void* A, const void* B, float* dW, void* workspace, int 
                   cs_stream_t stream);
 
 /* The same weight gradient without transposed copies: dW[N,K] (f32) += dY[tokens,N]^T . X[tokens,K], both operands token-major as the
- * backward left them (MFMA operands through the transposing LDS read ds_read_b64_tr_b16).  Covers tokens % 64 == 0, N % 256 == 0,
- * K % 256 == 0: cs_gemm_wgrad_tn_workspace returns 0 and cs_gemm_wgrad_tn returns 1 (nothing launched) otherwise -- use
- * cs_transpose_bf16 + cs_gemm_wgrad then. */
+ * backward left them (MFMA operands through the transposing LDS read ds_read_b64_tr_b16).  Any token count; N and K multiples of 8
+ * (ragged tiles re-read valid rows / columns, the last token tile's missing tokens are zeroed in the fragments): cs_gemm_wgrad_tn_workspace
+ * returns 0 and cs_gemm_wgrad_tn returns 1 (nothing launched) otherwise -- use cs_transpose_bf16 + cs_gemm_wgrad then. */
 size_t cs_gemm_wgrad_tn_workspace(int N, int K, int tokens);
 int cs_gemm_wgrad_tn(const void* dY, const void* X, float* dW, void* workspace, int N, int K, int tokens, int ldy, int ldx, int ldc,
                      cs_stream_t stream);

@@ -191,7 +191,7 @@ class RefOps:
         dW.add_(A.float() @ B.float().T)
 
     def gemm_wgrad_tn_workspace(self, N, K, tokens):
-        return 16 if (tokens % 64 == 0 and N % 256 == 0 and K % 256 == 0 and tokens > 0) else 0
+        return 16 if (tokens > 0 and N >= 8 and K >= 8 and N % 8 == 0 and K % 8 == 0) else 0
 
     def gemm_wgrad_tn(self, dY, X, dW, workspace):
         dW.add_(dY.float().T @ X.float())

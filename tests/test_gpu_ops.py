@@ -748,10 +748,12 @@ def test_multiscale_bilinear_resize_matches_torch(hip, ref, shape, size):
     check(f"resize_bilinear{list(shape)}->{size}", got, want, 1e-6)
 
 
-@pytest.mark.parametrize("N,K,T", [(768, 768, 12608), (2304, 768, 12608), (4096, 768, 12608), (768, 2048, 12608), (256, 256, 64), (1024, 3072, 1152)])
+@pytest.mark.parametrize("N,K,T", [(768, 768, 12608), (2304, 768, 12608), (4096, 768, 12608), (768, 2048, 12608), (256, 256, 64), (1024, 3072, 1152),
+                                   (5504, 1024, 9232), (1024, 2752, 9232), (64, 64, 17), (344, 64, 51), (768, 768, 8194), (8, 264, 1)])
 def test_gemm_wgrad_token_major_operands(hip, ref, N, K, T):
     """cs_gemm_wgrad_tn: dW += dY^T X straight from the token-major operands (transposing LDS reads, no transposed copies), against the
-    fp32 product; accumulates into dW; reports shapes it does not cover instead of computing them."""
+    fp32 product; accumulates into dW; ragged token counts and widths (L/14-336: 9232 tokens, hidden 2752; tiny towers: 17 tokens, width 64;
+    the recipe's 8194 tokens); reports shapes it does not cover instead of computing them."""
     dY, X = rnd((T, N), BF, 0.5, seed=70), rnd((T, K), BF, 0.5, seed=71)
     base = rnd((N, K), F32, seed=72)
     need = hip.gemm_wgrad_tn_workspace(N, K, T)
@@ -769,7 +771,7 @@ def test_gemm_wgrad_token_major_operands(hip, ref, N, K, T):
     got2 = torch.zeros(N, K, device="cuda")
     hip.gemm_wgrad_tn(wide.cuda()[:, 256:], X.cuda(), got2, ws)
     check(f"gemm_wgrad_tn_strided[{N},{K},{T}]", got2, wide[:, 256:].float().T @ X.float(), 2e-5)
-    assert hip.gemm_wgrad_tn_workspace(N, K, T + 32) == 0 and hip.gemm_wgrad_tn_workspace(N + 64, K, T) == 0
+    assert hip.gemm_wgrad_tn_workspace(N + 4, K, T) == 0 and hip.gemm_wgrad_tn_workspace(N, K + 2, T) == 0      # widths must be multiples of 8
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 768, 768), (2 * 197 * 7, 768, 2048), (300, 64, 64), (50432, 1024, 1024)])
