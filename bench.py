@@ -113,6 +113,29 @@ def cpu_model_name():
     return "unknown CPU"
 
 
+def physical_cores():
+    """Physical cores of the host (distinct (package, core) pairs of /proc/cpuinfo; SMT siblings counted once), capped by the cores this
+    process may run on."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if core is not None:
+            seen.add((phys, core))
+        n = len(seen)
+    except OSError:
+        n = 0
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, avail) if n else avail)
+
+
 def cpu_baseline_worker():
     """fp32 CPU oracle (oracle/eva_ref.py) on the host cores, protocol of SURVEY.md section 8 M5: BASELINE configs[0] exactly (2 images x 8
     boxes, 224^2; 1 warm-up + 3 timed optimizer steps) and the benchmark's own unit scaled down in images only (2 images x 32 crops, 2 timed
@@ -120,7 +143,7 @@ def cpu_baseline_worker():
     from clipself_amd.config import get_tower_cfg
     from clipself_amd.init import seeded_visual_state, synthetic_batch
     from oracle import eva_ref
-    cores = min(os.cpu_count() or 1, 32)
+    cores = physical_cores()                                                 # all physical cores of the host
     torch.set_num_threads(cores)
     cfg = get_tower_cfg(MODEL)
     student, teacher = seeded_visual_state(cfg, 0), seeded_visual_state(cfg, 0)

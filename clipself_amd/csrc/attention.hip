@@ -113,6 +113,11 @@ __device__ __forceinline__ bf16x8 load_t_frag(const __bf16* t, int ld, int d, in
     return r;
 }
 
+#ifdef CS_ABLATION_SWITCHES
+#define ATT_ABL(p, bit) ((p).dbg & (bit))
+#else
+#define ATT_ABL(p, bit) false
+#endif
 struct AttnArgs {
     const __bf16* qkv;     // [B*N, ldqkv]: q | k | v, each C = H*64 wide
     const __bf16* dout;    // bwd: dO [B*N, ldo]
@@ -120,7 +125,8 @@ struct AttnArgs {
     const float* sin_t;
     const float* lse_in;   // bwd: [B*H, N]
     const float* dsum;     // bwd: rowsum(dO*O) [B*H, N]
-    int dbg;               // timing ablations (env CS_ATTN_DBG, results wrong): 1 = no MFMA/softmax phase, 2 = no RoPE, 4 = no output stores
+    int dbg;               // timing ablations (results wrong; env CS_ATTN_DBG, read only in builds with -DCS_ABLATION_SWITCHES): 1 = no MFMA/softmax
+                           // phase, 2 = no RoPE, 4 = no output stores
     int grid;              // fwd: token grid side g (Ntok = g*g + 1)
     float inv_grid;
     float* stats_part;     // fwd, optional: [H][B*N][2] per-head (sum, sum of squares) of the output rows
@@ -348,7 +354,7 @@ __device__ __forceinline__ void store_o(const AttnArgs& p, size_t rowbase, int q
         for (int a = 0; a < 4; a += 2) {
             const auto r0 = __builtin_amdgcn_permlane32_swap(t[a].u.x, t[a + 1].u.x, false, false);
             const auto r1 = __builtin_amdgcn_permlane32_swap(t[a].u.y, t[a + 1].u.y, false, false);
-            if (!(p.dbg & 4)) *(uint4*)(orow + dt * 32 + (a + hf) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            if (!ATT_ABL(p, 4)) *(uint4*)(orow + dt * 32 + (a + hf) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
     }
     if (p.lse_out && hf == 0) p.lse_out[(size_t)bh * p.Ntok + q] = m * p.scale + logf(l);
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
         for (int it = 0; it < KI; ++it) {
             const int idx = tid + it * NT, r = idx >> 3, c = idx & 7;
             if (idx < CHK * 8) {
-                if (r > 0 && r < p.Ntok && !(p.dbg & 2)) rope8_lds(kr[it], rt, p.grid, p.inv_grid, r, c);
+                if (r > 0 && r < p.Ntok && !ATT_ABL(p, 2)) rope8_lds(kr[it], rt, p.grid, p.inv_grid, r, c);
                 *(uint4*)(Kl + k_off(r, c)) = kr[it].u;
             }
         }
@@ -464,12 +470,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
                 bf16x8 qf[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    if (qc > 0 && !(p.dbg & 2)) rope8_lds(qraw[j][ks], rt, p.grid, p.inv_grid, qc, ks * 2 + hf);
+                    if (qc > 0 && !ATT_ABL(p, 2)) rope8_lds(qraw[j][ks], rt, p.grid, p.inv_grid, qc, ks * 2 + hf);
                     qf[ks] = qraw[j][ks].h;
                 }
                 float m = -INFINITY, l = 0.f;
                 f32x16 o[2] = {zero16(), zero16()};
-                if (!(p.dbg & 1)) attend_chunk<CH, TAIL>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o);
+                if (!ATT_ABL(p, 1)) attend_chunk<CH, TAIL>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o);
                 else { l = 1.f; m = 0.f; o[0][0] = bf2f(qf[0][0]); }
                 if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
             }
@@ -795,8 +801,12 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
     int g = (int)(sqrtf((float)(Ntok - 1)) + 0.5f);
     CS_CHECK_ARG(g * g == Ntok - 1, "cs_attn_fwd: Ntok - 1 = %d is not a square token grid (the RoPE tables are read separably)", Ntok - 1);
     a.grid = g; a.inv_grid = 1.f / (float)g;
+#ifdef CS_ABLATION_SWITCHES
     static const int dbg_env = getenv("CS_ATTN_DBG") ? atoi(getenv("CS_ATTN_DBG")) : 0;
     a.dbg = dbg_env;
+#else
+    a.dbg = 0;
+#endif
     a.Ntok = Ntok; a.H = H; a.ldqkv = ldqkv; a.ldo = ldo; a.scale = scale;
     constexpr int CH = 7;
     static const size_t lds_pad = getenv("CS_ATTN_LDSPAD") ? (size_t)atoi(getenv("CS_ATTN_LDSPAD")) : 0;     // occupancy experiments

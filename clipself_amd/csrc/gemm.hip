@@ -262,7 +262,7 @@ __device__ __forceinline__ void epilogue_at(const GemmArgs& p, const f32x16 (&ac
                 const int row = min(row_base + rrow + it * 4, p.M - 1);
                 if (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
                     // flags bit 12 (A/B switch): non-temporal accesses for the streams of the residual epilogue (read once / written once)
-                    if (p.dbg & 1) {
+                    if (CS_ABL(p, 1)) {
                         const f32x4 t4 = __builtin_nontemporal_load((const f32x4*)(p.extra + (size_t)row * p.ldc + col));
                         xin[it] = make_float4(t4[0], t4[1], t4[2], t4[3]);
                     } else {
@@ -303,7 +303,7 @@ __device__ __forceinline__ void epilogue_at(const GemmArgs& p, const f32x16 (&ac
                     } else if (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN_F32) {
                         const float4 x = xin[it];
                         const float o[4] = {x.x + v[0], x.y + v[1], x.z + v[2], x.w + v[3]};
-                        if (p.dbg & 1) {
+                        if (CS_ABL(p, 1)) {
                             __builtin_nontemporal_store(f32x4{o[0], o[1], o[2], o[3]}, (f32x4*)((float*)p.C + (size_t)row * p.ldc + col));
                         } else {
                             *(float4*)((float*)p.C + (size_t)row * p.ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
             }
         } else {
             __syncthreads();        // tile kt landed (the barrier drains the LDS-DMA queue); buffer cur^1 is free
-            if (kt + 1 < kt_end && !(p.dbg & 1)) {
+            if (kt + 1 < kt_end && !CS_ABL(p, 1)) {
                 char* nxt = smem + (cur ^ 1) * STAGE;
                 stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 1) * BK, nxt, wave * A_INSTR, lane, arow, achk);
                 stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 1) * BK, nxt + A_BYTES, wave * B_INSTR, lane, brow, bchk);
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
         }
         const char* la = (AB ? smem + cur * A_BYTES : smem + cur * STAGE) + a_base;
         const char* lb = (AB ? b_ring + ((kt - kt_begin) & 1) * B_BYTES : smem + cur * STAGE + A_BYTES) + b_base;
-        if (p.dbg & 2) { cur = (NS == 3 || AB) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1); continue; }
+        if (CS_ABL(p, 2)) { cur = (NS == 3 || AB) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1); continue; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int off = ((par8 | (ks * 2 + hf)) ^ sw) << 4;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
         cur = (NS == 3 || AB) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
     }
     __syncthreads();                                    // every wave is done reading the operand buffers
-    if (p.dbg & 4) return;
+    if (CS_ABL(p, 4)) return;
     epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + wm * TM, n0, tn, wn);
 }
 
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(512, 2) void gemm_k32_kernel(GemmArgs p) {
         cur = cur == 2 ? 0 : cur + 1;
     }
     __syncthreads();
-    if (p.dbg & 4) return;
+    if (CS_ABL(p, 4)) return;
     epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + wm * TM, n0, tn, wn);
 }
 
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
         stage_tile<B_INSTR, true>(p.B, p.ldb, kt * BK, dst + A_BYTES, wave * B_INSTR, lane, brow, bchk);
     };
     bf16x8 fa[2][FM], fb[2][FN];
-    if (V == 2 && (p.dbg & 2)) {                      // ablation without ds_reads: defined (zero) fragments
+    if (V == 2 && CS_ABL(p, 2)) {                      // ablation without ds_reads: defined (zero) fragments
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
@@ -848,16 +848,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
             //   group 1: B pieces in L(kt,0) = 4kt+1, A pieces in L(kt,1) = 4kt+3 where the B pieces are waited for (vmcnt(4): loads
             //            retire in order), the A pieces at the end of C(kt,1) = 4kt+4, in front of its own first read.
             // timing ablations (flags bits 12-13, results wrong): 1 = no operand DMA in the loop, 2 = no fragment ds_reads
-            const bool nxt = kt + 1 < kt_end && (g == 0 || kt > kt_begin) && !(p.dbg & 1);   // group 1's tile kt_begin+1 comes from the prologue
+            const bool nxt = kt + 1 < kt_end && (g == 0 || kt > kt_begin) && !CS_ABL(p, 1);   // group 1's tile kt_begin+1 comes from the prologue
             // ---- L(kt,0)
-            if (!(p.dbg & 2)) load_frags(cur, 0);
+            if (!CS_ABL(p, 2)) load_frags(cur, 0);
             if (nxt) PP_PIECES(4, 8, kt + 1, cur ^ 1);
             PP_BARRIER();
             // ---- C(kt,0)
             mfma_half();
             PP_BARRIER();
             // ---- L(kt,1)
-            if (!(p.dbg & 2)) load_frags(cur, 1);
+            if (!CS_ABL(p, 2)) load_frags(cur, 1);
             if (nxt) PP_PIECES(0, 4, kt + 1, cur ^ 1);
             if (g == 1) {
                 if (nxt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 #undef PP_BARRIER
 #undef PP_PIECES
     __syncthreads();
-    if (p.dbg & 4) return;
+    if (CS_ABL(p, 4)) return;
     epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + g * TM, n0, tn, wn);
 }
 
@@ -1087,7 +1087,7 @@ int launch_persist(GemmArgs a, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + BN / 2 - 1) / (BN / 2) : (a.N + BN - 1) / BN;
     const long ntiles = (long)a.tiles_m * a.tiles_n;
-    const long cap = 256 - (a.reserve > 0 && a.reserve < 200 ? a.reserve : 0);       // flags bits 20-26: compute units left free
+    const long cap = cs_persistent_cap(a.reserve);       // flags bits 20-26: compute units left free
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
     if constexpr (EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16) {           // the wide-N GEMMs of the towers (q|k|v, W1|W2)
         const bool parts_ok = grid == 256 && a.tiles_n >= a.nsplit && a.tiles_m >= 8 / a.nsplit;
@@ -1141,7 +1141,7 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
     const double out_bytes = 4.0 * (double)a.M * (double)ncols;
     auto best_split = [&](int bm, int bn, int per_cu, double us_per_ktile, double& cost) {
         const long t = tiles(bm, bn);
-        const long slots = 256L * per_cu;
+        const long slots = (long)cs_num_cus() * per_cu;
         int best = 1;
         cost = 1e30;
         const int lo = splits > 0 ? splits : 1, hi = splits > 0 ? splits : (ktiles < 64 ? ktiles : 64);
@@ -1221,7 +1221,7 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 //       bits 8-11: raster group height override (0 = 8)
 //       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue;
 //       bit 15: split-ring schedule issues its DMA in one burst behind the barrier instead of interleaved with the MFMAs
-//       bits 20-26: compute units the persistent kernels leave free (grid = 256 - n; multi-GPU runs keep room for RCCL's kernels)
+//       bits 20-26: compute units the persistent kernels leave free (grid = compute units - n; multi-GPU runs keep room for RCCL's kernels)
 //       bits 16-17 (persistent kernel, epilogues 0 and 3): 1 = B-stationary raster (each XCD keeps its share of B in L2; bits 8-11 = N parts,
 //                 0 = automatic), 2 = the same with non-temporal A loads, 3 = grouped raster with non-temporal B loads
 static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias, const float* extra, const float* ln_mean,
@@ -1487,7 +1487,7 @@ void choose_wgrad(int M, int N, int K, int& cfg, int& splits) {
         if (M < c.bm || N < c.bn) continue;
         const long tiles = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
         for (int s = 1; s <= 64 && s <= ktiles; ++s) {
-            const long rounds = (tiles * s + 256L * c.per_cu - 1) / (256L * c.per_cu);
+            const long rounds = (tiles * s + (long)cs_num_cus() * c.per_cu - 1) / ((long)cs_num_cus() * c.per_cu);
             const int kper = (ktiles + s - 1) / s;
             const double t = rounds * (kper * c.us + 6.0) + (s + 2) * out_mb / 5.0 + 6.0;
             if (t < best) { best = t; cfg = c.cfg; splits = s; }

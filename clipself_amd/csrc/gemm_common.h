@@ -6,6 +6,15 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Timing-ablation switches (cs_gemm_nt flags bits 12-14: skip the operand DMA / the MFMA loop / the epilogue, mask every store) give wrong
+// results by construction.  They exist only in builds with -DCS_ABLATION_SWITCHES (CS_EXTRA_FLAGS of build.sh; tools/gemm_bench.py ablation
+// columns, tools/barrier_cost.py); the shipped library compiles them out, so no flag value reachable through the C ABI changes a result.
+#ifdef CS_ABLATION_SWITCHES
+#define CS_ABL(p, bit) ((p).dbg & (bit))
+#else
+#define CS_ABL(p, bit) false
+#endif
+
 constexpr int BK = 64;
 constexpr bool PP_DEFAULT = false;     // make the ping-pong schedule the default for 256x256 tiles (A/B knob, see tools/gemm_bench.py)
 enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID_F32 = 2, EPI_SWIGLU_BF16 = 3, EPI_ATOMIC_F32 = 4, EPI_PATCH_F32 = 5, EPI_RESID_LN_F32 = 6,
@@ -45,8 +54,24 @@ struct GemmArgs {
     unsigned short* lo = nullptr;
     int split = 0;
     int reserve;          // persistent kernels: compute units to leave free (grid = 256 - reserve), e.g. for RCCL kernels running beside the step
-    int dbg;              // ablation switches for tools/gemm_bench.py: bit0 skip the in-loop operand DMA, bit1 skip ds_read+MFMA
+    int dbg;              // flags bits 12-15: bit 0 = slab form of the streaming kernel's bf16 / SwiGLU epilogues, bit 3 = burst DMA issue (both exact
+                          // A/B switches); with -DCS_ABLATION_SWITCHES also the wrong-result timing ablations (CS_ABL)
 };
+
+// Compute units of the current device (multiProcessorCount, read once per process): the persistent kernels launch one workgroup per CU.
+inline int cs_num_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+// persistent grid: one workgroup per compute unit, minus the ones the caller keeps free (cs_gemm_nt flags bits 20-26)
+inline long cs_persistent_cap(int reserve) {
+    const int n = cs_num_cus();
+    return n - (reserve > 0 && reserve < n - 32 ? reserve : 0);
+}
 
 // gemm_stream.hip: streaming persistent kernel with register-level epilogues.  Returns 1 when the problem is outside what it covers
 // (the caller falls back to gemm_persist_kernel), 0 on launch, < 0 on error.

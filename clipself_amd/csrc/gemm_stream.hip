@@ -65,6 +65,10 @@ template <int CP>
 __device__ __forceinline__ void store8(const u32x2& v, __amdgpu_buffer_rsrc_t rs, unsigned off) {
     __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, CP);
 }
+// c + a.lo * b.lo + a.hi * b.hi on packed bf16 pairs (v_dot2c_f32_bf16)
+__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
 __device__ __forceinline__ float silu_mul(float u, float v) {               // hardware exp2 / rcp (1 ulp each; the result is rounded to bf16)
     return u * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u)) * v;
 }
@@ -125,12 +129,11 @@ __device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc
         for (int i = 0; i < 4; ++i) {
             pk[i][q][0] = pack2(hv[i][0], hv[i][1]);
             pk[i][q][1] = pack2(hv[i][2], hv[i][3]);
-            if (AUX) {                                                  // statistics of the ROUNDED outputs (what the next GEMM reads)
-#pragma unroll
+            if (AUX) {                                                  // statistics of the ROUNDED outputs (what the next GEMM reads):
+#pragma unroll                                                           // one v_dot2c_f32_bf16 per packed pair and moment, no unpacking
                 for (int d = 0; d < 2; ++d) {
-                    const float a = __uint_as_float(pk[i][q][d] << 16), b = __uint_as_float(pk[i][q][d] & 0xffff0000u);
-                    ssum[i] += a + b;
-                    ssq[i] = fmaf(a, a, fmaf(b, b, ssq[i]));
+                    ssum[i] = dot2_bf16(pk[i][q][d], 0x3f803f80u, ssum[i]);
+                    ssq[i] = dot2_bf16(pk[i][q][d], pk[i][q][d], ssq[i]);
                 }
             }
         }
@@ -138,7 +141,7 @@ __device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc
     const __amdgpu_buffer_rsrc_t rc = make_rsrc((const __bf16*)p.C + (size_t)row0 * p.ldc + hbase);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const bool ok = colok && row0 + i * 32 + l31 < p.M && !(p.dbg & 8);      // dbg 8: timing ablation, every store masked
+        const bool ok = colok && row0 + i * 32 + l31 < p.M && !CS_ABL(p, 8);      // dbg 8: timing ablation, every store masked
         const unsigned rowoff = (unsigned)((i * 32 + l31) * p.ldc + 8 * hf) * 2u;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
@@ -200,7 +203,7 @@ __device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[
     // stores in row-block order: the four 32-byte pieces of a row's 128-byte line (two column tiles x two group pairs) leave back to back
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const bool rowok = row0 + i * 32 + l31 < p.M && !(p.dbg & 8);        // dbg 8: timing ablation, every store masked
+        const bool rowok = row0 + i * 32 + l31 < p.M && !CS_ABL(p, 8);        // dbg 8: timing ablation, every store masked
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool ok = rowok && colw + j * 32 < p.N;                    // wave-uniform column test: N % 32 == 0
@@ -266,7 +269,7 @@ __device__ __forceinline__ void epi_bf16_slab(const GemmArgs& p, const f32x16 (&
         for (int k = 0; k < 8; ++k) {
             const int lrow = (lane >> 3) + 8 * k, rrel = half * 64 + lrow;
             const uint4 w = *(const uint4*)(slab + lrow * 128 + ((piece ^ (lrow & 7)) << 4));
-            const bool ok = row0 + rrel < p.M && col < p.N && !(p.dbg & 8);
+            const bool ok = row0 + rrel < p.M && col < p.N && !CS_ABL(p, 8);
             store16<CP>(u32x4{w.x, w.y, w.z, w.w}, rc, ok ? (unsigned)(rrel * p.ldc + piece * 8) * 2u : OOB);
         }
     }
@@ -314,10 +317,8 @@ __device__ __forceinline__ void epi_swiglu_slab(const GemmArgs& p, const f32x16 
         for (int i = 0; i < 4; ++i) {
             const unsigned d0 = pack2(hv[i][0], hv[i][1]), d1 = pack2(hv[i][2], hv[i][3]);
             if (AUX) {
-                const float a0 = __uint_as_float(d0 << 16), b0 = __uint_as_float(d0 & 0xffff0000u);
-                const float a1 = __uint_as_float(d1 << 16), b1v = __uint_as_float(d1 & 0xffff0000u);
-                ssum[i] += (a0 + b0) + (a1 + b1v);
-                ssq[i] = fmaf(a0, a0, fmaf(b0, b0, fmaf(a1, a1, fmaf(b1v, b1v, ssq[i]))));
+                ssum[i] = dot2_bf16(d1, 0x3f803f80u, dot2_bf16(d0, 0x3f803f80u, ssum[i]));
+                ssq[i] = dot2_bf16(d1, d1, dot2_bf16(d0, d0, ssq[i]));
             }
             const int lrow = i * 32 + l31;
             const int s8 = (2 * q + hf) ^ (((lrow >> 1) & 3) << 1);
@@ -330,7 +331,7 @@ __device__ __forceinline__ void epi_swiglu_slab(const GemmArgs& p, const f32x16 
     for (int k = 0; k < 8; ++k) {
         const int lrow = (lane >> 2) + 16 * k;
         const uint4 w = *(const uint4*)(slab + lrow * 64 + ((piece ^ ((lrow >> 1) & 3)) << 4));
-        const bool ok = colok && row0 + lrow < p.M && !(p.dbg & 8);
+        const bool ok = colok && row0 + lrow < p.M && !CS_ABL(p, 8);
         store16<CP>(u32x4{w.x, w.y, w.z, w.w}, rc, ok ? (unsigned)(lrow * p.ldc + piece * 8) * 2u : OOB);
     }
     if (AUX) {
@@ -339,55 +340,64 @@ __device__ __forceinline__ void epi_swiglu_slab(const GemmArgs& p, const f32x16 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float s = both_halves(ssum[i]), q2 = both_halves(ssq[i]);
-            const bool ok = colok && hf == 0 && row0 + i * 32 + l31 < p.M && !(p.dbg & 8);
+            const bool ok = colok && hf == 0 && row0 + i * 32 + l31 < p.M && !CS_ABL(p, 8);
             store8<CP>(u32x2{__float_as_uint(s), __float_as_uint(q2)}, rst, ok ? (unsigned)(i * 32 + l31) * 8u : OOB);
         }
     }
 }
 
-// fp32 residual through the slab: acc (+ folded LayerNorm + bias, applied while the lane still owns a whole row) of one 32-row block goes
-// [32 rows][256 bytes] (16-byte slot s of row r at r*256 + (s ^ (r & 15)) * 16) and comes back 16 lanes per row; residual rows, outputs
-// and the bf16 copy are whole-line accesses.
+// fp32 residual through the slab: the accumulators of one 32-row block go [32 rows][256 bytes] (16-byte slot s of row r at
+// r*256 + (s ^ (r & 15)) * 16, written with 16-byte DS stores while a lane still owns a row) and come back EIGHT lanes per row, eight
+// consecutive columns per lane: every global access of the epilogue is a 16-byte-per-lane request over whole 128- / 256-byte row segments
+// (hi / lo planes, bf16 copy: one 128-byte line per 8 lanes; fp32 rows: two).  Round 2 read the slab 16 lanes per row with 8-byte plane
+// accesses -- twice the memory instructions for the same bytes, and 8-byte requests run at 0.54-0.70x the rate of 16-byte ones
+// (MI355X_MICROARCH.md): the epilogue is bound by the CU's vector-memory path.
 // SPLIT bit 0 / bit 1: the stream arrives / leaves as the two 16-bit planes (p.xb_out, p.lo) of y = bits(x) + 0x8000 (GemmArgs::split).
 template <bool LN, bool AUX, int CP, bool F8 = false, int SPLIT = 0>
 __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, int tn, int wn,
                                                const EpiOps& eo, char* slab) {
     static_assert(!(SPLIT & 2) || AUX, "a split stream leaves together with the row statistics");
     const int l31 = lane & 31, hf = lane >> 5;
-    const int rrow = lane >> 4, piece = lane & 15, col = colw + piece * 4;
-    const bool colok = col < p.N;
+    const int rrow = lane >> 3, piece = lane & 7, col = colw + piece * 8;
+    const bool colok = col < p.N;                                           // N % 32 == 0: a lane's eight columns are inside or outside together
     const __amdgpu_buffer_rsrc_t rc = make_rsrc((SPLIT & 2) ? (const void*)p.xb_out : (const void*)((const float*)p.C + (size_t)row0 * p.ldc + colw));
     const __amdgpu_buffer_rsrc_t rx = make_rsrc((SPLIT & 1) ? (const void*)p.xb_out : (const void*)(p.extra + (size_t)row0 * p.ldc + colw));
     const __amdgpu_buffer_rsrc_t rb = make_rsrc((AUX || SPLIT) ? (const void*)(p.xb_out + (size_t)row0 * p.ldxb + colw) : (const void*)p.C);
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(SPLIT ? (const void*)(p.lo + (size_t)row0 * p.ldxb + colw) : (const void*)p.A);
     const size_t slice = (size_t)tn * 4 + wn;
     const __amdgpu_buffer_rsrc_t rst = make_rsrc(AUX ? (const void*)(p.stats_part + (slice * p.M + row0) * 2) : (const void*)p.C);
-    // The epilogue arithmetic runs AFTER the slab, where a lane owns 4 columns: the column constants are two 16-byte loads per tile and the
-    // row's rstd and rstd * mean cross over with one ds_bpermute each per output row (64 per tile).  In front of the slab a lane owns a row
-    // and every accumulator register needs its column's bias / column sum from another lane: 256 ds_bpermute per tile.  Same operations in
-    // the same order as gemm.hip's epilogue_at, so the two kernels agree bit for bit (tests compare batch sizes that pick different ones).
-    f32x4 cb4 = {0.f, 0.f, 0.f, 0.f}, cc4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) cb4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.bias), colok ? (unsigned)col * 4u : OOB, 0, 0));
-    if (LN || F8) cc4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.ln_colsum), colok ? (unsigned)col * 4u : OOB, 0, 0));
+    // The epilogue arithmetic runs AFTER the slab, where a lane owns 8 columns: the column constants are four 16-byte loads per tile and the
+    // row's rstd and rstd * mean cross over with one ds_bpermute each per output row.  In front of the slab a lane owns a row and every
+    // accumulator register needs its column's bias / column sum from another lane: 256 ds_bpermute per tile.  Same operations per element
+    // as gemm.hip's epilogue_at.
+    f32x4 cb4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, cc4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned off = colok ? (unsigned)(col + 4 * h) * 4u : OOB;
+        if (p.bias) cb4[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.bias), off, 0, 0));
+        if (LN || F8) cc4[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.ln_colsum), off, 0, 0));
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         // the residual rows of the block are requested before the accumulators go through the slab
-        f32x4 xin[8];
+        f32x4 xin[4][2];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int rrel = i * 32 + rrow + 4 * it;
-            const bool ok = colok && row0 + rrel < p.M && !(p.dbg & 8);
+        for (int it = 0; it < 4; ++it) {
+            const int rrel = i * 32 + rrow + 8 * it;
+            const bool ok = colok && row0 + rrel < p.M;
             if constexpr (SPLIT & 1) {
-                const unsigned off = ok ? (unsigned)(rrel * p.ldxb + piece * 4) * 2u : OOB;
-                const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rb, off, 0, CP));
-                const u32x2 l = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rl, off, 0, CP));
+                const unsigned off = ok ? (unsigned)(rrel * p.ldxb + piece * 8) * 2u : OOB;
+                const u32x4 h = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, CP));
+                const u32x4 l = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, off, 0, CP));
 #pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    xin[it][2 * w] = __uint_as_float(__builtin_amdgcn_perm(h[w], l[w], 0x05040100u) - 0x8000u);
-                    xin[it][2 * w + 1] = __uint_as_float(__builtin_amdgcn_perm(h[w], l[w], 0x07060302u) - 0x8000u);
+                for (int w = 0; w < 4; ++w) {
+                    xin[it][w >> 1][2 * (w & 1)] = __uint_as_float(__builtin_amdgcn_perm(h[w], l[w], 0x05040100u) - 0x8000u);
+                    xin[it][w >> 1][2 * (w & 1) + 1] = __uint_as_float(__builtin_amdgcn_perm(h[w], l[w], 0x07060302u) - 0x8000u);
                 }
             } else {
-                xin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(rrel * p.ldc + piece * 4) * 4u : OOB, 0, CP));
+                const unsigned off = ok ? (unsigned)(rrel * p.ldc + piece * 8) * 4u : OOB;
+                xin[it][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, CP));
+                xin[it][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off + 16u : OOB, 0, CP));
             }
         }
         const float rs_row = (LN || F8) ? eo.rstd[i] : 1.f, nm_row = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
@@ -401,63 +411,72 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
                 const int s16 = (j * 8 + 2 * q + hf) ^ (l31 & 15);
                 *(f32x4*)(slab + l31 * 256 + s16 * 16) = t;
             }
-        const int sel = lane & 15;
+        const int sel = lane & 7;
         float st_s = 0.f, st_q = 0.f;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int lrow = rrow + 4 * it, rrel = i * 32 + lrow;
-            const f32x4 sv = *(const f32x4*)(slab + lrow * 256 + ((piece ^ (lrow & 15)) << 4));
-            const bool ok = colok && row0 + rrel < p.M && !(p.dbg & 8);
-            f32x4 o;
-            if (LN) {                                                      // rstd, -rstd * mean of row lrow live in lanes lrow, lrow + 32
-                const float rs = lane_bcast(lrow << 2, rs_row), nm = lane_bcast(lrow << 2, nm_row);
+        for (int it = 0; it < 4; ++it) {
+            const int lrow = rrow + 8 * it, rrel = i * 32 + lrow;
+            const bool ok = colok && row0 + rrel < p.M;
+            float rs = 1.f, nm = 0.f;
+            if (LN || F8) rs = lane_bcast(lrow << 2, rs_row);                 // rstd, -rstd * mean of row lrow live in lanes lrow, lrow + 32
+            if (LN) nm = lane_bcast(lrow << 2, nm_row);
+            f32x4 o[2];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = xin[it][t] + fmaf(rs, sv[t], fmaf(nm, cc4[t], cb4[t]));
-            } else if (F8) {
-                const float rs = lane_bcast(lrow << 2, rs_row);
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 sv = *(const f32x4*)(slab + lrow * 256 + (((2 * piece + h) ^ (lrow & 15)) << 4));
+                if (LN) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = xin[it][t] + fmaf(rs * cc4[t], sv[t], cb4[t]);
-            } else {
-                o = xin[it] + (sv + cb4);
+                    for (int t = 0; t < 4; ++t) o[h][t] = xin[it][h][t] + fmaf(rs, sv[t], fmaf(nm, cc4[h][t], cb4[h][t]));
+                } else if (F8) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[h][t] = xin[it][h][t] + fmaf(rs * cc4[h][t], sv[t], cb4[h][t]);
+                } else {
+                    o[h] = xin[it][h] + (sv + cb4[h]);
+                }
             }
             if constexpr (SPLIT & 2) {
-                const unsigned off = ok ? (unsigned)(rrel * p.ldxb + piece * 4) * 2u : OOB;
-                unsigned y[4];
+                const unsigned off = ok ? (unsigned)(rrel * p.ldxb + piece * 8) * 2u : OOB;
+                unsigned y[8];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) y[t] = __float_as_uint(o[t]) + 0x8000u;
-                store8<CP>(u32x2{__builtin_amdgcn_perm(y[1], y[0], 0x07060302u), __builtin_amdgcn_perm(y[3], y[2], 0x07060302u)}, rb, off);
-                store8<CP>(u32x2{__builtin_amdgcn_perm(y[1], y[0], 0x05040100u), __builtin_amdgcn_perm(y[3], y[2], 0x05040100u)}, rl, off);
+                for (int t = 0; t < 8; ++t) y[t] = __float_as_uint(o[t >> 2][t & 3]) + 0x8000u;
+                store16<CP>(u32x4{__builtin_amdgcn_perm(y[1], y[0], 0x07060302u), __builtin_amdgcn_perm(y[3], y[2], 0x07060302u),
+                                  __builtin_amdgcn_perm(y[5], y[4], 0x07060302u), __builtin_amdgcn_perm(y[7], y[6], 0x07060302u)}, rb, off);
+                store16<CP>(u32x4{__builtin_amdgcn_perm(y[1], y[0], 0x05040100u), __builtin_amdgcn_perm(y[3], y[2], 0x05040100u),
+                                  __builtin_amdgcn_perm(y[5], y[4], 0x05040100u), __builtin_amdgcn_perm(y[7], y[6], 0x05040100u)}, rl, off);
             } else {
-                store16<CP>(__builtin_bit_cast(u32x4, o), rc, ok ? (unsigned)(rrel * p.ldc + piece * 4) * 4u : OOB);
+                const unsigned off = ok ? (unsigned)(rrel * p.ldc + piece * 8) * 4u : OOB;
+                store16<CP>(__builtin_bit_cast(u32x4, o[0]), rc, off);
+                store16<CP>(__builtin_bit_cast(u32x4, o[1]), rc, ok ? off + 16u : OOB);
             }
             if (AUX) {
                 if constexpr (!(SPLIT & 2))
-                    store8<CP>(u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])}, rb, ok ? (unsigned)(rrel * p.ldxb + piece * 4) * 2u : OOB);
-                // a row's 64 columns sit in 16 adjacent lanes (DPP butterfly); lane (lane & 15) == it keeps iteration it's row, so the
+                    store16<CP>(u32x4{pack2(o[0][0], o[0][1]), pack2(o[0][2], o[0][3]), pack2(o[1][0], o[1][1]), pack2(o[1][2], o[1][3])}, rb,
+                                ok ? (unsigned)(rrel * p.ldxb + piece * 8) * 2u : OOB);
+                // a row's 64 columns sit in 8 adjacent lanes (DPP butterfly); lane (lane & 7) == it keeps iteration it's row, so the
                 // 32 rows of the block leave in one 256-byte store below
                 float ps = 0.f, pq = 0.f;
                 if (colok) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) { ps += o[t]; pq = fmaf(o[t], o[t], pq); }
+                    for (int t = 0; t < 8; ++t) { ps += o[t >> 2][t & 3]; pq = fmaf(o[t >> 2][t & 3], o[t >> 2][t & 3], pq); }
                 }
-                const float a = sum_lanes16(ps), b = sum_lanes16(pq);
+                const float a = sum_lanes8(ps), b = sum_lanes8(pq);
                 if (sel == it) { st_s = a; st_q = b; }
             }
         }
         if (AUX) {
-            const int rrel = i * 32 + rrow + 4 * sel;
-            const bool ok = sel < 8 && row0 + rrel < p.M && colw < p.N && !(p.dbg & 8);
+            const int rrel = i * 32 + rrow + 8 * sel;
+            const bool ok = sel < 4 && row0 + rrel < p.M && colw < p.N;
             store8<CP>(u32x2{__float_as_uint(st_s), __float_as_uint(st_q)}, rst, ok ? (unsigned)rrel * 8u : OOB);
         }
-        __builtin_amdgcn_sched_barrier(0);       // keep the next block's 8 residual loads (32 registers) out of this block
+        __builtin_amdgcn_sched_barrier(0);       // keep the next block's residual loads (32 registers) out of this block
     }
 }
 
 // store instructions one epilogue issues per wave (exact: masked lanes keep their instruction, see OOB)
-template <int EPI, bool AUX, bool SLAB>
+template <int EPI, bool AUX, bool SLAB, int SPLIT = 0>
 constexpr int epi_stores() {
     if (EPI == EPI_SWIGLU_BF16) return 8 + (AUX ? 4 : 0);
-    if (EPI == EPI_RESID_F32) return 32 + (AUX ? 32 + 4 : 0);
+    if (EPI == EPI_RESID_F32) return 32 + (AUX ? ((SPLIT & 2) ? 0 : 16) + 4 : 0);      // per row group: two fp32 or two plane stores (+ the bf16 copy)
     return 16;
 }
 
@@ -478,7 +497,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     static_assert(SWI || RES || epi_is_bf16(EPI), "register epilogues");
     constexpr int BM = 256, BN = 256, WN = 4, TM = 128, TN = 64, FM = 4, FN = 2;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-    constexpr int S = epi_stores<EPI, AUX, SLAB>() < 56 ? epi_stores<EPI, AUX, SLAB>() : 56;     // vmcnt is a 6-bit counter; fewer = safe
+    constexpr int S = epi_stores<EPI, AUX, SLAB, SPLIT>() < 56 ? epi_stores<EPI, AUX, SLAB, SPLIT>() : 56;     // vmcnt is a 6-bit counter; fewer = safe
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -575,12 +594,6 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         tile_of_id(p, tile, ntiles, tm, tn);
         const int row0 = tm * BM + wm * TM, colw = tn * BN + wn * TN;
         f32x16 acc[FM][FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         EpiOps eo;
         // epilogue operands: LayerNorm statistics of the rows of the wave's four blocks (lane = row), constants of its 64 columns (lane = column)
         auto load_epi_ops = [&](int ln) {
@@ -599,13 +612,15 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             int co;
             if (SWI) co = hf * p.group + min(tn * 128 + wn * 32 + l31, p.group - 1);
             else co = min(colw + lane, p.N - 1);
-            if (!RES) {                                    // the residual epilogue reads its column constants 4 per lane behind the slab
+            if (!RES) {                                    // the residual epilogue reads its column constants 8 per lane behind the slab
                 if (p.bias) eo.cb = p.bias[co];
                 if (LN || F8) eo.cc = p.ln_colsum[co];
             }
         };
 
-        auto ktile = [&]() {
+        // ZERO: first K tile of the output tile -- its first k-step accumulates onto the inline constant 0 (no 128 v_mov per tile)
+        auto ktile = [&](auto zero_tag) {
+            constexpr bool ZERO = decltype(zero_tag)::value;
             // In issue order this wave's pending ops are ... A(g), B(g), A(g+1) [, the previous epilogue's S stores]: everything older
             // than A(g+1) must have landed; vmcnt retires in order, so the stores (newest) may stay in flight as well.
             if (after_epi) {
@@ -615,14 +630,13 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             }
             after_epi = false;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef CS_ABLATION_SWITCHES                 // build with CS_EXTRA_FLAGS=-DCS_ABLATION_SWITCHES for tools/barrier_cost.py: the run-time test costs 0.35 % of the step
-            if (!(p.dbg & 2))
-#endif
-            __builtin_amdgcn_s_barrier();     // K tile g landed everywhere; A slot (g+2)%3 and B slot (g+1)&1 are free
+            if (!CS_ABL(p, 2))                  // build with CS_EXTRA_FLAGS=-DCS_ABLATION_SWITCHES for tools/barrier_cost.py: the run-time test costs 0.35 % of the step
+                __builtin_amdgcn_s_barrier();     // K tile g landed everywhere; A slot (g+2)%3 and B slot (g+1)&1 are free
             const char* la = smem + curA * A_BYTES + a_base;
             const char* lb = b_ring + gpar * B_BYTES + b_base;
             const int slot_a2 = curA == 0 ? 2 : curA - 1, slot_b1 = gpar ^ 1;
-            bool a_iss = false, b_iss = false;
+            const bool iss_b = b_ok, iss_a = a_ok;
+            bool a_iss = false;
             if constexpr (F8) {
                 typedef __attribute__((ext_vector_type(8))) int i32x8;
                 typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -642,21 +656,26 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                         b8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     }
                     if (s2 == 0) {
-                        if (b_ok) { ISSUE_B(0, slot_b1); ISSUE_B(1, slot_b1); ISSUE_B(2, slot_b1); ISSUE_B(3, slot_b1); }
-                    } else if (a_ok) {
+                        if (iss_b) { ISSUE_B(0, slot_b1); ISSUE_B(1, slot_b1); ISSUE_B(2, slot_b1); ISSUE_B(3, slot_b1); }
+                    } else if (iss_a) {
                         ISSUE_A(0, slot_a2); ISSUE_A(1, slot_a2); ISSUE_A(2, slot_a2); ISSUE_A(3, slot_a2);
                     }
 #pragma unroll
                     for (int i = 0; i < FM; ++i)
 #pragma unroll
-                        for (int j = 0; j < FN; ++j)       // e4m3 x e4m3, unit (2^0) block scales
-                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                        for (int j = 0; j < FN; ++j) {     // e4m3 x e4m3, unit (2^0) block scales
+                            if (ZERO && s2 == 0) {
+                                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], z, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                            } else {
+                                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                            }
+                        }
                     if (s2 == 0) {
-                        b_iss = b_ok;
-                        if (b_ok) adv_b();
+                        if (iss_b) adv_b();
                     } else {
-                        a_iss = a_ok;
-                        if (a_ok) adv_a();
+                        a_iss = iss_a;
+                        if (iss_a) adv_a();
                     }
                 }
             } else {
@@ -669,23 +688,27 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(lb + j * (16 * 256) + off);
                 if (ks < 2) {                  // two DMA pieces per k-step: B(g+1) first, then A(g+2)
-                    if (b_ok) {
+                    if (iss_b) {
                         if ((ks & 1) == 0) { ISSUE_B(0, slot_b1); ISSUE_B(1, slot_b1); } else { ISSUE_B(2, slot_b1); ISSUE_B(3, slot_b1); }
                     }
-                } else if (a_ok) {
+                } else if (iss_a) {
                     if ((ks & 1) == 0) { ISSUE_A(0, slot_a2); ISSUE_A(1, slot_a2); } else { ISSUE_A(2, slot_a2); ISSUE_A(3, slot_a2); }
                 }
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-                if (ks == 1) {
-                    b_iss = b_ok;
-                    if (b_ok) adv_b();
-                }
+                    for (int j = 0; j < FN; ++j) {
+                        if (ZERO && ks == 0) {
+                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], z, 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                        }
+                    }
+                if (ks == 1 && iss_b) adv_b();
                 if (ks == 3) {
-                    a_iss = a_ok;
-                    if (a_ok) adv_a();
+                    a_iss = iss_a;
+                    if (iss_a) adv_a();
                 }
             }
             }
@@ -693,8 +716,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             curA = curA == 2 ? 0 : curA + 1;
             gpar ^= 1;
         };
-        for (int kt = 0; kt < ktiles; ++kt) ktile();
-        if (p.dbg & 4) continue;               // timing ablation (tools/gemm_bench.py): no epilogue, results are wrong
+        ktile(std::true_type{});
+        for (int kt = 1; kt < ktiles; ++kt) ktile(std::false_type{});
+        if (CS_ABL(p, 4)) continue;            // timing ablation (tools/gemm_bench.py): no epilogue, results are wrong
         after_epi = true;
         // Everything the epilogue derives from the lane id (swizzled slab addresses, store offsets, ds_bpermute sources: ~80 values) is
         // loop-invariant; hoisted out of the tile loop it would live -- spilled -- across the whole MFMA loop.  An opaque copy of the
@@ -776,7 +800,7 @@ int cs_gemm_stream_launch_f8(GemmArgs a, int epi, int reserve, hipStream_t strea
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.N + 255) / 256;
     const long ntiles = (long)a.tiles_m * a.tiles_n;
-    const long cap = 256 - (reserve > 0 && reserve < 200 ? reserve : 0);
+    const long cap = cs_persistent_cap(reserve);
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
     if (epi == EPI_BF16) return launch_stream_f8<EPI_BF16, false>(a, grid, stream);
     return launch_stream_f8<EPI_RESID_F32, true>(a, grid, stream);
@@ -797,11 +821,12 @@ int cs_gemm_stream_launch(GemmArgs a, int epi, int reserve, hipStream_t stream) 
     else if (res) {
         if ((a.stats_part != nullptr) != (a.xb_out != nullptr)) return 1;
         aux = a.stats_part != nullptr;
+        if (aux && (a.ldxb % 8 != 0 || ((uintptr_t)a.xb_out % 16) != 0)) return 1;        // the bf16 copy leaves in 16-byte pieces
     } else if (a.stats_part || a.xb_out) return 1;
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = swi ? (a.group + 127) / 128 : (a.N + 255) / 256;
     const long ntiles = (long)a.tiles_m * a.tiles_n;
-    const long cap = 256 - (reserve > 0 && reserve < 200 ? reserve : 0);
+    const long cap = cs_persistent_cap(reserve);
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
     if (swi) {
         if (ln) return aux ? launch_stream_t<EPI_SWIGLU_BF16, true, true>(a, grid, stream) : launch_stream_t<EPI_SWIGLU_BF16, true, false>(a, grid, stream);
@@ -828,10 +853,11 @@ extern "C" int cs_gemm_nt_ln_split(const void* A, const void* B, const float* bi
     CS_CHECK_ARG(ln_mean && ln_rstd && ln_colsum && bias && ((uintptr_t)ln_colsum % 16) == 0 && ((uintptr_t)bias % 16) == 0,
                  "cs_gemm_nt_ln_split: mean, rstd, column sums and bias are required (16-byte aligned vectors)");
     CS_CHECK_ARG(x_in == nullptr || x_out == nullptr, "cs_gemm_nt_ln_split: fp32 in and fp32 out is cs_gemm_nt_ln");
-    CS_CHECK_ARG(hi && lo && ((uintptr_t)hi % 8) == 0 && ((uintptr_t)lo % 8) == 0 && ldxb % 4 == 0 && ldxb >= N, "cs_gemm_nt_ln_split: hi / lo planes: 8-byte aligned, ldxb %% 4 == 0");
+    CS_CHECK_ARG(hi && lo && ((uintptr_t)hi % 16) == 0 && ((uintptr_t)lo % 16) == 0 && ldxb % 8 == 0 && ldxb >= N, "cs_gemm_nt_ln_split: hi / lo planes: 16-byte aligned, ldxb %% 8 == 0");
     CS_CHECK_ARG((x_in == nullptr || (((uintptr_t)x_in % 16) == 0 && ldc % 4 == 0)) && (x_out == nullptr || (((uintptr_t)x_out % 16) == 0 && ldc % 4 == 0)),
                  "cs_gemm_nt_ln_split: the fp32 stream must be 16-byte aligned with ldc %% 4 == 0");
     CS_CHECK_ARG(x_out != nullptr || stats_part != nullptr, "cs_gemm_nt_ln_split: a stream that leaves split leaves with its row statistics");
+    CS_CHECK_ARG(x_out == nullptr || stats_part == nullptr, "cs_gemm_nt_ln_split: fp32 out takes no stats_part (hi / lo are only read then; the statistics epilogue would overwrite hi)");
     CS_CHECK_ARG(!(x_in != nullptr && stats_part == nullptr), "cs_gemm_nt_ln_split: fp32 in -> split out needs stats_part");
     CS_CHECK_ARG((long)ldc * 128 * 4 < 0x70000000L && (long)ldxb * 128 * 2 < 0x70000000L, "cs_gemm_nt_ln_split: row stride too large");
     GemmArgs a;
@@ -846,11 +872,11 @@ extern "C" int cs_gemm_nt_ln_split(const void* A, const void* B, const float* bi
     a.tiles_m = (M + 255) / 256;
     a.tiles_n = (N + 255) / 256;
     const long ntiles = (long)a.tiles_m * a.tiles_n;
-    const long cap = 256 - (a.reserve > 0 && a.reserve < 200 ? a.reserve : 0);
+    const long cap = cs_persistent_cap(a.reserve);
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
     if (a.split == 3) return launch_stream_split<true, 3>(a, grid, stream);
     if (a.split == 2) return launch_stream_split<true, 2>(a, grid, stream);
-    return stats_part ? launch_stream_split<true, 1>(a, grid, stream) : launch_stream_split<false, 1>(a, grid, stream);
+    return launch_stream_split<false, 1>(a, grid, stream);
 }
 
 // C ABI: fp8 (OCP e4m3) operands quantised row-wise by cs_quant_rows_fp8 -- BASELINE configs[4] "fp8 MFMA weights".

@@ -11,7 +11,6 @@
 // per-row / per-column weights Wy[h], Wx[w] (sequentially, fixed order -> deterministic) and then touches each
 // map cell at most once:   pooled = sum_{r,c} Wy[r] Wx[c] F[r,c] / max(gh*gw,1).
 #include "cs_common.h"
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
 
@@ -78,24 +77,94 @@ __global__ __launch_bounds__(256) void roialign_fwd_kernel(const float* __restri
     }
 }
 
-// dfeat [B, Ntok, E] f32 (pre-zeroed) += scatter of dpooled; overlapping boxes -> hardware float atomics
-__global__ __launch_bounds__(256) void roialign_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ rois,
-                                                           float* __restrict__ dfeat, int Ntok, int gh_map, int gw_map, int E, int tok_off) {
-    __shared__ float Wy[MAXGRID], Wx[MAXGRID];
-    const int k = blockIdx.x, tid = threadIdx.x;
-    const RoiGeom g = box_setup(rois + (size_t)k * 5, gh_map, gw_map, Wy, Wx, tid);
-    __syncthreads();
-    if (g.gh <= 0 || g.gw <= 0) return;
-    float* fb = dfeat + ((size_t)g.b * Ntok + tok_off) * E;
-    for (int ch = tid; ch < E; ch += 256) {
-        const float gv = dpooled[(size_t)k * E + ch] * g.inv_count;
-        for (int r = 0; r < gh_map; ++r) {
-            const float wy = Wy[r];
+// Weight of map cell `cell` along one axis: the same samples, in the same order, as axis_weights() adds into w[cell] -> bit-identical to
+// the forward's Wy[cell] / Wx[cell].
+__device__ float axis_weight_at(float start, float extent, int grid, int size, int cell) {
+    float w = 0.f;
+    for (int i = 0; i < grid; ++i) {
+        float c = __fadd_rn(start, __fdiv_rn(__fmul_rn((float)i + 0.5f, extent), (float)grid));
+        if (c < -1.0f || c > (float)size) continue;
+        if (c <= 0.f) c = 0.f;
+        int lo = (int)c, hi;
+        if (lo >= size - 1) { hi = lo = size - 1; c = (float)lo; } else { hi = lo + 1; }
+        const float l = __fsub_rn(c, (float)lo);
+        if (lo == cell) w += __fsub_rn(1.f, l);
+        if (hi == cell) w += l;
+    }
+    return w;
+}
+
+// Backward as a GATHER: one workgroup owns RB_CELLS consecutive cells of one grid row of one image and adds up, box by box in ascending
+// box order, what every box of that image sends to them:  dfeat[b, r, c, :] += sum_k Wy_k[r] Wx_k[c] dpooled[k, :] / count_k.
+// No atomics, a fixed summation order -> the gradient is bit-reproducible (torchvision's backward, and round 2's scatter kernel, add with
+// float atomics in arrival order: 2.8e-4 relative run-to-run differences on the step's gradients).
+constexpr int RB_CELLS = 16, RB_EPT = 4;          // cells per workgroup; channels per thread (E <= 256 * RB_EPT)
+__global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(const float* __restrict__ dpooled, const float* __restrict__ rois,
+                                                                  float* __restrict__ dfeat, int K, int Ntok, int gh_map, int gw_map, int E,
+                                                                  int tok_off) {
+    __shared__ int list[256];
+    __shared__ int wave_cnt[4];
+    __shared__ float Wxs[RB_CELLS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c0 = blockIdx.x * RB_CELLS, r = blockIdx.y, b = blockIdx.z;
+    float acc[RB_CELLS][RB_EPT];
+#pragma unroll
+    for (int c = 0; c < RB_CELLS; ++c)
+#pragma unroll
+        for (int j = 0; j < RB_EPT; ++j) acc[c][j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 256) {
+        // ordered compaction of the boxes k0 .. k0+255 that belong to image b
+        const int k = k0 + tid;
+        const bool mine = k < K && (int)rois[(size_t)k * 5] == b;
+        const unsigned long long m = __ballot(mine);
+        if (lane == 0) wave_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wv) base += wave_cnt[w];
+            total += wave_cnt[w];
+        }
+        if (mine) list[base + __popcll(m & ((1ull << lane) - 1ull))] = k;
+        __syncthreads();
+        for (int n = 0; n < total; ++n) {                  // workgroup-uniform control flow below: every value comes from the box record
+            const float* roi = rois + (size_t)list[n] * 5;
+            const float x0 = __fsub_rn(__fmul_rn(roi[1], (float)gw_map), 0.5f), y0 = __fsub_rn(__fmul_rn(roi[2], (float)gh_map), 0.5f);
+            const float x1 = __fsub_rn(__fmul_rn(roi[3], (float)gw_map), 0.5f), y1 = __fsub_rn(__fmul_rn(roi[4], (float)gh_map), 0.5f);
+            const float rw = __fsub_rn(x1, x0), rh = __fsub_rn(y1, y0);
+            const int gh = (int)ceilf(rh), gw = (int)ceilf(rw);
+            if (gh <= 0 || gw <= 0) continue;
+            const float wy = axis_weight_at(y0, rh, gh, gh_map, r);
             if (wy == 0.f) continue;
-            for (int c = 0; c < gw_map; ++c) {
-                const float w = wy * Wx[c];
-                if (w != 0.f) unsafeAtomicAdd(fb + (size_t)(r * gw_map + c) * E + ch, w * gv);
+            const int cnt = gh * gw;
+            const float inv_count = 1.f / (float)(cnt > 1 ? cnt : 1);
+            __syncthreads();                               // the previous box's Wxs has been consumed
+            if (tid < RB_CELLS) Wxs[tid] = c0 + tid < gw_map ? axis_weight_at(x0, rw, gw, gw_map, c0 + tid) : 0.f;
+            __syncthreads();
+            float gv[RB_EPT];
+#pragma unroll
+            for (int j = 0; j < RB_EPT; ++j) {
+                const int ch = tid + 256 * j;
+                gv[j] = ch < E ? dpooled[(size_t)list[n] * E + ch] * inv_count : 0.f;
             }
+#pragma unroll
+            for (int c = 0; c < RB_CELLS; ++c) {
+                const float w = wy * Wxs[c];
+                if (w != 0.f) {
+#pragma unroll
+                    for (int j = 0; j < RB_EPT; ++j) acc[c][j] += w * gv[j];
+                }
+            }
+        }
+        __syncthreads();                                   // list / wave_cnt are rewritten by the next chunk
+    }
+#pragma unroll
+    for (int c = 0; c < RB_CELLS; ++c) {
+        float* cell = dfeat + ((size_t)b * Ntok + tok_off + (size_t)r * gw_map + min(c0 + c, gw_map - 1)) * E;
+#pragma unroll
+        for (int j = 0; j < RB_EPT; ++j) {
+            const int ch = tid + 256 * j;
+            if (c0 + c < gw_map && ch < E && acc[c][j] != 0.f) cell[ch] += acc[c][j];
         }
     }
 }
@@ -159,12 +228,16 @@ extern "C" int cs_roialign_fwd(const float* feat, const float* rois, float* pool
     CS_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int cs_roialign_bwd(const float* dpooled, const float* rois, float* dfeat, int K, int Ntok, int grid_h, int grid_w, int E,
+// dfeat [B, Ntok, E] f32 += the gradient of every box (the caller zeroes it, or accumulates); B = images in the map.  Deterministic: a
+// gather per map cell over the image's boxes in ascending box order, no atomics.
+extern "C" int cs_roialign_bwd(const float* dpooled, const float* rois, float* dfeat, int K, int B, int Ntok, int grid_h, int grid_w, int E,
                                int tok_off, hipStream_t stream) {
     CS_CHECK_ARG(grid_h > 0 && grid_w > 0 && grid_h <= MAXGRID && grid_w <= MAXGRID, "cs_roialign_bwd: bad grid");
     CS_CHECK_ARG(tok_off + grid_h * grid_w <= Ntok, "cs_roialign_bwd: grid does not fit the token map");
+    CS_CHECK_ARG(B > 0 && B <= 65535 && E > 0 && E <= 256 * RB_EPT, "cs_roialign_bwd: B=%d images (1..65535), E=%d channels (<= %d)", B, E, 256 * RB_EPT);
     if (K == 0) return 0;
-    hipLaunchKernelGGL(roialign_bwd_kernel, dim3(K), dim3(256), 0, stream, dpooled, rois, dfeat, Ntok, grid_h, grid_w, E, tok_off);
+    hipLaunchKernelGGL(roialign_bwd_gather_kernel, dim3((grid_w + RB_CELLS - 1) / RB_CELLS, grid_h, B), dim3(256), 0, stream, dpooled, rois,
+                       dfeat, K, Ntok, grid_h, grid_w, E, tok_off);
     CS_LAUNCH_CHECK();
     return 0;
 }

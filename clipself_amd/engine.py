@@ -87,6 +87,7 @@ def is_no_decay(name: str, ndim: int) -> bool:
 
 class EvaEngine:
     BLOCK_TAG = "blocks."                     # state-dict name of the block list below the tower prefix
+    FP8_MAX_ROW = 4096                        # widest row cs_quant_rows_fp8 quantises (one row per wave, held in registers)
 
     def _layout(self):
         return param_groups_layout(self.cfg, self.prefix)
@@ -283,6 +284,13 @@ class EvaEngine:
             self.w8[(i, "w3")] = self._fp8_rows(self.storage_of(self.shadow, b + "mlp.w3.weight"))
 
     def enable_fp8_forward(self, on: bool = True):
+        if on and not self.trainable:
+            raise RuntimeError("fp8 forward operands belong to the training schedule; a frozen tower keeps its bf16 operands "
+                               "(teacher targets and evaluation features must not depend on the run's precision flag)")
+        widest = max(self.cfg.width, self.Hp)
+        if on and widest > self.FP8_MAX_ROW:
+            raise NotImplementedError(f"amp_fp8: cs_quant_rows_fp8 keeps a row in registers and covers rows up to {self.FP8_MAX_ROW} wide; "
+                                      f"this tower's widest GEMM operand is {widest}")
         self.fp8_forward = bool(on)
         self.w8 = {}
         if on:

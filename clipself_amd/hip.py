@@ -59,7 +59,7 @@ SIGNATURES = {
     "cs_im2row": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "cs_cls_row": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "cs_roialign_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "cs_roialign_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "cs_roialign_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "cs_cosine_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "cs_cosine_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     "cs_fed_bce_fwd": (_i, [_vp, _l, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
@@ -186,7 +186,8 @@ class HipOps:
         M, K = A.shape
         N = B.shape[0]
         assert hi.dtype == torch.bfloat16 and lo.dtype == torch.int16 and hi.shape == (M, N) and lo.shape == (M, N)
-        assert hi.stride(1) == 1 and lo.stride(1) == 1 and hi.stride(0) == lo.stride(0)
+        assert hi.stride(1) == 1 and lo.stride(1) == 1 and hi.stride(0) == lo.stride(0) and hi.stride(0) % 8 == 0
+        assert x_out is None or stats_part is None, "fp32 out: hi / lo are only read, no statistics epilogue"
         x = x_in if x_in is not None else x_out
         assert x is None or (x.dtype == torch.float32 and x.shape == (M, N) and x.stride(1) == 1)
         self._ok(self.lib.cs_gemm_nt_ln_split(_p(A), _p(B), _p(bias), _p(ln_mean), _p(ln_rstd), _p(ln_colsum), _p(x_in), _p(x_out), _p(hi), _p(lo),
@@ -396,7 +397,7 @@ class HipOps:
     def roialign_bwd(self, dpooled, rois, dfeat, grid_h, grid_w, tok_off):
         self._chk(dpooled, rois, dfeat)
         B, Ntok, E = dfeat.shape
-        self._ok(self.lib.cs_roialign_bwd(_p(dpooled), _p(rois), _p(dfeat), rois.shape[0], Ntok, grid_h, grid_w, E, tok_off,
+        self._ok(self.lib.cs_roialign_bwd(_p(dpooled), _p(rois), _p(dfeat), rois.shape[0], B, Ntok, grid_h, grid_w, E, tok_off,
                                           self._stream()), "cs_roialign_bwd")
 
     def cosine_loss_fwd(self, student, teacher, stats, loss, weight):

@@ -105,7 +105,10 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
         from ..init import seeded_visual_state
         logging.info(f"No checkpoint at {cache_dir!r}: {model_name} starts from the seeded random initialisation")
         model.visual.engine.load_state(seeded_visual_state(cfg, seed=0))
-    if fp8:
+    if fp8 and trainable:
+        # amp_fp8 applies to the TRAINING forward schedule (the student of configs[4]); frozen towers -- the CLIPSelf teacher, the
+        # end-of-epoch evaluation copy -- stay on bf16 operands, so distillation targets and evaluation features do not depend on
+        # the precision flag of the run
         model.visual.engine.enable_fp8_forward()
     return model
 

@@ -17,6 +17,7 @@ from typing import Optional, Sequence
 
 import numpy as np
 import torch
+import torch.utils.data
 
 OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)
 OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -30,7 +31,10 @@ def _triple(v, default):
 class ResizeLongestNormalize:
     """One image -> [3, size, size]: resize the longest side to `size` (bicubic, Pillow arithmetic), zero-pad to a square (centred for the
     crop transform, right/bottom for the det transform), /255, normalise.  `ops` = the kernel face (HipOps by default, created on first
-    use: needs a ROCm device); the result stays on the device the kernel ran on unless `output_device` says otherwise."""
+    use: needs a ROCm device); the result stays on the device the kernel ran on unless `output_device` says otherwise.
+    Input contract: a PIL image, or an HxWx3 uint8 array / tensor (channels LAST -- the reference's ResizeLongest takes CHW tensors).
+    The kernel runs in the calling process: not from DataLoader workers (it raises there).  Down-sampling is limited by the kernel's
+    filter-tap budget, max(H, W) * 4 + 1 <= 64 * size (about 16x at size 224); larger images raise instead of being resized."""
 
     def __init__(self, size: int, pad_center: bool, mean=None, std=None, ops=None, output_device=None):
         if isinstance(size, (list, tuple)):
@@ -63,6 +67,11 @@ class ResizeLongestNormalize:
         ops = self.ops
         u8 = self._as_u8(img)
         if getattr(ops, "name", "") == "hip":
+            if torch.utils.data.get_worker_info() is not None:
+                raise RuntimeError(
+                    "this transform runs the crop / resize kernel on the GPU and cannot be called from a DataLoader worker process (a forked "
+                    "worker cannot re-initialise the device): use num_workers=0 with it, or the batch loaders of clipself_amd.training.data "
+                    "(GpuGridDistillLoader / GpuProposalDistillLoader), which decode on host threads and crop on the GPU")
             u8 = u8.cuda(non_blocking=True)
         H, W = u8.shape[0], u8.shape[1]
         box = torch.tensor([[0.0, 0.0, float(W), float(H)]], device=u8.device)

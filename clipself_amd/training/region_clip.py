@@ -78,9 +78,10 @@ class RegionCLIP(nn.Module):
         labels = sel[:, 4].long()
         box_features = model.encode_pseudo_boxes(images, rois, normalize=True, extract_type=getattr(args, "extract_type", "v2"))
         temp = model.logit_scale.exp().detach()
-        # the kernels take the temperature as a launch argument: read it back only when logit_scale actually changed (it receives no
-        # gradient in this method -- `.detach()` above -- so that is once)
-        ver = (id(model.logit_scale), model.logit_scale._version)
+        # the kernels take the temperature as a launch argument: read it back only when logit_scale was written in place (it receives no
+        # gradient in this method -- `.detach()` above -- and train_step's per-step clamp skips a parameter without a gradient, so that is
+        # once per run; load_state_dict / copy_ bump the version, writes through `.data` must be followed by `_temp_cache = None`)
+        ver = (id(model.logit_scale), model.logit_scale.data_ptr(), model.logit_scale._version)
         if getattr(self, "_temp_cache", (None, None))[0] != ver:
             self._temp_cache = (ver, float(temp))
         temp_f = self._temp_cache[1]

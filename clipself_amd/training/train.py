@@ -66,7 +66,12 @@ def train_step(model, method, batch, optimizer, scheduler, step, dist_model, arg
         torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], args.grad_clip_norm * scale, norm_type=2.0)
     optimizer.step()
     with torch.no_grad():
-        unwrap_model(model).logit_scale.clamp_(0, math.log(100))
+        # train.py:118-119 clamps every step.  A clamp of an unchanged, in-range scalar is the identity; skipping it then keeps the parameter's
+        # version counter still, which RegionCLIP uses to read the temperature back from the device once instead of every step.
+        ls = unwrap_model(model).logit_scale
+        if ls.grad is not None or not getattr(ls, "_cs_clamped_once", False):
+            ls.clamp_(0, math.log(100))
+            ls._cs_clamped_once = True
     return losses, batch_size, logit_scale
 
 

@@ -83,8 +83,10 @@ int cs_gemm_nt_ln(const void* A, const void* B, void* C, const float* bias, cons
  * A residual GEMM then moves 8 bytes per stream element (4 in, 4 out) instead of 10 (fp32 in, fp32 out, bf16 copy) and nothing is lost.
  *   x_in  != NULL: the stream is read as fp32 [M, ldc] (first block, after the stem);  NULL: as (hi, lo)
  *   x_out != NULL: it is written as fp32 [M, ldc] (last folded block; hi / lo are only read);  NULL: back to (hi, lo), in place
- *   stats_part: per 64-column slice (sum, sum of squares) of the fp32 outputs as in cs_gemm_nt_ln; required unless x_out != NULL.
- * out = x + rstd[m] * (A.B^T - mean[m] * ln_colsum[n]) + bias[n];  N % 32 == 0, K % 64 == 0; flags bits 20-26 as cs_gemm_nt. */
+ *   stats_part: per 64-column slice (sum, sum of squares) of the fp32 outputs as in cs_gemm_nt_ln; required when the stream leaves
+ *               split (x_out == NULL), rejected with x_out != NULL.
+ * out = x + rstd[m] * (A.B^T - mean[m] * ln_colsum[n]) + bias[n];  N % 32 == 0, K % 64 == 0; hi / lo 16-byte aligned with ldxb % 8 == 0
+ * (the planes move in 16-byte pieces); flags bits 20-26 as cs_gemm_nt. */
 int cs_gemm_nt_ln_split(const void* A, const void* B, const float* bias, const float* ln_mean, const float* ln_rstd,
                         const float* ln_colsum, const float* x_in, float* x_out, void* hi, void* lo, int ldxb, float* stats_part,
                         int M, int N, int K, int lda, int ldb, int ldc, int flags, cs_stream_t stream);
@@ -150,7 +152,9 @@ int cs_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok, in
  *     eva_vit_model.py:628-629 with boxes from _denormalize_boxes :655-664 (boxes given normalised to [0,1]). */
 int cs_roialign_fwd(const float* feat, const float* rois, float* pooled, int K, int Ntok, int grid_h, int grid_w, int E,
                     int tok_off, cs_stream_t stream);
-int cs_roialign_bwd(const float* dpooled, const float* rois, float* dfeat, int K, int Ntok, int grid_h, int grid_w, int E,
+/* backward: dfeat [B, Ntok, E] += the boxes' gradients; a gather per map cell over the image's boxes in ascending box order (no atomics:
+ * bit-reproducible, unlike torchvision's atomicAdd scatter); E <= 1024 */
+int cs_roialign_bwd(const float* dpooled, const float* rois, float* dfeat, int K, int B, int Ntok, int grid_h, int grid_w, int E,
                     int tok_off, cs_stream_t stream);
 
 /* --- cosine distillation loss: src/training/clipself.py:42-47.  stats [K,3] f32 workspace kept for the backward. */

@@ -185,6 +185,88 @@ def encode_image(sd, cfg, images, emulate_bf16=False, prefix="visual."):
     return x @ rq(sd[prefix + "head.weight"]).T + sd[prefix + "head.bias"]
 
 
+# ----------------------------------------------------------------------------
+# bf16 emulation at the FROZEN tower's own rounding points
+# ----------------------------------------------------------------------------
+def _plane_round(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> the bf16 value held by the `hi` plane of the split residual stream: upper half of bits(x) + 0x8000, i.e. round to
+    nearest with halves away from zero (include/clipself_hip.h, cs_gemm_nt_ln_split)."""
+    y = (x.float().contiguous().view(torch.int32) + 0x8000) & ~0xFFFF
+    return y.view(torch.float32)
+
+
+def _folded_linear(a_bf16, stats_of, ln_w, ln_b, W, b, eps, rq):
+    """LayerNorm(z) . W^T + b the way the frozen tower evaluates it (engine._build_folds / cs_gemm_nt_ln): the GEMM contracts the
+    UN-normalised bf16 rows `a_bf16` with bf16(gamma (.) W); the row statistics (of `stats_of`, fp32) and beta enter in the fp32 epilogue:
+    rstd * (acc - mean * colsum) + (W . beta + b).  Same function as eva_vit_model.py:102-103,218-219,306-307 up to where bf16 rounds."""
+    Wf = rq(W * ln_w[None, :])
+    colsum = Wf.sum(dim=1)
+    d = W @ ln_b + b
+    mean = stats_of.mean(-1, keepdim=True)
+    var = (stats_of * stats_of).mean(-1, keepdim=True) - mean * mean
+    rstd = torch.rsqrt(var + eps)
+    return rstd * (a_bf16 @ Wf.T - mean * colsum) + d
+
+
+def encode_image_frozen_schedule(sd, cfg, images, prefix="visual."):
+    """encode_image() with bf16 rounding exactly where the frozen (teacher) schedule of the HIP path rounds -- an independent restatement of
+    that schedule's ARITHMETIC, not of its code (clipself_amd/engine.py: _teacher_block_folded, _block_fwd_cls):
+      * operands of every GEMM bf16, accumulation and epilogues fp32, q|k|v / attention output / SwiGLU hidden stored bf16;
+      * the four LayerNorms of a block are folded into the following GEMM (_folded_linear): norm1 / norm2 see the residual stream rounded
+        half-away-from-zero (the split stream's hi plane) with the statistics of its fp32 values; inner_attn_ln / ffn_ln see the stored
+        bf16 activations with the statistics of those rounded values; block 0 keeps a plain norm1 and the last block is unfolded;
+      * SiLU(x1) * x2 is formed from the fp32 accumulators (x1 / x2 are never stored), unlike emulate_bf16=True above, which rounds them
+        as the training schedule does.
+    Against this oracle the kernels' own error is what is left (summation order + the rounding flips it triggers); against
+    encode_image(emulate_bf16=True) the different rounding points alone move the features by ~5e-3 (profiles/r03_parity.md)."""
+    rq = _Round(True)
+    eps = cfg.ln_eps
+    x, g = stem(sd, cfg, images, rq, prefix)
+    cos, sin = rope_tables(g, cfg.head_width, cfg.pt_hw_seq_len)
+    B, N, C = x.shape
+    H, d = cfg.heads, cfg.head_width
+    L = cfg.layers
+
+    def attention_core(q, k, v):
+        q, k, v = (rq(t).reshape(B, N, H, d).permute(0, 2, 1, 3) for t in (q, k, v))
+        q, k = rq(apply_rope(q, cos, sin)), rq(apply_rope(k, cos, sin))
+        att = ((q * (d ** -0.5)) @ k.transpose(-2, -1)).softmax(dim=-1)
+        return rq((rq(att) @ v).transpose(1, 2).reshape(B, N, C))
+
+    for i in range(L):
+        blk = f"{prefix}blocks.{i}."
+        wqkv = torch.cat([sd[blk + "attn.q_proj.weight"], sd[blk + "attn.k_proj.weight"], sd[blk + "attn.v_proj.weight"]])
+        bqkv = torch.cat([sd[blk + "attn.q_bias"], torch.zeros_like(sd[blk + "attn.q_bias"]), sd[blk + "attn.v_bias"]])
+        w12 = torch.cat([sd[blk + "mlp.w1.weight"], sd[blk + "mlp.w2.weight"]])
+        b12 = torch.cat([sd[blk + "mlp.w1.bias"], sd[blk + "mlp.w2.bias"]])
+        Hd = sd[blk + "mlp.w1.weight"].shape[0]
+        folded = i < L - 1                                        # the CLS-only last block runs the plain schedule
+        if i == 0 or not folded:
+            n1 = rq(layer_norm(x, sd[blk + "norm1.weight"], sd[blk + "norm1.bias"], eps))
+            qkv = n1 @ rq(wqkv).T + bqkv
+        else:
+            qkv = _folded_linear(_plane_round(x), x, sd[blk + "norm1.weight"], sd[blk + "norm1.bias"], wqkv, bqkv, eps, rq)
+        o = attention_core(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:])
+        if folded:
+            x = x + _folded_linear(o, o, sd[blk + "attn.inner_attn_ln.weight"], sd[blk + "attn.inner_attn_ln.bias"],
+                                   sd[blk + "attn.proj.weight"], sd[blk + "attn.proj.bias"], eps, rq)
+            x12 = _folded_linear(_plane_round(x), x, sd[blk + "norm2.weight"], sd[blk + "norm2.bias"], w12, b12, eps, rq)
+        else:
+            o = rq(layer_norm(o, sd[blk + "attn.inner_attn_ln.weight"], sd[blk + "attn.inner_attn_ln.bias"], eps))
+            x = x + (o @ rq(sd[blk + "attn.proj.weight"]).T + sd[blk + "attn.proj.bias"])
+            n2 = rq(layer_norm(x, sd[blk + "norm2.weight"], sd[blk + "norm2.bias"], eps))
+            x12 = n2 @ rq(w12).T + b12
+        h = rq(F.silu(x12[..., :Hd]) * x12[..., Hd:])
+        if folded:
+            x = x + _folded_linear(h, h, sd[blk + "mlp.ffn_ln.weight"], sd[blk + "mlp.ffn_ln.bias"], sd[blk + "mlp.w3.weight"],
+                                   sd[blk + "mlp.w3.bias"], eps, rq)
+        else:
+            h = rq(layer_norm(h, sd[blk + "mlp.ffn_ln.weight"], sd[blk + "mlp.ffn_ln.bias"], eps))
+            x = x + (h @ rq(sd[blk + "mlp.w3.weight"]).T + sd[blk + "mlp.w3.bias"])
+    x = rq(layer_norm(x, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], eps))[:, 0]
+    return x @ rq(sd[prefix + "head.weight"]).T + sd[prefix + "head.bias"]
+
+
 def encode_dense(sd, cfg, images, emulate_bf16=False, prefix="visual."):
     """Student dense path -> L2-normalised token map [B, g*g, E] (eva_vit_model.py:588-623)."""
     rq = _Round(emulate_bf16)

@@ -82,3 +82,46 @@ def test_factory_precision_amp_fp8_switches_the_engine():
     q, s = eng.w8[(0, "w3")]
     assert q.dtype == torch.uint8 and q.shape == (768, 2048) and s.shape == (768,)
     assert not create_model("EVA02-CLIP-B-16", "eva", precision="amp_bf16", cache_dir=None, ops=RefOps()).visual.engine.fp8_forward
+
+
+def test_factory_enables_fp8_for_the_student_only():
+    """`--precision amp_fp8` builds the CLIPSelf teacher and the evaluation copy with the same precision string (training/main.py); a frozen
+    tower must keep its bf16 operands -- distillation targets and evaluation features may not depend on the run's precision flag -- and
+    allocates no e4m3 shadows.  Only the trainable student switches its forward linears to fp8."""
+    from clipself_amd.open_clip import factory
+    from clipself_amd.open_clip.model import CustomCLIP
+    cfg = tiny_cfg()
+    made = {}
+
+    def fake_cfg(name):
+        return cfg
+    orig = factory.get_tower_cfg
+    factory.get_tower_cfg = fake_cfg
+    try:
+        for trainable in (False, True):
+            made[trainable] = factory.create_model("tiny", "eva", precision="amp_fp8", ops=RefOps(), trainable=trainable)
+        plain = factory.create_model("tiny", "eva", precision="amp", ops=RefOps(), trainable=False)
+    finally:
+        factory.get_tower_cfg = orig
+    assert isinstance(made[False], CustomCLIP)
+    assert not made[False].visual.engine.fp8_forward and not made[False].visual.engine.w8
+    assert made[True].visual.engine.fp8_forward and made[True].visual.engine.w8
+    _, _, crops = synthetic_batch(2, 3, cfg.image_size, cfg.image_size, seed=9)
+    with torch.no_grad():
+        a = made[False].encode_image(crops.flatten(0, 1), normalize=False)
+        b = plain.encode_image(crops.flatten(0, 1), normalize=False)
+    assert torch.equal(a, b), "teacher features must be bit-identical with and without amp_fp8"
+    import pytest
+    with pytest.raises(RuntimeError):
+        made[False].visual.engine.enable_fp8_forward()
+
+
+def test_fp8_rejects_rows_wider_than_the_quantiser_covers():
+    import dataclasses
+    import pytest
+    from clipself_amd.engine import EvaEngine
+    cfg = tiny_cfg()
+    eng = EvaEngine(cfg, RefOps(), trainable=True)
+    eng.FP8_MAX_ROW = 16
+    with pytest.raises(NotImplementedError):
+        eng.enable_fp8_forward()

@@ -518,6 +518,30 @@ def test_roialign_fwd_bwd(hip, ref, grid, E):
     check(f"roialign[{grid}].fwd", pd, pr, TOL_F32)
     check(f"roialign[{grid}].bwd", dfd, dfr, TOL_F32)
     assert float(dfd[:, 0].abs().max()) == 0.0          # CLS rows never receive gradient
+    # the backward is a gather in a fixed order: bit-reproducible, and "+=" onto what the caller left in dfeat
+    again = torch.zeros(B, Ntok, E, device="cuda")
+    hip.roialign_bwd(dp.cuda(), rois.cuda(), again, grid, grid, 1)
+    assert torch.equal(again, dfd)
+    hip.roialign_bwd(dp.cuda(), rois.cuda(), again, grid, grid, 1)
+    check(f"roialign[{grid}].bwd accumulates", again, 2 * dfr, TOL_F32)
+
+
+def test_roialign_bwd_is_deterministic_at_step_size(hip):
+    """BASELINE configs[1]'s pooling problem (64 images x 32 heavily overlapping boxes on the 14 x 14 map, E = 512): two backward passes
+    give identical bits (torchvision's / round 2's atomic scatter differed run to run by ~3e-4 relative)."""
+    B, per, grid, E = 64, 32, 14, 512
+    g = torch.Generator().manual_seed(5)
+    xy0 = torch.rand(B * per, 2, generator=g) * 0.6
+    wh = torch.rand(B * per, 2, generator=g) * 0.3 + 0.1
+    rois = torch.cat([torch.arange(B).repeat_interleave(per)[:, None].float(), xy0, (xy0 + wh).clamp(max=1.0)], dim=1).cuda()
+    dp = torch.randn(B * per, E, generator=g).cuda()
+    outs = []
+    for _ in range(3):
+        d = torch.zeros(B, grid * grid + 1, E, device="cuda")
+        hip.roialign_bwd(dp, rois, d, grid, grid, 1)
+        outs.append(d)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert float(outs[0].abs().sum()) > 0.0
 
 
 def test_cosine_loss(hip, ref):
