@@ -222,6 +222,8 @@ def main():
                     help="A/B: keep the teacher's residual stream in fp32 + bf16 copy (10 B / element / residual GEMM) instead of the two 16-bit planes (8 B)")
     ap.add_argument("--no-block-ln-fold", action="store_true",
                     help="keep norm1 / norm2 of the teacher as LayerNorm kernels (only the two sub-LayerNorms folded; A/B switch)")
+    ap.add_argument("--bf16-grad-buckets", action="store_true",
+                    help="data parallel: all-reduce the gradient buckets in bf16 (half the xGMI bytes; CLIPSELF_GRAD_BUCKET_DTYPE=bf16)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher check without a GPU: the ranks rendezvous over gloo, all-reduce a one and rank 0 prints the world size")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -292,7 +294,8 @@ def main():
     teacher.eval()
     model, dist_model = student, teacher
     if distributed:
-        model, dist_model = StudentDataParallel(student), FrozenDataParallel(teacher)
+        model = StudentDataParallel(student, bucket_dtype=torch.bfloat16 if a.bf16_grad_buckets else None)
+        dist_model = FrozenDataParallel(teacher)
     opt = FlatAdamW(student, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, grad_divisor=float(world))
     sched = cosine_lr(opt, 1e-5, 1000, 100000)
     args = SimpleNamespace(device=device, precision="amp_bf16", distributed=distributed, skip_scheduler=False, grad_clip_norm=None,
@@ -318,6 +321,8 @@ def main():
         train_step(model, method, batches[step % 2], opt, sched, step, dist_model, args, next_batch=batches[(step + 1) % 2])
         step += 1
     sync()
+    if distributed:
+        model.reset_stats()
     timer.on = True
     t0 = time.perf_counter()
     last = None
@@ -327,10 +332,16 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     timer.on = False
+    comm = None
     if distributed:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        # what the step exchanged and how long AdamW stood behind it (max over ranks), and how many ranks the collective really spans
+        comm = model.comm_summary()
+        t = torch.tensor([elapsed, comm["grad_sync_wait_ms"]], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        elapsed, comm["grad_sync_wait_ms"] = float(t[0]), float(t[1])
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        comm["ranks_seen"] = int(ones.item())
     loss = last["loss"].detach().item() if last is not None else float("nan")
 
     if rank == 0:
@@ -363,6 +374,10 @@ def main():
                 iso = isolated_swiglu_gemm(teacher.visual.engine.ops, min(a.teacher_chunk, BATCH * CROPS) * cfg.tokens, cfg)
                 out["roofline"]["isolated"] = {"mean_us": iso, "achieved": kt["flops_per_launch"] / iso / 1e6,
                                                "frac": kt["flops_per_launch"] / iso / 1e6 / PEAK_BF16_TFLOPS}
+        if comm is not None:
+            # data-parallel diagnostics: bytes each rank hands to the all-reduce per step (a ring moves 2 (N-1)/N of them over every
+            # xGMI link), buckets, the exposed wait in front of AdamW, CUs the persistent GEMMs leave to RCCL's kernels
+            out["data_parallel"] = comm
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

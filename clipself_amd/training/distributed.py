@@ -87,15 +87,30 @@ def _reserve_for_collectives(module):
         ops.reserve_compute_units(rccl_reserved_cus())
 
 
+def grad_bucket_dtype() -> torch.dtype:
+    """Wire format of the gradient buckets (CLIPSELF_GRAD_BUCKET_DTYPE = fp32 | bf16, default fp32).  bf16 halves the bytes every ring step
+    moves over its xGMI link (168 MB instead of 336 MB per step for B/16) at the price of one bf16 rounding of each rank's partial sum:
+    the all-reduce then returns the SUM of the ranks' bf16-rounded gradients, accumulated by RCCL in bf16."""
+    v = os.environ.get("CLIPSELF_GRAD_BUCKET_DTYPE", "fp32").lower()
+    if v not in ("fp32", "bf16"):
+        raise ValueError(f"CLIPSELF_GRAD_BUCKET_DTYPE={v!r}: fp32 or bf16")
+    return torch.float32 if v == "fp32" else torch.bfloat16
+
+
 class StudentDataParallel(torch.nn.Module):
     """`.module`-carrying wrapper (the reference's methods unwrap it: clipself.py:8-10) that (1) broadcasts rank 0's
-    parameters once and (2) arms the engine's per-block grad-ready hook with asynchronous bucket all-reduces."""
+    parameters once and (2) arms the engine's per-block grad-ready hook with asynchronous bucket all-reduces.
 
-    def __init__(self, module, process_group=None):
+    `stats` counts what a step exchanged (buckets, bytes on the wire per rank) and how long the optimizer had to wait for the outstanding
+    buckets (`finish_grad_sync`: device events around the waits on a GPU, wall clock on CPU) -- bench.py prints them, so that a scaling
+    number can be read against its communication volume and exposed wait."""
+
+    def __init__(self, module, process_group=None, bucket_dtype=None):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        self.bucket_dtype = bucket_dtype if bucket_dtype is not None else grad_bucket_dtype()
         eng = module.visual.engine
         dist.broadcast(eng.master, src=0, group=process_group)
         with torch.no_grad():
@@ -103,19 +118,68 @@ class StudentDataParallel(torch.nn.Module):
         eng.sync_shadow()
         _reserve_for_collectives(module)
         self._pending = []
+        self._wire = None                      # bf16 staging buffer of the flat gradient (bucket_dtype == bf16)
+        self.stats = dict(steps=0, buckets=0, bytes=0, wait_ms=0.0)
+        self._wait_events = []
         if eng.trainable:
             eng.grad_ready_hook = self._on_block_ready
 
     def _on_block_ready(self, block: int):
         eng = self.module.visual.engine
         lo, hi = eng.block_ranges[block]
-        self._pending.append(dist.all_reduce(eng.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        g = eng.grad[lo:hi]
+        if self.bucket_dtype == torch.float32:
+            buf = g
+        else:
+            if self._wire is None:
+                self._wire = torch.empty(eng.grad.numel(), dtype=self.bucket_dtype, device=eng.grad.device)
+            buf = self._wire[lo:hi]
+            if hasattr(eng.ops, "cast_f32_bf16") and g.is_cuda:
+                eng.ops.cast_f32_bf16(g, buf)
+            else:
+                buf.copy_(g)
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((work, lo, hi))
+        self.stats["buckets"] += 1
+        self.stats["bytes"] += buf.numel() * buf.element_size()
 
     def finish_grad_sync(self):
         """Make the current stream wait for every outstanding bucket (call before the optimizer step)."""
-        for h in self._pending:
-            h.wait()
+        eng = self.module.visual.engine
+        on_gpu = eng.grad.is_cuda
+        if on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        else:
+            import time
+            t0 = time.perf_counter()
+        for work, lo, hi in self._pending:
+            work.wait()
+            if self.bucket_dtype != torch.float32:
+                eng.grad[lo:hi].copy_(self._wire[lo:hi])          # back to the fp32 accumulator AdamW reads
         self._pending.clear()
+        if on_gpu:
+            e1.record()
+            self._wait_events.append((e0, e1))
+        else:
+            self.stats["wait_ms"] += 1e3 * (time.perf_counter() - t0)
+        self.stats["steps"] += 1
+
+    def reset_stats(self):
+        self.stats = dict(steps=0, buckets=0, bytes=0, wait_ms=0.0)
+        self._wait_events = []
+
+    def comm_summary(self):
+        """Per-step communication figures of this rank since the last reset_stats(): buckets, bytes handed to the all-reduce, exposed wait
+        (the time the stream that runs AdamW stood behind unfinished buckets).  Synchronises the device events."""
+        if self._wait_events:
+            torch.cuda.synchronize()
+            self.stats["wait_ms"] += sum(a.elapsed_time(b) for a, b in self._wait_events)
+            self._wait_events = []
+        n = max(self.stats["steps"], 1)
+        return dict(allreduce_buckets_per_step=self.stats["buckets"] / n, allreduce_bytes_per_step=self.stats["bytes"] / n,
+                    grad_sync_wait_ms=self.stats["wait_ms"] / n, grad_bucket_dtype="fp32" if self.bucket_dtype == torch.float32 else "bf16",
+                    rccl_reserved_cus=rccl_reserved_cus() if (self.world > 1 or os.environ.get("CLIPSELF_FORCE_DIST") == "1") else 0)
 
     def forward(self, *a, **k):
         return self.module(*a, **k)

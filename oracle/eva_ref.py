@@ -30,7 +30,12 @@ this restatement against the captured outputs (tests/golden/*.npz).
 ``emulate_bf16=True`` rounds tensors to bf16 at the points where the HIP path
 stores bf16 (GEMM operands, LN outputs, q/k/v, attention output, hidden), with
 a straight-through gradient, to give the "bf16 reference" the north star's
-1e-3 tolerance is quoted against.
+1e-3 tolerance is quoted against.  ``emulate_bf16="kernel"`` and
+``encode_image_frozen_schedule`` / ``frozen_block`` move those points to exactly
+where the kernels of the training / frozen schedule round (un-normalised
+attention probabilities, folded LayerNorms on the split stream, fused
+SiLU*mul): where bf16 rounds accounts for ~5e-3 of the distance between two
+bf16 evaluations of the tower (tests/test_gpu_parity.py, profiles/r03_parity.md).
 """
 from __future__ import annotations
 
@@ -47,8 +52,13 @@ from .roi_align_ref import roi_align_1x1
 # rounding hook
 # ----------------------------------------------------------------------------
 class _Round:
-    def __init__(self, on: bool):
-        self.on = on
+    """emulate_bf16 = False | True | "kernel".  True rounds at the generic points listed in the module docstring; "kernel" additionally
+    moves the attention's probability rounding to where the HIP attention kernels round: the UN-normalised exp(s - max) is what goes to
+    the P.V MFMA in bf16 and the fp32 row sum divides afterwards (csrc/attention.hip), instead of rounding softmax(s)."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+        self.kernel_points = on == "kernel"
 
     def __call__(self, t: torch.Tensor) -> torch.Tensor:
         if not self.on:
@@ -135,8 +145,12 @@ def attention(sd, cfg, x, blk, cos, sin, rq):
     q = rq(apply_rope(q, cos, sin))
     k = rq(apply_rope(k, cos, sin))
     att = (q * (d ** -0.5)) @ k.transpose(-2, -1)
-    att = att.softmax(dim=-1)
-    o = (rq(att) @ v).transpose(1, 2).reshape(B, N, C)
+    if rq.kernel_points:
+        e = torch.exp(att - att.amax(dim=-1, keepdim=True))
+        o = ((rq(e) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, N, C)
+    else:
+        att = att.softmax(dim=-1)
+        o = (rq(att) @ v).transpose(1, 2).reshape(B, N, C)
     o = rq(o)
     o = rq(layer_norm(o, sd[blk + "attn.inner_attn_ln.weight"], sd[blk + "attn.inner_attn_ln.bias"], cfg.ln_eps))
     return o @ rq(sd[blk + "attn.proj.weight"]).T + sd[blk + "attn.proj.bias"]
@@ -208,7 +222,48 @@ def _folded_linear(a_bf16, stats_of, ln_w, ln_b, W, b, eps, rq):
     return rstd * (a_bf16 @ Wf.T - mean * colsum) + d
 
 
-def encode_image_frozen_schedule(sd, cfg, images, prefix="visual."):
+def frozen_block(sd, cfg, x, i, cos, sin, folded=True, fold_norm1=True, prefix="visual."):
+    """One block of the frozen (teacher) tower with bf16 rounding exactly where the HIP schedule rounds (see
+    encode_image_frozen_schedule).  x fp32 [B, N, C] -> fp32 [B, N, C].  folded=False: the plain schedule of the CLS-only last block;
+    fold_norm1=False: block 0, whose norm1 is a LayerNorm kernel."""
+    rq = _Round("kernel")
+    eps = cfg.ln_eps
+    B, N, C = x.shape
+    H, d = cfg.heads, cfg.head_width
+    blk = f"{prefix}blocks.{i}."
+    wqkv = torch.cat([sd[blk + "attn.q_proj.weight"], sd[blk + "attn.k_proj.weight"], sd[blk + "attn.v_proj.weight"]])
+    bqkv = torch.cat([sd[blk + "attn.q_bias"], torch.zeros_like(sd[blk + "attn.q_bias"]), sd[blk + "attn.v_bias"]])
+    w12 = torch.cat([sd[blk + "mlp.w1.weight"], sd[blk + "mlp.w2.weight"]])
+    b12 = torch.cat([sd[blk + "mlp.w1.bias"], sd[blk + "mlp.w2.bias"]])
+    Hd = sd[blk + "mlp.w1.weight"].shape[0]
+    if not (folded and fold_norm1):
+        n1 = rq(layer_norm(x, sd[blk + "norm1.weight"], sd[blk + "norm1.bias"], eps))
+        qkv = n1 @ rq(wqkv).T + bqkv
+    else:
+        qkv = _folded_linear(_plane_round(x), x, sd[blk + "norm1.weight"], sd[blk + "norm1.bias"], wqkv, bqkv, eps, rq)
+    q, k, v = (rq(t).reshape(B, N, H, d).permute(0, 2, 1, 3) for t in (qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]))
+    q, k = rq(apply_rope(q, cos, sin)), rq(apply_rope(k, cos, sin))
+    att = (q * (d ** -0.5)) @ k.transpose(-2, -1)
+    e = torch.exp(att - att.amax(dim=-1, keepdim=True))          # un-normalised probabilities go to the P.V MFMA in bf16
+    o = rq(((rq(e) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, N, C))
+    if folded:
+        x = x + _folded_linear(o, o, sd[blk + "attn.inner_attn_ln.weight"], sd[blk + "attn.inner_attn_ln.bias"],
+                               sd[blk + "attn.proj.weight"], sd[blk + "attn.proj.bias"], eps, rq)
+        x12 = _folded_linear(_plane_round(x), x, sd[blk + "norm2.weight"], sd[blk + "norm2.bias"], w12, b12, eps, rq)
+    else:
+        o = rq(layer_norm(o, sd[blk + "attn.inner_attn_ln.weight"], sd[blk + "attn.inner_attn_ln.bias"], eps))
+        x = x + (o @ rq(sd[blk + "attn.proj.weight"]).T + sd[blk + "attn.proj.bias"])
+        n2 = rq(layer_norm(x, sd[blk + "norm2.weight"], sd[blk + "norm2.bias"], eps))
+        x12 = n2 @ rq(w12).T + b12
+    h = rq(F.silu(x12[..., :Hd]) * x12[..., Hd:])                 # x1 / x2 stay in the fp32 accumulators: never rounded on their own
+    if folded:
+        return x + _folded_linear(h, h, sd[blk + "mlp.ffn_ln.weight"], sd[blk + "mlp.ffn_ln.bias"], sd[blk + "mlp.w3.weight"],
+                                  sd[blk + "mlp.w3.bias"], eps, rq)
+    h = rq(layer_norm(h, sd[blk + "mlp.ffn_ln.weight"], sd[blk + "mlp.ffn_ln.bias"], eps))
+    return x + (h @ rq(sd[blk + "mlp.w3.weight"]).T + sd[blk + "mlp.w3.bias"])
+
+
+def encode_image_frozen_schedule(sd, cfg, images, prefix="visual.", return_stream=False):
     """encode_image() with bf16 rounding exactly where the frozen (teacher) schedule of the HIP path rounds -- an independent restatement of
     that schedule's ARITHMETIC, not of its code (clipself_amd/engine.py: _teacher_block_folded, _block_fwd_cls):
       * operands of every GEMM bf16, accumulation and epilogues fp32, q|k|v / attention output / SwiGLU hidden stored bf16;
@@ -216,55 +271,21 @@ def encode_image_frozen_schedule(sd, cfg, images, prefix="visual."):
         half-away-from-zero (the split stream's hi plane) with the statistics of its fp32 values; inner_attn_ln / ffn_ln see the stored
         bf16 activations with the statistics of those rounded values; block 0 keeps a plain norm1 and the last block is unfolded;
       * SiLU(x1) * x2 is formed from the fp32 accumulators (x1 / x2 are never stored), unlike emulate_bf16=True above, which rounds them
-        as the training schedule does.
+        as the training schedule does; the attention's P.V product takes the un-normalised exp(s - max) in bf16 (_Round("kernel")).
     Against this oracle the kernels' own error is what is left (summation order + the rounding flips it triggers); against
-    encode_image(emulate_bf16=True) the different rounding points alone move the features by ~5e-3 (profiles/r03_parity.md)."""
-    rq = _Round(True)
-    eps = cfg.ln_eps
+    encode_image(emulate_bf16=True) the different rounding points alone move the features by ~5e-3 (profiles/r03_parity.md).
+    return_stream: also the fp32 residual stream in front of every block ([L + 1] tensors, the last one is the tower's output stream)."""
+    rq = _Round("kernel")
     x, g = stem(sd, cfg, images, rq, prefix)
     cos, sin = rope_tables(g, cfg.head_width, cfg.pt_hw_seq_len)
-    B, N, C = x.shape
-    H, d = cfg.heads, cfg.head_width
     L = cfg.layers
-
-    def attention_core(q, k, v):
-        q, k, v = (rq(t).reshape(B, N, H, d).permute(0, 2, 1, 3) for t in (q, k, v))
-        q, k = rq(apply_rope(q, cos, sin)), rq(apply_rope(k, cos, sin))
-        att = ((q * (d ** -0.5)) @ k.transpose(-2, -1)).softmax(dim=-1)
-        return rq((rq(att) @ v).transpose(1, 2).reshape(B, N, C))
-
+    stream = [x]
     for i in range(L):
-        blk = f"{prefix}blocks.{i}."
-        wqkv = torch.cat([sd[blk + "attn.q_proj.weight"], sd[blk + "attn.k_proj.weight"], sd[blk + "attn.v_proj.weight"]])
-        bqkv = torch.cat([sd[blk + "attn.q_bias"], torch.zeros_like(sd[blk + "attn.q_bias"]), sd[blk + "attn.v_bias"]])
-        w12 = torch.cat([sd[blk + "mlp.w1.weight"], sd[blk + "mlp.w2.weight"]])
-        b12 = torch.cat([sd[blk + "mlp.w1.bias"], sd[blk + "mlp.w2.bias"]])
-        Hd = sd[blk + "mlp.w1.weight"].shape[0]
-        folded = i < L - 1                                        # the CLS-only last block runs the plain schedule
-        if i == 0 or not folded:
-            n1 = rq(layer_norm(x, sd[blk + "norm1.weight"], sd[blk + "norm1.bias"], eps))
-            qkv = n1 @ rq(wqkv).T + bqkv
-        else:
-            qkv = _folded_linear(_plane_round(x), x, sd[blk + "norm1.weight"], sd[blk + "norm1.bias"], wqkv, bqkv, eps, rq)
-        o = attention_core(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:])
-        if folded:
-            x = x + _folded_linear(o, o, sd[blk + "attn.inner_attn_ln.weight"], sd[blk + "attn.inner_attn_ln.bias"],
-                                   sd[blk + "attn.proj.weight"], sd[blk + "attn.proj.bias"], eps, rq)
-            x12 = _folded_linear(_plane_round(x), x, sd[blk + "norm2.weight"], sd[blk + "norm2.bias"], w12, b12, eps, rq)
-        else:
-            o = rq(layer_norm(o, sd[blk + "attn.inner_attn_ln.weight"], sd[blk + "attn.inner_attn_ln.bias"], eps))
-            x = x + (o @ rq(sd[blk + "attn.proj.weight"]).T + sd[blk + "attn.proj.bias"])
-            n2 = rq(layer_norm(x, sd[blk + "norm2.weight"], sd[blk + "norm2.bias"], eps))
-            x12 = n2 @ rq(w12).T + b12
-        h = rq(F.silu(x12[..., :Hd]) * x12[..., Hd:])
-        if folded:
-            x = x + _folded_linear(h, h, sd[blk + "mlp.ffn_ln.weight"], sd[blk + "mlp.ffn_ln.bias"], sd[blk + "mlp.w3.weight"],
-                                   sd[blk + "mlp.w3.bias"], eps, rq)
-        else:
-            h = rq(layer_norm(h, sd[blk + "mlp.ffn_ln.weight"], sd[blk + "mlp.ffn_ln.bias"], eps))
-            x = x + (h @ rq(sd[blk + "mlp.w3.weight"]).T + sd[blk + "mlp.w3.bias"])
-    x = rq(layer_norm(x, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], eps))[:, 0]
-    return x @ rq(sd[prefix + "head.weight"]).T + sd[prefix + "head.bias"]
+        x = frozen_block(sd, cfg, x, i, cos, sin, folded=i < L - 1, fold_norm1=i > 0, prefix=prefix)
+        stream.append(x)
+    out = rq(layer_norm(x, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], cfg.ln_eps))[:, 0]
+    out = out @ rq(sd[prefix + "head.weight"]).T + sd[prefix + "head.bias"]
+    return (out, stream) if return_stream else out
 
 
 def encode_dense(sd, cfg, images, emulate_bf16=False, prefix="visual."):

@@ -220,3 +220,31 @@ def test_split_residual_stream_is_lossless_and_changes_nothing(gold):
     xa2 = xa.clone()
     ops.gemm_nt_ln(A, B, xa2, bias=bias, extra=xa2, ln_mean=mean, ln_rstd=rstd, ln_colsum=cs, epi=6)
     assert torch.equal(out.view(torch.int32), xa2.view(torch.int32))
+
+
+def test_kernel_rounding_oracles_track_the_schedule_twin_and_the_reference(gold):
+    """oracle/eva_ref.py's bf16 emulation at the kernels' own rounding points (`encode_image_frozen_schedule`, `emulate_bf16="kernel"`) is an
+    independent restatement of what the HIP schedules compute: on the 2-block tiny tower it agrees with the engine driven by the
+    per-kernel references to <= 2e-3 (the generic `emulate_bf16=True` points sit 4e-3..9e-3 away -- where bf16 rounds is most of the
+    difference between two bf16 implementations), and it stays as close to the reference's fp32 golden as any bf16 evaluation."""
+    g, rec = gold
+    cfg = tiny_cfg()
+    sd = seeded_visual_state(cfg, rec["seed_w"])
+    images, boxes, crops = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"])
+    flat = crops.flatten(0, 1)
+    frozen = _engine(cfg, rec["seed_w"], False).encode_image(flat, chunk=4)
+    train_eng = _engine(cfg, rec["seed_w"], True)
+    dense, grid = train_eng.encode_dense(images, need_grad=True)          # the training forward (activations kept)
+    pooled = train_eng.roi_pool(dense, _rois(boxes), grid)
+    with torch.no_grad():
+        t_k = eva_ref.encode_image_frozen_schedule(sd, cfg, flat)
+        t_g = eva_ref.encode_image(sd, cfg, flat, emulate_bf16=True)
+        s_k = eva_ref.encode_pseudo_boxes(sd, cfg, images, [b[:, :4] for b in boxes], emulate_bf16="kernel")
+    assert rel(frozen, t_k) < 2e-3 < rel(frozen, t_g)
+    assert rel(pooled, s_k) < 2e-3
+    assert rel(t_k, g["teacher"]) < 2e-2 and rel(s_k, g["student_roi"]) < 2e-2
+    # the split stream's hi plane: round to nearest, halves away from zero; exact on bf16-representable values
+    x = torch.tensor([1.0, -1.0, 1.00390625, -1.00390625, 1.001953125, 1.005859375, 65280.0])      # ties: 1 + 2^-8 lies halfway to 1 + 2^-7
+    want = torch.tensor([1.0, -1.0, 1.0078125, -1.0078125, 1.0, 1.0078125, 65280.0])
+    assert torch.equal(eva_ref._plane_round(x), want)
+    assert float(x[2:3].to(torch.bfloat16)) == 1.0                                                    # RNE sends the tie to the even neighbour

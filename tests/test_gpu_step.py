@@ -332,6 +332,13 @@ def test_bench_rccl_single_rank_path():
     _log(f"bench RCCL single-rank path: {a['value']:.1f} img/s (plain {b['value']:.1f}), loss {a['config']['loss_last_step']:.6f} vs {b['config']['loss_last_step']:.6f}")
     assert a["n_gpus"] == 1 and a["config"]["parallelism"] == "dp1"
     assert abs(a["config"]["loss_last_step"] - b["config"]["loss_last_step"]) < 2e-4
+    # the data-parallel diagnostics that make a scaling number readable: 12 block buckets = the trainable parameters in fp32 (B/16:
+    # 84.9 M elements, 340 MB per step and rank), the wait AdamW stood behind them, the CUs left to RCCL, the ranks the collective spans
+    dp = a["data_parallel"]
+    _log(f"bench RCCL single-rank path, data_parallel = {dp}")
+    assert "data_parallel" not in b
+    assert dp["allreduce_buckets_per_step"] == 12 and dp["grad_bucket_dtype"] == "fp32" and dp["ranks_seen"] == 1
+    assert 3.3e8 < dp["allreduce_bytes_per_step"] < 3.5e8 and dp["grad_sync_wait_ms"] >= 0.0 and dp["rccl_reserved_cus"] == 16
 
 
 def test_teacher_prefetch_on_side_stream_equals_inline():
