@@ -122,6 +122,10 @@ class EvaEngine:
                 self.logical[name] = shape
                 off += math.prod(storage)
         self.numel = _round_up(off, 256)
+        # stem (cls_token, pos_embed, patch embedding) and head (final norm, head) slices of the flat store: two more gradient buckets
+        # when the whole tower trains (training without --lock-image)
+        self.stem_range = (0, self.block_ranges[0][0]) if self.block_ranges else (0, 0)
+        self.head_range = (self.block_ranges[-1][1], self.numel) if self.block_ranges else (0, self.numel)
         self.master = ops.zeros((self.numel,), F32)
         self.shadow = ops.zeros((self.numel,), BF16)
         self.device = self.master.device
@@ -135,6 +139,7 @@ class EvaEngine:
         self.g = {}
         self.wt = {}
         self.first_trainable = cfg.layers      # no block trainable until lock()/unlock is applied
+        self.train_all = False                 # stem + final norm + head train as well (set_trainable_all: training without --lock-image)
         self.grad_ready_hook = None            # callable(block_index) fired when a block's grads are complete
         self._ctx = None
         self._wgrad_ws = None
@@ -313,20 +318,42 @@ class EvaEngine:
         (blocks[-0:] is the whole list, as in the reference)."""
         L = self.cfg.layers
         self.first_trainable = L - unlocked_groups if 0 < unlocked_groups <= L else 0
+        self.train_all = False
+        self._set_flags()
+
+    def set_trainable_all(self):
+        """No lock at all (training.main without --lock-image, src/training/main.py:161-166): every parameter of the visual tower trains --
+        besides the blocks the stem (cls_token, pos_embed, patch_embed.proj), the final norm and the head, which the dense path
+        differentiates as well (eva_vit_model.py:537-544,615-623)."""
+        self.first_trainable = 0
+        self.train_all = True
+        self._set_flags()
+
+    def _set_flags(self):
         if not self.trainable:
             return
         self.flags.zero_()
-        for name, (o, s) in self.offsets.items():
+        names = list(self.offsets)
+        for k, name in enumerate(names):
+            o, s = self.offsets[name]
             i = self.block_index(name)
-            if i is None or "._" in name or i < self.first_trainable or self._never_reached(i, name):
+            if "._" in name or (i is None and not self.train_all) or (i is not None and (i < self.first_trainable or self._never_reached(i, name))):
                 continue
             n = math.prod(s)
-            assert o % 64 == 0 and n % 64 == 0, f"{name}: flag granularity"
-            self.flags[o // 64:(o + n) // 64] = 1 | (0 if is_no_decay(name, len(s)) else 2)
+            nxt = self.offsets[names[k + 1]][0] if k + 1 < len(names) else self.numel
+            n64 = _round_up(n, 64)            # a tensor that ends its 64-aligned allocation group short of a flag granule (tiny head.bias)
+            assert o % 64 == 0 and (n % 64 == 0 or o + n64 <= nxt), f"{name}: flag granularity"
+            self.flags[o // 64:(o + n64) // 64] = 1 | (0 if is_no_decay(name, len(self.logical[name])) else 2)
         self.sync_transposed()
 
     def trainable_names(self):
+        if self.train_all:
+            return self.public_names()
         return [n for n in self.public_names() if (self.block_index(n) if self.block_index(n) is not None else -1) >= self.first_trainable]
+
+    def bucket_range(self, key):
+        """Flat [begin, end) of a gradient bucket: a block index, "head" (final norm + head) or "stem" (cls_token, pos_embed, patch embedding)."""
+        return self.head_range if key == "head" else self.stem_range if key == "stem" else self.block_ranges[key]
 
     # ------------------------------------------------------------------------------------------ tables
     def rope_tables(self, grid: int):
@@ -357,7 +384,7 @@ class EvaEngine:
         return self._pos_cache[grid]
 
     # ------------------------------------------------------------------------------------------ forward pieces
-    def _stem(self, images):
+    def _stem(self, images, keep=None):
         ops, cfg, P = self.ops, self.cfg, self.prefix
         B, _, S, _ = images.shape
         p, C = cfg.patch_size, cfg.width
@@ -370,6 +397,8 @@ class EvaEngine:
         ops.gemm_nt(A, self.storage_of(self.shadow, P + "patch_embed.proj.weight"), x.view(B * N, C),
                     bias=self.p[P + "patch_embed.proj.bias"], extra=pos, epi=EPI_PATCH_F32, group=g * g)
         ops.cls_row(x, self.p[P + "cls_token"].view(C), pos)
+        if keep is not None:
+            keep["patches"] = A                  # operand of the patch-embedding weight gradient
         return x, g
 
     def _qkv_w(self, b):
@@ -586,7 +615,8 @@ class EvaEngine:
         With need_grad the activations of the trainable blocks are kept for backward_dense()."""
         ops, cfg, P = self.ops, self.cfg, self.prefix
         B = images.shape[0]
-        x, g = self._stem(images)
+        stem_keep = {} if (need_grad and self.train_all) else None
+        x, g = self._stem(images, stem_keep)
         N, C, E = g * g + 1, cfg.width, cfg.embed_dim
         cos, sin = self.rope_tables(g)
         xf = x.view(B * N, C)
@@ -608,7 +638,8 @@ class EvaEngine:
         inv = ops.empty((M,), F32)
         ops.l2norm_fwd(feats, dense, inv)
         if need_grad:
-            self._ctx = dict(B=B, N=N, g=g, saves=saves, xL=xf, stf=(mean, rstd), dense=dense, inv=inv, cos=cos, sin=sin)
+            self._ctx = dict(B=B, N=N, g=g, saves=saves, xL=xf, stf=(mean, rstd), dense=dense, inv=inv, cos=cos, sin=sin,
+                             lnf=lnf if self.train_all else None, patches=stem_keep["patches"] if stem_keep is not None else None)
         return dense.view(B, N, E), g
 
     def roi_pool(self, dense, rois, g):
@@ -715,15 +746,53 @@ class EvaEngine:
         d_feats = ops.empty((M, E), BF16)
         ops.l2norm_bwd(d_dense.reshape(M, E), c["dense"], c["inv"], d_feats)
         d_lnf = ops.empty((M, C), BF16)
-        ops.gemm_nt(d_feats, self.wt["head"][:, :E], d_lnf, epi=EPI_BF16)                  # head frozen: dgrad only
+        ops.gemm_nt(d_feats, self.wt["head"][:, :E], d_lnf, epi=EPI_BF16)                  # dgrad through the head
         g = ops.empty((M, C), F32)
-        ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "norm.weight"], *c["stf"], g, DX_F32_ASSIGN)   # final norm frozen
         ws_bytes = max(ops.layernorm_bwd_workspace(M, max(C, self.Hp)), ops.attn_bwd_workspace(B, N, cfg.heads))
         ws = ops.empty((ws_bytes,), torch.uint8)
+        if self.train_all:
+            # head (eva_vit_model.py:617) and final norm (:616) train: bias = column sums, weight = dY^T . LN(x), LayerNorm gamma / beta.
+            # The CLS rows of d_feats are exact zeros (the dense map drops them, :615), so they add nothing to any of the sums.
+            ops.colsum_bf16(d_feats, self.g[P + "head.bias"])
+            self._wgrad(d_feats, c["lnf"], self.g[P + "head.weight"])
+            ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "norm.weight"], *c["stf"], g, DX_F32_ASSIGN,
+                              self.g[P + "norm.weight"], self.g[P + "norm.bias"], True, ws)
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook("head")
+        else:
+            ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "norm.weight"], *c["stf"], g, DX_F32_ASSIGN)   # head and final norm frozen
         for i in range(cfg.layers - 1, self.first_trainable - 1, -1):
             self._block_bwd(i, c["saves"].pop(i), g, B, N, c["cos"], c["sin"], ws)
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook(i)
+        if self.train_all:
+            self._stem_bwd(g, c["patches"], B, N, c["g"])
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook("stem")
+
+    def _stem_bwd(self, g, patches, B, N, grid):
+        """Gradients of the stem from g = d loss / d (stem output) fp32 [B*N, C]  (eva_vit_model.py:537-544: x = cat(cls, conv(img)) + pos):
+        pos_embed <- sum over images (through the bicubic rescale for a non-native grid, :631-643), cls_token <- the CLS rows,
+        patch_embed.proj <- bias = column sums of the patch rows, weight = dY^T . im2row(images).  Runs once per step on [B*N, C]
+        tensors; the row bookkeeping (dropping the CLS rows, the sum over images) is plain tensor code, the contraction is the wgrad kernel."""
+        ops, cfg, P = self.ops, self.cfg, self.prefix
+        C = cfg.width
+        g3 = g.view(B, N, C)
+        d_pos = g3.sum(dim=0)                                                   # [N, C]
+        self.g[P + "cls_token"].view(C).add_(d_pos[0])
+        gpos = self.g[P + "pos_embed"][0]                                       # [native N, C]
+        if grid == cfg.grid:
+            gpos.add_(d_pos)
+        else:
+            gpos[0].add_(d_pos[0])
+            with torch.enable_grad():
+                pe = self.p[P + "pos_embed"].detach()[0, 1:].T.reshape(1, C, cfg.grid, cfg.grid).clone().requires_grad_(True)
+                out = F.interpolate(pe, (grid, grid), mode="bicubic", align_corners=False)
+                (d_pe,) = torch.autograd.grad(out, pe, d_pos[1:].T.reshape(1, C, grid, grid))
+            gpos[1:].add_(d_pe.reshape(C, cfg.grid * cfg.grid).T)
+        gp = g3[:, 1:, :].to(BF16).reshape(B * (N - 1), C)                      # patch rows, in the im2row matrix's row order
+        ops.colsum_bf16(gp, self.g[P + "patch_embed.proj.bias"])
+        self._wgrad(gp, patches, self.storage_of(self.grad, P + "patch_embed.proj.weight"))
 
     def roi_pool_backward(self, d_pooled, rois, B, N, g):
         d_dense = self.ops.zeros((B, N, self.cfg.embed_dim), F32)
@@ -737,5 +806,7 @@ class EvaEngine:
         self.ops.adamw_step(self.master, self.grad, self.exp_avg, self.exp_avg_sq, self.shadow, self.flags,
                             lr, beta1, beta2, eps, wd, step, grad_scale)
         self.sync_transposed()
+        if self.train_all:
+            self._pos_cache.clear()                # pos_embed moved: drop the rescaled copies of non-native grids
         if self.fp8_forward:
             self.sync_fp8(range(self.first_trainable, self.cfg.layers))

@@ -78,6 +78,7 @@ class _Node(nn.Module):
 class EVAVisionTower(_Node):
     """`model.visual`: EVA02 ViT (RoPE + SwiGLU + sub-LN) executing on the HIP engine."""
     ENGINE = EvaEngine
+    UNLOCKED_TRAINS_ALL = True                 # False: the tower only differentiates transformer blocks (OpenAI-CLIP ViT family)
 
     def __init__(self, cfg: TowerCfg, ops=None, trainable: bool = True, teacher_chunk: int = 2048):
         super().__init__()
@@ -99,6 +100,8 @@ class EVAVisionTower(_Node):
         self._register_tables()
         self._anchor = torch.zeros((), device=self.engine.device, requires_grad=True)
         self.grad_checkpointing = False
+        if trainable and hasattr(self.engine, "set_trainable_all") and self.UNLOCKED_TRAINS_ALL:
+            self.engine.set_trainable_all()       # the reference's state before lock_image_tower(): the whole visual tower trains
 
     def _register_tables(self):
         # the reference registers the RoPE tables as buffers of the tower and (shared module) of every attention
@@ -122,6 +125,14 @@ class EVAVisionTower(_Node):
         for full, p in self._flat.items():
             blk = self.engine.block_index(full)
             p.requires_grad = blk is not None and blk >= first
+
+    def unlock(self):
+        """Undo lock(): the whole tower trains again (the state a freshly built model is in, like the reference's)."""
+        if not self.UNLOCKED_TRAINS_ALL:
+            raise NotImplementedError("this tower family only differentiates its transformer blocks: lock it with unlocked_groups <= layers")
+        self.engine.set_trainable_all()
+        for p in self._flat.values():
+            p.requires_grad = True
 
     def set_grad_checkpointing(self, enable=True):
         self.grad_checkpointing = enable       # activations are kept; 288 GB of HBM makes recompute pointless here
@@ -309,6 +320,7 @@ class CustomCLIP(nn.Module):
 class ClipVisionTower(EVAVisionTower):
     """`model.visual` of the OpenAI-CLIP family: class/positional embeddings, ln_pre, fused-QKV blocks with a GELU MLP, ln_post, proj."""
     ENGINE = ClipVitEngine
+    UNLOCKED_TRAINS_ALL = False                # conv1 / class + positional embeddings / ln_pre / ln_post / proj stay frozen in this family
 
     def __init__(self, cfg: TowerCfg, ops=None, trainable: bool = True, teacher_chunk: int = 2048):
         super().__init__(cfg, ops=ops, trainable=trainable, teacher_chunk=teacher_chunk)

@@ -124,9 +124,9 @@ class StudentDataParallel(torch.nn.Module):
         if eng.trainable:
             eng.grad_ready_hook = self._on_block_ready
 
-    def _on_block_ready(self, block: int):
+    def _on_block_ready(self, block):
         eng = self.module.visual.engine
-        lo, hi = eng.block_ranges[block]
+        lo, hi = eng.bucket_range(block) if hasattr(eng, "bucket_range") else eng.block_ranges[block]     # block index, "head" or "stem"
         g = eng.grad[lo:hi]
         if self.bucket_dtype == torch.float32:
             buf = g

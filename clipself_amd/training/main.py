@@ -99,11 +99,13 @@ def main(argv):
     if args.lock_image:
         model.lock_image_tower(unlocked_groups=args.lock_image_unlocked_groups, freeze_bn_stats=args.lock_image_freeze_bn_stats)
     elif args.train_data:
-        # Without --lock-image the reference trains the whole visual tower (stem, positional embedding, final norm, head) plus
-        # logit_scale through the dense path; this engine differentiates transformer blocks only.  Every shipped recipe passes
-        # --lock-image (scripts/*.sh), so refuse instead of silently freezing what the reference would train.
-        raise NotImplementedError("training without --lock-image is not supported: only transformer blocks are trainable here "
-                                  "(pass --lock-image --lock-image-unlocked-groups N, as the reference's scripts do)")
+        # Without --lock-image the reference trains the whole visual tower -- stem, positional embedding, final norm and head besides the
+        # blocks -- through the dense path (main.py:161-166; eva_vit_model.py:537-544,615-623).  A freshly built EVA02 tower is in that
+        # state (EvaEngine.set_trainable_all); the OpenAI-CLIP ViT family differentiates its transformer blocks only.
+        if not getattr(model.visual, "UNLOCKED_TRAINS_ALL", False):
+            raise NotImplementedError("training without --lock-image is supported for the EVA02 towers; pass --lock-image "
+                                      "--lock-image-unlocked-groups N for this model family")
+        model.visual.unlock()
     if is_master(args):
         with open(os.path.join(args.logs, args.name, "params.txt"), "w") as f:
             for name in sorted(vars(args)):

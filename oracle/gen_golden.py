@@ -105,7 +105,8 @@ def _run_steps(oc, cfg, rec, image_size, crop_size, build=None):
     build = build or _build
     student = build(oc, cfg, rec["seed_w"])
     teacher = build(oc, cfg, rec["seed_w"])          # main.py:150-157 loads the same checkpoint
-    student.lock_image_tower(unlocked_groups=rec.get("unlocked", cfg.layers))
+    if rec.get("lock", True):                        # main.py:161-166: without --lock-image the whole visual tower trains
+        student.lock_image_tower(unlocked_groups=rec.get("unlocked", cfg.layers))
     student.train()
     teacher.eval()
     opt, groups = _optimizer(student, rec["lr"], rec["wd"])
@@ -165,6 +166,41 @@ def gen_tiny(oc):
     blob["recipe"] = np.array(json.dumps(rec))
     np.savez_compressed(GOLD / "tiny_step.npz", **blob)
     print("tiny losses", out["losses"], "grad_none", none)
+
+
+def gen_tiny_unlocked(oc):
+    """training.main WITHOUT --lock-image (src/training/main.py:161-166): nothing but the text tower is frozen, so the dense path also
+    differentiates the stem (patch_embed.proj, cls_token, pos_embed), the final norm and the head (eva_vit_model.py:537-544,615-623).
+    Every gradient of step 0, the parameters after 3 AdamW steps, the optimizer grouping, and the pos_embed / cls_token gradients on a
+    64-px image (8x8 tokens: the gradient runs back through rescale_positional_embedding's bicubic resize, :631-643)."""
+    cfg = _register_tiny(oc)
+    rec = dict(TINY, lock=False, seed_w=4, seed_b=60)
+    student, teacher, out, first, groups = _run_steps(oc, cfg, rec, cfg.image_size, cfg.image_size)
+    blob = {"losses": np.array(out["losses"], np.float64), "lrs": np.array(out["lrs"], np.float64)}
+    none = []
+    for n, g in first["grads"].items():
+        if g is None:
+            none.append(n)
+        else:
+            blob["grad/" + n] = g.numpy()
+    for n, p in student.named_parameters():
+        if n.startswith("visual.") and p.requires_grad:
+            blob["final/" + n] = p.detach().numpy()
+    blob["grad_none"] = np.array(none)
+    blob["groups"] = np.array(json.dumps({n: v for n, v in groups.items() if not n.startswith("text.")}))
+    from training.clipself import CLIPSelf
+    fresh, frozen = _build(oc, cfg, rec["seed_w"]), _build(oc, cfg, rec["seed_w"])
+    fresh.train()
+    frozen.eval()
+    batch = synthetic_batch(2, 3, 64, cfg.image_size, seed=78)
+    losses, _, _ = CLIPSelf()(batch, fresh, frozen, None, "cpu", None, False, SimpleNamespace(multiscale=False, extract_type="v2", cosine_weight=1.0))
+    sum(losses.values()).backward()
+    for n in ("visual.pos_embed", "visual.cls_token", "visual.patch_embed.proj.weight", "visual.head.weight"):
+        blob["grad64/" + n] = dict(fresh.named_parameters())[n].grad.numpy()
+    blob["loss64"] = np.array(float(sum(losses.values())))
+    blob["recipe"] = np.array(json.dumps(rec))
+    np.savez_compressed(GOLD / "tiny_unlocked_step.npz", **blob)
+    print("tiny unlocked losses", out["losses"], "grad_none", none, "trainable", sum(v != "frozen" for v in groups.values()))
 
 
 CURVE = dict(TINY, seed_w=7, seed_b=300, steps=24, n_batches=4, warmup=4, total=24, lr=2e-3)
@@ -442,6 +478,9 @@ def main():
     if "--zeroshot-only" in sys.argv:
         gen_zeroshot(oc)
         return
+    if "--unlocked-only" in sys.argv:
+        gen_tiny_unlocked(oc)
+        return
     if "--curve-only" in sys.argv:
         gen_curve(oc)
         return
@@ -455,6 +494,7 @@ def main():
         gen_schedules(oc)
         return
     gen_tiny(oc)
+    gen_tiny_unlocked(oc)
     gen_tiny14(oc)
     gen_regionclip(oc)
     gen_curve(oc)

@@ -45,7 +45,7 @@ def _args(distributed, device, clip=None):
                            multiscale=False, extract_type="v2", cosine_weight=1.0)
 
 
-def _worker(rank, world, port, out_dir, device, family="eva02", clip=None, bucket="fp32"):
+def _worker(rank, world, port, out_dir, device, family="eva02", clip=None, bucket="fp32", lock=True):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), CLIPSELF_GRAD_BUCKET_DTYPE=bucket)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -61,29 +61,31 @@ def _worker(rank, world, port, out_dir, device, family="eva02", clip=None, bucke
     # deliberately different initial weights per rank: the wrapper must broadcast rank 0's
     student.visual.engine.load_state(seeded(cfg, 1 + rank))
     teacher.visual.engine.load_state(seeded(cfg, 1 + rank))
-    student.lock_image_tower(unlocked_groups=cfg.layers)
+    if lock:
+        student.lock_image_tower(unlocked_groups=cfg.layers)
     model, dist_model = StudentDataParallel(student), FrozenDataParallel(teacher)
     opt = FlatAdamW(student, lr=1e-3, weight_decay=0.1, grad_divisor=float(world))
     batch = synthetic_batch(2, 3, cfg.image_size, cfg.image_size, seed=40 + rank)
     train_step(model, CLIPSelf(), batch, opt, None, 0, dist_model, _args(True, device, clip))
     eng = student.visual.engine
     torch.save({"grad": eng.grad.cpu().clone(), "master": eng.master.cpu().clone(), "comm": model.comm_summary(),
-                "bucket_elems": sum(hi - lo for lo, hi in eng.block_ranges[eng.first_trainable:])},
+                "bucket_elems": sum(hi - lo for lo, hi in eng.block_ranges[eng.first_trainable:])
+                + (sum(hi - lo for lo, hi in (eng.stem_range, eng.head_range)) if eng.train_all else 0)},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def run_two_rank_equivalence(device, tmp_path, tol, family="eva02", clip=None, bucket="fp32"):
+def run_two_rank_equivalence(device, tmp_path, tol, family="eva02", clip=None, bucket="fp32", lock=True):
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path), device, family, clip, bucket), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), device, family, clip, bucket, lock), nprocs=world, join=True)
     r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
     assert torch.equal(r0["master"], r1["master"]), "ranks diverged after the step"
     assert torch.equal(r0["grad"], r1["grad"]), "all-reduced gradients differ between ranks"
     # what the step exchanged, as bench.py reports it: one bucket per trainable block, the block's flat slice in the wire dtype
     comm = r0["comm"]
     cfg0 = _cfg(family)
-    assert comm["allreduce_buckets_per_step"] == cfg0.layers and comm["grad_bucket_dtype"] == bucket
+    assert comm["allreduce_buckets_per_step"] == cfg0.layers + (0 if lock else 2) and comm["grad_bucket_dtype"] == bucket     # + head, stem
     assert comm["allreduce_bytes_per_step"] == r0["bucket_elems"] * (4 if bucket == "fp32" else 2)
     assert comm["grad_sync_wait_ms"] >= 0.0 and comm["rccl_reserved_cus"] == 16
 
@@ -95,7 +97,8 @@ def run_two_rank_equivalence(device, tmp_path, tol, family="eva02", clip=None, b
     student, teacher, seeded = _build(cfg, device)
     student.visual.engine.load_state(seeded(cfg, 1))
     teacher.visual.engine.load_state(seeded(cfg, 1))
-    student.lock_image_tower(unlocked_groups=cfg.layers)
+    if lock:
+        student.lock_image_tower(unlocked_groups=cfg.layers)
     parts = [synthetic_batch(2, 3, cfg.image_size, cfg.image_size, seed=40 + r) for r in range(2)]
     union = tuple(torch.cat([p[i] for p in parts]) for i in range(3))
     opt = FlatAdamW(student, lr=1e-3, weight_decay=0.1)
@@ -134,3 +137,9 @@ def test_two_rank_bf16_gradient_buckets(tmp_path):
     exchanged gradient equals the fp32-bucket one up to one bf16 rounding per rank (168 MB instead of 336 MB per step)."""
     rel, relp = run_two_rank_equivalence("cpu", tmp_path, 8e-3, bucket="bf16")
     assert rel > 1e-6, "the wire format did not change anything: were the buckets really bf16?"
+
+
+def test_two_rank_unlocked_tower(tmp_path):
+    """Training without --lock-image under data parallel: the stem and head slices of the flat gradient travel as two more buckets
+    ("head" is ready first, "stem" last) and the step still equals one process on the union batch."""
+    run_two_rank_equivalence("cpu", tmp_path, 1e-3, lock=False)

@@ -660,3 +660,14 @@ def test_training_main_reads_coco_files(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stderr.count("Train Epoch: 0") == 3 and "Loss_cosine" in r.stderr           # 6 files -> 3 batches of 2
     assert "Cannot load" in r.stdout and "Invalid image" in r.stdout                       # the corrupt and the 5x5 file fell back
+
+
+def test_unlocked_tower_step_matches_the_reference_goldens(golden_dir):
+    """training.main without --lock-image through the HIP kernels: stem (patch_embed.proj wgrad, cls_token, pos_embed), final norm and
+    head gradients, the 3-step AdamW trajectory and the pos_embed gradient through the bicubic rescale of a non-native grid -- against
+    tests/golden/tiny_unlocked_step.npz (captured from the real reference with lock_image off)."""
+    from clipself_amd.hip import HipOps
+    from test_unlocked_cpu import check_rescaled_grid_gradients, check_unlocked_step
+    worst = check_unlocked_step(golden_dir, HipOps, "cuda", tol_grad=6e-2, tol_final=2e-2)
+    _log(f"unlocked tiny tower: worst per-parameter gradient rel-L2 vs the reference golden {worst:.3e}")
+    check_rescaled_grid_gradients(golden_dir, HipOps, "cuda", 6e-2)
