@@ -18,13 +18,11 @@
 //     SOURCE address: two 128-byte tile rows share one 256-byte LDS row whose sixteen 16-byte slots are XOR-permuted
 //     by (lds_row & 15) -> every ds_read_b128 lane group hits 16 distinct slots (conflict free; SQ_LDS_BANK_CONFLICT
 //     < 2 % of wave cycles in profiles/).
-//   * main-loop schedules (the default for the tower shapes is the persistent split-ring loop, gemm_persist_kernel):
-//       - "lockstep": one barrier per K tile, all 8 waves read fragments and issue MFMAs together (any tile shape); with split
-//         operand rings (three A stages, two B stages, DMA pieces interleaved with the MFMAs) for the 256x256 tile;
-//       - "ping-pong" (256x256 only): the two 4-wave row groups run half a K tile out of phase, separated by raw
-//         s_barriers, so in every barrier interval one group issues 16 MFMAs per wave while the other reads its
-//         next fragments from LDS / issues the next tile's DMA -- each SIMD hosts one wave of either group, so its
-//         matrix pipe alternates between them instead of idling during fragment loads.
+//   * main-loop schedules here: "lockstep" -- one barrier per K tile, all 8 waves read fragments and issue MFMAs together (any tile
+//     shape; small and split-K problems, the patch embedding, the wgrad partials) -- and, for the 256x256 tile, split operand rings
+//     (three A stages, two B stages, DMA pieces interleaved with the MFMAs), one tile per workgroup (schedule 7) or as a persistent tile
+//     loop (gemm_persist_kernel, schedule 9).  The tower shapes run the streaming kernel of gemm_stream.hip (schedule 11); this file's
+//     persistent kernel is its fallback for the epilogues it does not cover (exact GELU, shapes with N % 32 != 0).
 //   * epilogue through LDS: each wave parks a 32 x 64 fp32 slab of its accumulators in a private LDS region and reads
 //     it back row-wise, so global stores/loads (bias, residual, pos-embed) are 16-byte per lane and cover whole
 //     256-byte row segments.
@@ -351,7 +349,7 @@ __device__ __forceinline__ void epilogue_at(const GemmArgs& p, const f32x16 (&ac
 }
 
 // ------------------------------------------------------------------------------------------------ lockstep schedule
-template <int EPI, int BM, int BN, int WM, int WN, bool GLDS, int NS, bool PF>
+template <int EPI, int BM, int BN, int WM, int WN, bool GLDS, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;           // wave tile
@@ -397,24 +395,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
     const int a_base = ((wm * TM + l31) >> 1) << 8;
     const int b_base = ((wn * TN + l31) >> 1) << 8;
     const int par8 = (l31 & 1) << 3, sw = l31 >> 1;
-    if (NS == 3 && kt_begin + 1 < kt_end) {               // 3-stage ring: two tiles in flight before the first MFMA
-        stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt_begin + 1) * BK, smem + STAGE, wave * A_INSTR, lane, arow, achk);
-        stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt_begin + 1) * BK, smem + STAGE + A_BYTES, wave * B_INSTR, lane, brow, bchk);
-    }
     int cur = 0;
-    bool pf_pending = false;
-    const __bf16* pf_base = p.A;
-    if (PF) {                                           // the operand line this lane warms up in L2 (see main loop)
-        const int L = wave * 64 + lane;
-        if (L < BM) {
-            pf_base = p.A + (size_t)min(m0 + L, p.M - 1) * p.lda;
-        } else {
-            const int tr = min(L - BM, BN - 1);
-            int br = min(n0 + tr, p.N - 1);
-            if (EPI == EPI_SWIGLU_BF16) br = ((tr >> 5) & 1) * p.group + min(tn * (BN / 2) + (tr >> 6) * 32 + (tr & 31), p.group - 1);
-            pf_base = p.B + (size_t)br * p.ldb;
-        }
-    }
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         if (AB) {
             // In issue order this wave's pending DMA is A(kt), B(kt), A(kt+1): everything but the newest A_INSTR ops must
@@ -430,38 +411,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
                 if (kt + 2 < kt_end)
                     stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 2) * BK, smem + ((i + 2) % 3) * A_BYTES, wave * A_INSTR, lane, arow, achk);
             }
-        } else if (NS == 3) {
-            // Counted wait: tile kt (older) must have landed, tile kt+1 (A_INSTR+B_INSTR newer DMA ops of this wave) may stay
-            // in flight across the barrier.  Raw s_barrier: __syncthreads() would drain the DMA queue (vmcnt(0)).
-            if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();     // everyone's tile kt landed; everyone finished reading buffer (cur+2)%3 = tile kt-1
-            if (kt + 2 < kt_end) {
-                char* nxt = smem + ((cur + 2) % 3) * STAGE;
-                stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 2) * BK, nxt, wave * A_INSTR, lane, arow, achk);
-                stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 2) * BK, nxt + A_BYTES, wave * B_INSTR, lane, brow, bchk);
-            }
-        } else if (PF && GLDS) {
-            // 2-stage ring + L2 warm-up: besides tile kt+1's DMA, each wave touches one 16-byte piece of 64 distinct
-            // 128-byte lines of tile kt+2 (the 8 waves cover all 512 operand lines) with a throw-away LDS-DMA into a
-            // scratch slot, so that tile kt+2's real DMA one iteration later hits L2 instead of the fabric.  The
-            // throw-away op is the newest VMEM op of the wave: vmcnt(1) waits for tile kt only.
-            if (pf_pending) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 < kt_end) {
-                char* nxt = smem + (cur ^ 1) * STAGE;
-                stage_tile<A_INSTR, GLDS>(p.A, p.lda, (kt + 1) * BK, nxt, wave * A_INSTR, lane, arow, achk);
-                stage_tile<B_INSTR, GLDS>(p.B, p.ldb, (kt + 1) * BK, nxt + A_BYTES, wave * B_INSTR, lane, brow, bchk);
-            }
-            pf_pending = kt + 2 < kt_end;
-            if (pf_pending) {
-                const __bf16* g = pf_base + (size_t)(kt + 2) * BK;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                 (__attribute__((address_space(3))) void*)(smem + 2 * STAGE + wave * 1024), 16, 0, 0);
-            }
         } else {
             __syncthreads();        // tile kt landed (the barrier drains the LDS-DMA queue); buffer cur^1 is free
             if (kt + 1 < kt_end && !CS_ABL(p, 1)) {
@@ -472,7 +421,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
         }
         const char* la = (AB ? smem + cur * A_BYTES : smem + cur * STAGE) + a_base;
         const char* lb = (AB ? b_ring + ((kt - kt_begin) & 1) * B_BYTES : smem + cur * STAGE + A_BYTES) + b_base;
-        if (CS_ABL(p, 2)) { cur = (NS == 3 || AB) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1); continue; }
+        if (CS_ABL(p, 2)) { cur = AB ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1); continue; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int off = ((par8 | (ks * 2 + hf)) ^ sw) << 4;
@@ -504,7 +453,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        cur = (NS == 3 || AB) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
+        cur = AB ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
     }
     __syncthreads();                                    // every wave is done reading the operand buffers
     if (CS_ABL(p, 4)) return;
@@ -624,449 +573,26 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ two-workgroups-per-CU schedule
-// 256x128 tile, K tiles of 32, 3-stage LDS-DMA ring (72 KiB), 8 waves of 64x64 (<=128 registers): TWO workgroups fit a CU, so one
-// workgroup's epilogue (an HBM-bound store phase that is 25-45 % of a lockstep 256x256 kernel on the K=768 shapes of the towers)
-// and prologue overlap the other's MFMA loop.  LDS image of a K-32 tile: row r (64 B) at r*64, 16-byte chunk c at slot
-// c ^ ((r>>2)&3) -- conflict-free for the ds_read_b128 lane groups, and lane-linear for global_load_lds (lane l of the
-// instruction covering rows 16g.. lands on row 16g + (l>>2), slot l&3, so it fetches chunk (l&3) ^ ((l>>4)&3)).
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_k32_kernel(GemmArgs p) {
-    constexpr int BM = 256, BN = 128, WN = 2, TM = 64, TN = 64, FM = 2, FN = 2, KT = 32;
-    constexpr int A_BYTES = BM * KT * 2, B_BYTES = BN * KT * 2, STAGE = A_BYTES + B_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const int hf = lane >> 5, l31 = lane & 31;
-    int tm, tn;
-    tile_of_block(p, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const int lrow = lane >> 2, lchk = (lane & 3) ^ ((lane >> 4) & 3);
-    const __bf16* asrc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) asrc[i] = p.A + (size_t)min(m0 + (wave * 2 + i) * 16 + lrow, p.M - 1) * p.lda + lchk * 8;
-    const __bf16* bsrc;
-    {
-        const int tr = wave * 16 + lrow;
-        int br;
-        if (EPI == EPI_SWIGLU_BF16) br = ((tr >> 5) & 1) * p.group + min(tn * (BN / 2) + (tr >> 6) * 32 + (tr & 31), p.group - 1);
-        else br = min(n0 + tr, p.N - 1);
-        bsrc = p.B + (size_t)br * p.ldb + lchk * 8;
-    }
-    auto stage = [&](int kt, int slot) {
-        char* dst = smem + slot * STAGE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)kt * KT),
-                                             (__attribute__((address_space(3))) void*)(dst + (wave * 2 + i) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc + (size_t)kt * KT),
-                                         (__attribute__((address_space(3))) void*)(dst + A_BYTES + wave * 1024), 16, 0, 0);
-    };
-
-    const int kt_begin = blockIdx.y * p.ktiles_per_split * 2;            // ktiles_per_split counts K-64 tiles
-    const int kt_end = min(kt_begin + p.ktiles_per_split * 2, p.K / KT);
-    f32x16 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    if (kt_begin < kt_end) stage(kt_begin, 0);
-    if (kt_begin + 1 < kt_end) stage(kt_begin + 1, 1);
-    const int a_off = (wm * TM + l31) * 64, b_off = A_BYTES + (wn * TN + l31) * 64;
-    const int swz = (l31 >> 2) & 3;
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        // counted wait: tile kt landed, tile kt+1 (the 3 newest DMA ops of this wave) may stay in flight across the barrier
-        if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();         // everyone's tile kt landed; everyone finished reading slot (cur+2)%3 (tile kt-1)
-        if (kt + 2 < kt_end) stage(kt + 2, cur == 0 ? 2 : cur - 1);
-        const char* st = smem + cur * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int off = ((ks * 2 + hf) ^ swz) << 4;
-            bf16x8 a[FM], b[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(st + a_off + i * 2048 + off);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(st + b_off + j * 2048 + off);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        cur = cur == 2 ? 0 : cur + 1;
-    }
-    __syncthreads();
-    if (CS_ABL(p, 4)) return;
-    epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + wm * TM, n0, tn, wn);
-}
-
-// ------------------------------------------------------------------------------------------------ ping-pong schedule
-// 256x256x64 tile, 8 waves = 2 row groups (g = wave>>2) x 4 column waves, wave tile 128x64.  Barrier intervals:
-//   group 0:  L(kt,0) | C(kt,0) | L(kt,1) | C(kt,1) | L(kt+1,0) ...        L(kt,h): 12 ds_read_b128 (fragments of k-steps
-//   group 1:     -    | L(kt,0) | C(kt,0) | L(kt,1) | C(kt,1)   ...                 2h,2h+1);  C(kt,h): the 16 MFMAs on them
-// Tile kt+1's DMA is issued during interval 4kt (group 0 in L(kt,0), group 1 in C(kt-1,1)): the buffer it overwrites was last
-// read in interval 4kt-1.  It is waited for (vmcnt(0)) just before the barrier that ends interval 4kt+3.
-// Pieces [X0, X1) of one wave's share of a K tile (pieces 0..A_INSTR-1 = its A row groups, the rest its B row groups), one DMA each.
-template <int X0, int X1, int A_INSTR, int B_INSTR>
-__device__ __forceinline__ void stage_pieces(const GemmArgs& p, int k0, char* dst, int a_bytes, int wave, int lane, const int (&arow)[A_INSTR],
-                                             const int (&achk)[A_INSTR], const int (&brow)[B_INSTR], const int (&bchk)[B_INSTR]) {
-#pragma unroll
-    for (int x = X0; x < X1; ++x) {
-        if (x < A_INSTR) {
-            const int r1[1] = {arow[x]}, c1[1] = {achk[x]};
-            stage_tile<1, true>(p.A, p.lda, k0, dst, wave * A_INSTR + x, lane, r1, c1);
-        } else {
-            const int r1[1] = {brow[x - A_INSTR]}, c1[1] = {bchk[x - A_INSTR]};
-            stage_tile<1, true>(p.B, p.ldb, k0, dst + a_bytes, wave * B_INSTR + (x - A_INSTR), lane, r1, c1);
-        }
-    }
-}
-
-// V = 1: the DMA of the next K tile is spread over three barrier intervals (3 + 3 + 2 pieces per wave) instead of one burst of 8, and the
-// MFMA clusters run at raised wave priority, so the other row group's ds_reads / DMA issue fill the gaps instead of delaying them.
-template <int EPI, int V = 0>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
-    constexpr int BM = 256, BN = 256, NW = 8, WN = 4, TM = 128, FM = 4, FN = 2;
-    constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
-    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wave >> 2, wn = wave & 3;
-    const int hf = lane >> 5, l31 = lane & 31;
-    int tm, tn;
-    tile_of_block(p, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    int arow[A_INSTR], achk[A_INSTR], brow[B_INSTR], bchk[B_INSTR];
-    source_rows<EPI, BM, BN, NW, A_INSTR, B_INSTR>(p, wave, lane, m0, n0, tn, arow, achk, brow, bchk);
-
-    const int kt_begin = blockIdx.y * p.ktiles_per_split;
-    const int kt_end = min(kt_begin + p.ktiles_per_split, p.K / BK);
-
-    f32x16 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int a_base = ((g * TM + l31) >> 1) << 8;
-    const int b_base = ((wn * 64 + l31) >> 1) << 8;
-    const int par8 = (l31 & 1) << 3, sw = l31 >> 1;
-
-    auto issue = [&](int kt, int buf) {
-        char* dst = smem + buf * STAGE;
-        stage_tile<A_INSTR, true>(p.A, p.lda, kt * BK, dst, wave * A_INSTR, lane, arow, achk);
-        stage_tile<B_INSTR, true>(p.B, p.ldb, kt * BK, dst + A_BYTES, wave * B_INSTR, lane, brow, bchk);
-    };
-    bf16x8 fa[2][FM], fb[2][FN];
-    if (V == 2 && CS_ABL(p, 2)) {                      // ablation without ds_reads: defined (zero) fragments
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i) fa[s2][i] = bf16x8{};
-#pragma unroll
-            for (int j = 0; j < FN; ++j) fb[s2][j] = bf16x8{};
-        }
-    }
-    auto load_frags = [&](int buf, int h) {
-        const char* la = smem + buf * STAGE + a_base;
-        const char* lb = smem + buf * STAGE + A_BYTES + b_base;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int off = ((par8 | ((h * 2 + s) * 2 + hf)) ^ sw) << 4;
-#pragma unroll
-            for (int i = 0; i < FM; ++i) fa[s][i] = *(const bf16x8*)(la + i * (16 * 256) + off);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) fb[s][j] = *(const bf16x8*)(lb + j * (16 * 256) + off);
-        }
-    };
-    auto mfma_half = [&]() {
-        if (V) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
-        if (V) __builtin_amdgcn_s_setprio(0);
-    };
-#define PP_PIECES(X0, X1, KT, BUF) \
-    stage_pieces<X0, X1, A_INSTR, B_INSTR>(p, (KT) * BK, smem + (BUF) * STAGE, A_BYTES, wave, lane, arow, achk, brow, bchk)
-    // sched_barrier(0): MFMAs are register-only, nothing else stops the scheduler from moving them across the s_barrier
-#define PP_BARRIER()                                        \
-    do {                                                    \
-        __builtin_amdgcn_sched_barrier(0);                  \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
-        __builtin_amdgcn_s_barrier();                       \
-        __builtin_amdgcn_sched_barrier(0);                  \
-    } while (0)
-
-    if (kt_begin < kt_end) {
-        issue(kt_begin, 0);
-        if (g == 1 && kt_begin + 1 < kt_end) issue(kt_begin + 1, 1);   // group 1 has no C(-1,1) part to issue tile 1 from
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (group 1 also waits for its tile-1 share: prologue only)
-    }
-    PP_BARRIER();                       // tile 0 visible to everyone
-    if (g == 1) PP_BARRIER();           // interval 0: group 1 idles one interval behind
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        if constexpr (V == 0) {
-            // ---- L(kt,0)
-            if (g == 0 && kt + 1 < kt_end) issue(kt + 1, cur ^ 1);
-            load_frags(cur, 0);
-            PP_BARRIER();
-            // ---- C(kt,0)
-            mfma_half();
-            PP_BARRIER();
-            // ---- L(kt,1)
-            load_frags(cur, 1);
-            if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 (issued in C(kt-1,1)) has landed
-            PP_BARRIER();
-            // ---- C(kt,1)
-            if (g == 1 && kt + 2 < kt_end) issue(kt + 2, cur);               // buffer `cur` was last read in this group's L(kt,1)
-            mfma_half();
-            if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 (issued in L(kt,0)) has landed
-            PP_BARRIER();
-        } else if constexpr (V == 2) {
-            // All DMA in the L intervals (4 pieces beside the 12 ds_reads), none beside the MFMA clusters.  Pieces 0-3 of a wave are its
-            // A row groups -- rows of its OWN row group's half of A, read by nobody else -- pieces 4-7 its B row groups (read by everyone).
-            // Global interval numbers (group 1 runs one behind): tile kt+1 is first read by group 0 in 4kt+4, by group 1 in 4kt+5.
-            //   group 0: B pieces in L(kt,0) = 4kt, A pieces in L(kt,1) = 4kt+2, all waited for at the end of C(kt,1) = 4kt+3;
-            //   group 1: B pieces in L(kt,0) = 4kt+1, A pieces in L(kt,1) = 4kt+3 where the B pieces are waited for (vmcnt(4): loads
-            //            retire in order), the A pieces at the end of C(kt,1) = 4kt+4, in front of its own first read.
-            // timing ablations (flags bits 12-13, results wrong): 1 = no operand DMA in the loop, 2 = no fragment ds_reads
-            const bool nxt = kt + 1 < kt_end && (g == 0 || kt > kt_begin) && !CS_ABL(p, 1);   // group 1's tile kt_begin+1 comes from the prologue
-            // ---- L(kt,0)
-            if (!CS_ABL(p, 2)) load_frags(cur, 0);
-            if (nxt) PP_PIECES(4, 8, kt + 1, cur ^ 1);
-            PP_BARRIER();
-            // ---- C(kt,0)
-            mfma_half();
-            PP_BARRIER();
-            // ---- L(kt,1)
-            if (!CS_ABL(p, 2)) load_frags(cur, 1);
-            if (nxt) PP_PIECES(0, 4, kt + 1, cur ^ 1);
-            if (g == 1) {
-                if (nxt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            PP_BARRIER();
-            // ---- C(kt,1)
-            mfma_half();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PP_BARRIER();
-        } else {
-            // Group 0 spreads tile kt+1 over L(kt,0) | C(kt,0) | L(kt,1) and waits in C(kt,1); group 1 (one interval behind) spreads
-            // tile kt+2 over C(kt,1) | L(kt+1,0) | C(kt+1,0) and waits in L(kt+1,1) -- the same four global intervals, ending at the
-            // barrier in front of the first read of that tile.  Tile kt_begin+1 of group 1 comes from the prologue.
-            const bool g0_next = g == 0 && kt + 1 < kt_end, g1_next = g == 1 && kt > kt_begin && kt + 1 < kt_end;
-            // ---- L(kt,0)
-            load_frags(cur, 0);
-            if (g0_next) PP_PIECES(0, 3, kt + 1, cur ^ 1);
-            if (g1_next) PP_PIECES(3, 6, kt + 1, cur ^ 1);
-            PP_BARRIER();
-            // ---- C(kt,0)
-            if (g0_next) PP_PIECES(3, 6, kt + 1, cur ^ 1);
-            if (g1_next) PP_PIECES(6, 8, kt + 1, cur ^ 1);
-            mfma_half();
-            PP_BARRIER();
-            // ---- L(kt,1)
-            load_frags(cur, 1);
-            if (g0_next) PP_PIECES(6, 8, kt + 1, cur ^ 1);
-            if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 has landed (this wave's share)
-            PP_BARRIER();
-            // ---- C(kt,1)
-            if (g == 1 && kt + 2 < kt_end) PP_PIECES(0, 3, kt + 2, cur);     // buffer `cur` was last read in this group's L(kt,1)
-            mfma_half();
-            if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt+1 has landed (this wave's share)
-            PP_BARRIER();
-        }
-    }
-    if (g == 0) PP_BARRIER();           // group 0 waits for group 1's last interval
-#undef PP_BARRIER
-#undef PP_PIECES
-    __syncthreads();
-    if (CS_ABL(p, 4)) return;
-    epilogue<EPI, FM, FN, BN>(p, acc, smem, wave, lane, m0 + g * TM, n0, tn, wn);
-}
-
-
-// ------------------------------------------------------------------------------------------------ persistent ping-pong schedule
-// The v2 ping-pong loop (all LDS-DMA pieces in the fragment-load intervals, MFMA clusters at raised priority) inside a persistent tile
-// loop, for the packed epilogues.  LDS: two 64 KiB operand stages + 32 KiB of wave-private epilogue slabs (no aliasing with the
-// stages), row statistics of a folded LayerNorm in the first 8 KiB of stage 1.  After the last K tile of an output tile every wave puts
-// its share of the NEXT tile's K tile 0 in flight (stage 0) and only then runs its epilogue; stage 1 is refilled after the barrier that
-// follows the epilogues (row group 1 in its idle first interval, row group 0 in its first two load intervals, as in the one-tile kernel).
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_pp_persist_kernel(GemmArgs p) {
-    static_assert(epi_is_bf16(EPI) || EPI == EPI_SWIGLU_BF16, "packed epilogues only");
-    constexpr int BM = 256, BN = 256, NW = 8, TM = 128, FM = 4, FN = 2;
-    constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
-    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wave >> 2, wn = wave & 3;
-    const int hf = lane >> 5, l31 = lane & 31;
-    char* const slab = smem + 2 * STAGE + wave * 4096;
-    char* const rowst = smem + STAGE + wave * 1024;
-    const int ntiles = p.tiles_m * p.tiles_n, ktiles = p.K / BK;
-    const int a_base = ((g * TM + l31) >> 1) << 8, b_base = ((wn * 64 + l31) >> 1) << 8;
-    const int par8 = (l31 & 1) << 3, sw = l31 >> 1;
-
-    int tile = blockIdx.x, tm, tn;
-    tile_of_id(p, tile, ntiles, tm, tn);
-    int arow[A_INSTR], achk[A_INSTR], brow[B_INSTR], bchk[B_INSTR];
-    source_rows<EPI, BM, BN, NW, A_INSTR, B_INSTR>(p, wave, lane, tm * BM, tn * BN, tn, arow, achk, brow, bchk);
-#define PP_PIECES(X0, X1, KT, BUF) \
-    stage_pieces<X0, X1, A_INSTR, B_INSTR>(p, (KT) * BK, smem + (BUF) * STAGE, A_BYTES, wave, lane, arow, achk, brow, bchk)
-#define PP_BARRIER()                                        \
-    do {                                                    \
-        __builtin_amdgcn_sched_barrier(0);                  \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
-        __builtin_amdgcn_s_barrier();                       \
-        __builtin_amdgcn_sched_barrier(0);                  \
-    } while (0)
-    PP_PIECES(0, 8, 0, 0);
-    bf16x8 fa[2][FM], fb[2][FN];
-    for (;;) {
-        const int m0 = tm * BM, n0 = tn * BN, tn_cur = tn;
-        f32x16 acc[FM][FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        auto load_frags = [&](int buf, int h) {
-            const char* la = smem + buf * STAGE + a_base;
-            const char* lb = smem + buf * STAGE + A_BYTES + b_base;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int off = ((par8 | ((h * 2 + s2) * 2 + hf)) ^ sw) << 4;
-#pragma unroll
-                for (int i = 0; i < FM; ++i) fa[s2][i] = *(const bf16x8*)(la + i * (16 * 256) + off);
-#pragma unroll
-                for (int j = 0; j < FN; ++j) fb[s2][j] = *(const bf16x8*)(lb + j * (16 * 256) + off);
-            }
-        };
-        auto mfma_half = [&]() {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s2][i], fb[s2][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        };
-        // K tile 0 of this output tile (issued before the previous epilogue, or above) has landed; the previous epilogue's stores share
-        // the queue and do not retire in order with the loads: drain it.  The barrier also ends every wave's use of the slabs / row stats.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PP_BARRIER();
-        if (g == 1) {                                       // interval 0: row group 1 idles one interval behind and refills stage 1
-            if (ktiles > 1) PP_PIECES(0, 8, 1, 1);
-            PP_BARRIER();
-        }
-        for (int kt = 0; kt < ktiles; ++kt) {
-            const int cur = kt & 1;
-            const bool nxt = kt + 1 < ktiles && (g == 0 || kt > 0);
-            // ---- L(kt,0)
-            load_frags(cur, 0);
-            if (nxt) PP_PIECES(4, 8, kt + 1, cur ^ 1);
-            PP_BARRIER();
-            // ---- C(kt,0)
-            mfma_half();
-            PP_BARRIER();
-            // ---- L(kt,1)
-            load_frags(cur, 1);
-            if (nxt) PP_PIECES(0, 4, kt + 1, cur ^ 1);
-            if (g == 1) {
-                if (nxt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            PP_BARRIER();
-            // ---- C(kt,1)
-            mfma_half();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PP_BARRIER();
-        }
-        if (g == 0) PP_BARRIER();                           // row group 0 waits for group 1's last interval: both stages are free now
-        const int next = tile + (int)gridDim.x;
-        const bool more = next < ntiles;
-        if (more) {                                         // the next tile's K tile 0 flies during this tile's epilogue
-            tile_of_id(p, next, ntiles, tm, tn);
-            source_rows<EPI, BM, BN, NW, A_INSTR, B_INSTR>(p, wave, lane, tm * BM, tn * BN, tn, arow, achk, brow, bchk);
-            PP_PIECES(0, 8, 0, 0);
-        }
-        if constexpr (EPI == EPI_SWIGLU_BF16) epilogue_swiglu<FM, BN>(p, acc, slab, rowst, lane, m0 + g * TM, tn_cur, wn);
-        else epilogue_bf16<FM, BN, epi_act(EPI)>(p, acc, slab, rowst, lane, m0 + g * TM, n0, wn);
-        if (!more) break;
-        tile = next;
-    }
-#undef PP_BARRIER
-#undef PP_PIECES
-}
-
 // ------------------------------------------------------------------------------------------------ launch
-template <int EPI, int BM, int BN, int WM, int WN, int NS, bool PF = false>
+template <int EPI, int BM, int BN, int WM, int WN, int NS>
 int launch_cfg(GemmArgs a, int splits, int use_glds, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + BN / 2 - 1) / (BN / 2) : (a.N + BN - 1) / BN;
     constexpr int NW = WM * WN;
-    constexpr size_t stage = NS == 32 ? (size_t)(3 * BM + 2 * BN) * BK * 2 : (size_t)(BM + BN) * BK * 2 * NS + (PF ? (size_t)NW * 1024 : 0);
+    constexpr size_t stage = NS == 32 ? (size_t)(3 * BM + 2 * BN) * BK * 2 : (size_t)(BM + BN) * BK * 2 * NS;
     constexpr size_t lds = stage > (size_t)NW * EP_BYTES ? stage : (size_t)NW * EP_BYTES;
     dim3 grid(a.tiles_m * a.tiles_n, splits), block(NW * 64);
     if (use_glds) {
-        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, true, NS, PF>,
+        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, true, NS>,
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, true, NS, PF>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, true, NS>), grid, block, lds, stream, a);
     } else {
-        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, false, NS, false>,
+        static bool once = ((void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, BM, BN, WM, WN, false, NS>,
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, false, NS, false>), grid, block, lds, stream, a);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, BM, BN, WM, WN, false, NS>), grid, block, lds, stream, a);
     }
-    CS_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int EPI>
-int launch_pp(GemmArgs a, int splits, hipStream_t stream) {
-    a.tiles_m = (a.M + 255) / 256;
-    a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + 127) / 128 : (a.N + 255) / 256;
-    constexpr size_t lds = (size_t)512 * BK * 2 * 2;
-    if (a.rm == 1) {                                        // flags bits 16-17 = 1 with the ping-pong schedule: spread DMA + MFMA priority
-        static bool once1 = ((void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once1;
-        hipLaunchKernelGGL((gemm_pp_kernel<EPI, 1>), dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
-        CS_LAUNCH_CHECK();
-        return 0;
-    }
-    if (a.rm == 2) {                                        // = 2: all DMA in the fragment-load intervals + MFMA priority
-        static bool once2 = ((void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once2;
-        hipLaunchKernelGGL((gemm_pp_kernel<EPI, 2>), dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
-        CS_LAUNCH_CHECK();
-        return 0;
-    }
-    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-    (void)once;
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
     CS_LAUNCH_CHECK();
     return 0;
 }
@@ -1096,38 +622,6 @@ int launch_persist(GemmArgs a, hipStream_t stream) {
         if (a.rm == 3) return launch_persist_rm<EPI, 3>(a, grid, stream);
     }
     return launch_persist_rm<EPI, 0>(a, grid, stream);
-}
-
-template <int EPI>
-int launch_pp_persist(GemmArgs a, hipStream_t stream) {
-    a.tiles_m = (a.M + 255) / 256;
-    a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + 127) / 128 : (a.N + 255) / 256;
-    constexpr size_t lds = 160 * 1024;
-    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_pp_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-    (void)once;
-    const long ntiles = (long)a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL(gemm_pp_persist_kernel<EPI>, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), lds, stream, a);
-    CS_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int EPI>
-int launch_k32(GemmArgs a, int splits, hipStream_t stream) {
-    constexpr int BM = 256, BN = 128;
-    a.tiles_m = (a.M + BM - 1) / BM;
-    a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + BN / 2 - 1) / (BN / 2) : (a.N + BN - 1) / BN;
-    constexpr size_t lds = (size_t)(BM + BN) * 32 * 2 * 3;                  // 72 KiB: operand ring, reused by the epilogue slabs
-    static_assert(lds >= (size_t)8 * EP_BYTES, "epilogue slabs must fit the operand ring");
-    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_k32_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-    (void)once;
-    if (getenv("CS_GEMM_DEBUG")) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_k32_kernel<EPI>, 512, lds);
-        fprintf(stderr, "[cs_gemm] k32 epi=%d: %d resident workgroups per CU (lds %zu)\n", EPI, nb, lds);
-    }
-    hipLaunchKernelGGL(gemm_k32_kernel<EPI>, dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
-    CS_LAUNCH_CHECK();
-    return 0;
 }
 
 template <int EPI>
@@ -1166,25 +660,20 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
         // ... and with register-level epilogues on a continuous operand ring (gemm_stream.hip) for the bf16 / QuickGELU / SwiGLU outputs:
         // q|k|v 1600 -> 1480 us, W1|W2 2840 -> 2430 us per 2048-crop launch; the fp32 residual epilogues (HBM-bound, whole-line slab
         // form) proj 870 -> 800 us, w3 1510 -> 1445 us (profiles/r02_a_stream_gemm.md)
-        if (cfg == 3 && use_glds) cfg = PP_DEFAULT ? 5 : 11;
+        if (cfg == 3 && use_glds) cfg = 11;
     }
-    const int ns = sp[(cfg == 4 || cfg == 8) ? 2 : (cfg >= 5 ? 3 : cfg)];   // cfgs 5..7, 9 and 10 are 256x256 variants
+    if (cfg != 1 && cfg != 2 && cfg != 3 && cfg != 7 && cfg != 9 && cfg != 11) {
+        cs_set_error("cs_gemm_nt: schedule %d does not exist (flags bits 4-7: 0 heuristic, 1, 2, 3, 7, 9, 11)", cfg);
+        return -1;
+    }
+    const int ns = sp[cfg >= 7 ? 3 : cfg];                                                  // 7, 9 and 11 are 256x256 schedules
     a.ktiles_per_split = (ktiles + ns - 1) / ns;
-    switch (cfg) {
-        case 11:                                                                                // streaming persistent kernel, register epilogues
-            if (use_glds && ns == 1) {
-                const int rc = cs_gemm_stream_launch(a, EPI, a.reserve, stream);
-                if (rc <= 0) return rc;
-            }
-            cfg = 9;                                                                            // outside its coverage: slab-epilogue persistent kernel
-            break;
-        case 10:                                                                                // persistent ping-pong (packed epilogues)
-            if constexpr (epi_is_bf16(EPI) || EPI == EPI_SWIGLU_BF16) {
-                if (use_glds && ns == 1) return launch_pp_persist<EPI>(a, stream);
-            }
-            cfg = 9;
-            break;
-        default: break;
+    if (cfg == 11) {                                                                        // streaming persistent kernel, register epilogues
+        if (use_glds && ns == 1) {
+            const int rc = cs_gemm_stream_launch(a, EPI, a.reserve, stream);
+            if (rc <= 0) return rc;
+        }
+        cfg = 9;                                                                            // outside its coverage: slab-epilogue persistent kernel
     }
     switch (cfg) {
         case 9:                                                                                 // persistent split rings (packed / residual epilogues)
@@ -1192,11 +681,7 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
                 if (use_glds && ns == 1) return launch_persist<EPI>(a, stream);
             }
             return launch_cfg<EPI, 256, 256, 2, 4, 32>(a, ns, use_glds, stream);
-        case 8: return launch_k32<EPI>(a, ns, stream);                                          // 256x128, K-32 tiles, 3-stage ring, two workgroups per CU
         case 7: return launch_cfg<EPI, 256, 256, 2, 4, 32>(a, ns, use_glds, stream);       // 256x256, A ring 3 / B ring 2 (160 KiB)
-        case 6: return launch_cfg<EPI, 256, 256, 2, 4, 2, true>(a, ns, use_glds, stream);   // 256x256 lockstep + L2 warm-up of tile kt+2
-        case 5: return launch_pp<EPI>(a, ns, stream);                                  // 256x256 ping-pong
-        case 4: return launch_cfg<EPI, 256, 128, 4, 2, 3>(a, ns, use_glds, stream);     // 256x128, 3-stage ring
         case 3: return launch_cfg<EPI, 256, 256, 2, 4, 2>(a, ns, use_glds, stream);
         case 2: return launch_cfg<EPI, 256, 128, 4, 2, 2>(a, ns, use_glds, stream);
         default: return launch_cfg<EPI, 128, 128, 2, 2, 2>(a, ns, use_glds, stream);
@@ -1212,15 +697,16 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 //      5 patch-embed: out row = row + row/group + 1, += extra[(row%group+1)*ldc + col] |
 //      6 residual with a folded LayerNorm (cs_gemm_nt_ln) | 7 bf16 out = GELU(acc + bias) (exact, erf) | 8 bf16 out = QuickGELU(acc + bias)
 // flags bit0: 0 = global_load_lds staging, 1 = register staging (debug/fallback A-B switch)
-//       bits 4-7: force schedule (1 = 128x128, 2 = 256x128, 3 = 256x256 lockstep, 4 = 256x128 3-stage ring,
-//                 5 = 256x256 ping-pong, 6 = 256x256 lockstep + L2 warm-up, 7 = 256x256 split rings A3/B2,
-//                 8 = 256x128 K-32 ring, two workgroups per CU, 9 = persistent split rings (bf16 / GELU / SwiGLU / residual epilogues),
-//                 10 = persistent ping-pong (bf16 / GELU / SwiGLU epilogues; others fall back to 9),
+//       bits 4-7: force schedule (1 = 128x128, 2 = 256x128, 3 = 256x256 lockstep, 7 = 256x256 split rings A3/B2 (one tile per workgroup),
+//                 9 = persistent split rings (bf16 / GELU / SwiGLU / residual epilogues through LDS slabs),
 //                 11 = streaming persistent kernel with register epilogues (gemm_stream.hip: bf16 / QuickGELU / SwiGLU / residual;
-//                      others fall back to 9); 0 = heuristic)
+//                      others fall back to 9); 0 = heuristic: the cheapest of 1 / 2 / 3 by a cost model, 3 running as 11).
+//                 Rounds 1-2 also carried a 3-stage 256x128 ring, an L2 warm-up variant, two ping-pong schedules and a two-workgroups-
+//                 per-CU K-32 ring; all measured slower on this path (profiles/r01_t_gemm_schedule_experiments.md) and were removed.
 //       bits 8-11: raster group height override (0 = 8)
-//       bits 12-13: timing ablations (results are wrong): 1 = no in-loop operand DMA, 2 = no ds_read/MFMA, 4 = no epilogue;
-//       bit 15: split-ring schedule issues its DMA in one burst behind the barrier instead of interleaved with the MFMAs
+//       bit 12: streaming kernel: slab form of the bf16 / SwiGLU epilogues (exact A/B switch); bit 15: split-ring schedule issues its DMA in
+//               one burst behind the barrier instead of interleaved with the MFMAs (exact A/B switch).  Builds with -DCS_ABLATION_SWITCHES
+//               additionally read bits 12-14 as timing ablations with wrong results (gemm_common.h: CS_ABL); the shipped library does not.
 //       bits 20-26: compute units the persistent kernels leave free (grid = compute units - n; multi-GPU runs keep room for RCCL's kernels)
 //       bits 16-17 (persistent kernel, epilogues 0 and 3): 1 = B-stationary raster (each XCD keeps its share of B in L2; bits 8-11 = N parts,
 //                 0 = automatic), 2 = the same with non-temporal A loads, 3 = grouped raster with non-temporal B loads
@@ -1271,7 +757,6 @@ static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias
     const int force = (flags >> 4) & 15;
     a.dbg = (flags >> 12) & 15;
     a.reserve = (flags >> 20) & 127;
-    CS_CHECK_ARG(!(force == 5 && !glds), "cs_gemm_nt: the ping-pong schedule only exists with LDS-DMA staging");
     switch (epi) {
         case EPI_BF16: return launch<EPI_BF16>(a, splits, glds, force, stream);
         case EPI_F32: return launch<EPI_F32>(a, splits, glds, force, stream);

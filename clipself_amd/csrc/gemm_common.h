@@ -16,7 +16,6 @@
 #endif
 
 constexpr int BK = 64;
-constexpr bool PP_DEFAULT = false;     // make the ping-pong schedule the default for 256x256 tiles (A/B knob, see tools/gemm_bench.py)
 enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID_F32 = 2, EPI_SWIGLU_BF16 = 3, EPI_ATOMIC_F32 = 4, EPI_PATCH_F32 = 5, EPI_RESID_LN_F32 = 6,
            EPI_GELU_BF16 = 7, EPI_QGELU_BF16 = 8 };
 // bf16 output of acc + bias, optionally through the MLP activation of the OpenAI-CLIP ViT (0 none, 1 exact GELU, 2 QuickGELU)

@@ -51,7 +51,7 @@ def both(cpu_tensors):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x31, 0x40, 0x41, 0x50, 0x10050, 0x20050, 0x60, 0x70, 0x71, 0x80, 0x8070, 0x90, 0xA0, 0xB0, 0x10B0])      # heuristic, register staging, forced 128x128 / 256x128 / 256x256 / 3-stage
+@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x31, 0x70, 0x71, 0x8070, 0x90, 0xB0, 0x10B0])      # heuristic, register staging, forced 128x128 / 256x128 / 256x256 / split rings (+ burst DMA) / persistent / streaming (+ slab epilogue)
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (3152, 768, 768), (300, 192, 64), (128, 64, 256), (1000, 2304, 768)])
 def test_gemm_bf16_bias(hip, ref, M, N, K, flags):
     A, B, bias = rnd((M, K), BF, seed=1), rnd((N, K), BF, 0.05, seed=2), rnd((N,), F32, seed=3)
@@ -63,7 +63,7 @@ def test_gemm_bf16_bias(hip, ref, M, N, K, flags):
     check(f"gemm_bf16[{M},{N},{K}] flags={flags}", Cd, Cr, TOL_BF)
 
 
-@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60, 0x70, 0x71, 0x80, 0x90, 0xA0, 0xB0, 0x10B0])
+@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x70, 0x71, 0x90, 0xB0, 0x10B0])
 def test_gemm_f32_resid_strided(hip, ref, flags):
     M, N, K = 788, 768, 2048
     Abig = rnd((M, K + 64), BF, seed=4)
@@ -82,7 +82,7 @@ def test_gemm_f32_resid_strided(hip, ref, flags):
     check(f"gemm_f32_nobias flags={flags}", Cd2, Cr2, TOL_F32)
 
 
-@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x40, 0x50, 0x10050, 0x20050, 0x60, 0x70, 0x71, 0x80, 0x8070, 0x90, 0xA0, 0xB0, 0x10B0])
+@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x70, 0x71, 0x8070, 0x90, 0xB0, 0x10B0])
 @pytest.mark.parametrize("Hd,M", [(2048, 394), (256, 34), (96, 130)])
 def test_gemm_swiglu(hip, ref, Hd, M, flags):
     K = 128
@@ -101,10 +101,28 @@ def test_gemm_splitk_atomic_wgrad_shape(hip, ref):
     base = rnd((N, Kd), F32, seed=13)
     Cr = base.clone()
     ref.gemm_nt(A, B, Cr, epi=4)
-    for flags in (0, 0x10, 0x20, 0x30, 0x40, 0x50, 0x60, 0x70, 0x80):
+    for flags in (0, 0x10, 0x20, 0x30, 0x70):
         Cd = base.cuda()
         hip.gemm_nt(A.cuda(), B.cuda(), Cd, epi=4, splits=7, flags=flags)
         check(f"gemm_splitk_atomic flags={flags}", Cd, Cr, TOL_F32)
+
+
+def test_removed_schedules_and_ablation_bits_are_not_reachable(hip, ref):
+    """Round 3 removed the schedules that lost every measurement (3-stage ring 4, ping-pong 5 / 10, L2 warm-up 6, two workgroups per CU 8):
+    asking for one is an argument error, not a silent fallback.  The timing-ablation bits (flags bits 13-14: skip the MFMA loop / the
+    epilogue, mask the stores -- wrong results by construction) are compiled out of the shipped library: setting them changes nothing."""
+    M, N, K = 300, 192, 128
+    A, B, bias = rnd((M, K), BF, seed=1), rnd((N, K), BF, seed=2), rnd((N,), F32, seed=3)
+    Cr = torch.empty(M, N, dtype=BF)
+    ref.gemm_nt(A, B, Cr, bias, epi=0)
+    for cfg in (4, 5, 6, 8, 10, 12):
+        with pytest.raises(RuntimeError, match="does not exist"):
+            hip.gemm_nt(A.cuda(), B.cuda(), torch.empty(M, N, dtype=BF, device="cuda"), bias.cuda(), epi=0, flags=cfg << 4)
+    for cfg in (0x30, 0x70, 0x90, 0xB0):
+        for abl in (0x2000, 0x4000, 0x6000, 0x8000 if cfg == 0xB0 else 0):
+            Cd = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+            hip.gemm_nt(A.cuda(), B.cuda(), Cd, bias.cuda(), epi=0, flags=cfg | abl)
+            check(f"ablation bits ignored cfg={cfg:#x} abl={abl:#x}", Cd, Cr, TOL_BF)
 
 
 @pytest.mark.parametrize("N,Kd,Mp", [(768, 256, 3200), (2304, 768, 12672), (128, 64, 64), (4096, 768, 1280), (300, 192, 640)])
@@ -278,7 +296,7 @@ def test_attention_cls_query(hip, ref, B, Ntok, H, qscale):
 
 
 # ------------------------------------------------------------------------------------------------ folded sub-LayerNorm pieces
-@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x70, 0x80, 0x90, 0xA0, 0xB0, 0x10B0])
+@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x70, 0x90, 0xB0, 0x10B0])
 @pytest.mark.parametrize("Hd,Hl,M", [(2048, 2048, 394), (384, 341, 130), (2752, 2730, 300)])
 def test_gemm_swiglu_stats_finalize_and_folded_w3(hip, ref, Hd, Hl, M, flags):
     """SwiGLU GEMM that also emits per-slice LayerNorm partials -> cs_ln_stats_finalize -> w3 GEMM with the LayerNorm folded in,
@@ -325,7 +343,7 @@ def test_gemm_swiglu_stats_finalize_and_folded_w3(hip, ref, Hd, Hl, M, flags):
     check(tag + ".vs_unfolded", out_d - res.cuda(), plain - res, 1e-2)
 
 
-@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x70, 0x80, 0x90, 0xA0, 0xB0, 0x10B0])
+@pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x70, 0x90, 0xB0, 0x10B0])
 @pytest.mark.parametrize("M,C,Hd", [(394, 768, 2048), (130, 192, 384), (1000, 1024, 2752)])
 def test_block_layernorms_folded_into_gemms(hip, ref, M, C, Hd, flags):
     """norm1 -> q|k|v and norm2 -> W1|W2 folded into the GEMM epilogues, fed by the residual GEMM's bf16 copy + row statistics:
@@ -605,7 +623,7 @@ def test_fed_bce(hip, ref):
 
 
 # ------------------------------------------------------------------------------------------------ OpenAI-CLIP ViT family (N4)
-@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x50, 0x70, 0x80, 0x90, 0xA0, 0xB0, 0x10B0])
+@pytest.mark.parametrize("flags", [0, 1, 0x10, 0x20, 0x30, 0x70, 0x90, 0xB0, 0x10B0])
 @pytest.mark.parametrize("quick", [False, True])
 @pytest.mark.parametrize("M,N,K", [(394, 3072, 768), (130, 512, 128), (1000, 4096, 1024)])
 def test_gemm_gelu_epilogues(hip, ref, M, N, K, quick, flags):
@@ -676,7 +694,7 @@ def test_layernorm_fwd_f32_out(hip, ref, C):
 
 
 # ------------------------------------------------------------------------------------------------ persistent-kernel raster / cache-policy modes
-@pytest.mark.parametrize("mode", [0x10090, 0x10190, 0x10290, 0x10490, 0x10890, 0x20090, 0x20290, 0x30090, 0xA0, 0xB0, 0x10B0, 0xB0 | (24 << 20)])      # last: streaming kernel with 24 CUs left free
+@pytest.mark.parametrize("mode", [0x10090, 0x10190, 0x10290, 0x10490, 0x10890, 0x20090, 0x20290, 0x30090, 0xB0, 0x10B0, 0xB0 | (24 << 20)])      # last: streaming kernel with 24 CUs left free
 @pytest.mark.parametrize("M,N,K,epi", [(65536 + 300, 2304, 128, 0), (70000, 4096, 64, 3), (66000, 768, 192, 0), (300, 512, 64, 0)])
 def test_gemm_persistent_raster_modes_cover_every_tile(hip, ref, M, N, K, epi, mode):
     """flags bits 16-17: B-stationary raster (N parts in bits 8-11; 0 = automatic), with non-temporal A loads, and non-temporal B loads on the
