@@ -1,7 +1,6 @@
 // HBM-bound helper kernels of the CLIPSelf step: SiLU*mul (fwd/bwd), f32->bf16 cast, padded bf16 transpose,
 // column sums (bias gradients), patch im2row, CLS-row fill.  All vectorised to 16-byte accesses per lane.
 #include "cs_common.h"
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
 
@@ -148,8 +147,8 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const __bf16* __res
     }
 }
 
-// out[n] (+)= sum_m x[m, n]   (bias gradients; bf16 in, f32 out).  grid.x tiles columns by 256*... each thread one
-// column pair, grid.y splits rows; partial sums combined with hardware float atomics (out pre-zeroed by the step).
+// out[n] += sum_m x[m, n]   (bias gradients; bf16 in, f32 out).  grid.x tiles columns, grid.y splits rows into blocks whose partial sums
+// go to a workspace row each; colsum_reduce_kernel adds them up in a fixed order.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ x, long ldx, float* __restrict__ out, int M, int N,
                                                           int rows_per_block) {
     // 64 column-vectors (8 bf16 = 16 bytes each) x 4 row phases per workgroup; LDS combine, then one atomic per column
@@ -186,8 +185,24 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
     __syncthreads();
     for (int c = threadIdx.x; c < 512; c += 256) {
         const int col = blockIdx.x * 512 + c;
-        if (col < N) unsafeAtomicAdd(out + col, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+        if (col < N) out[(size_t)blockIdx.y * N + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);      // partial row of this row block
     }
+}
+
+// out[n] += sum over the row blocks' partials, in ascending block order (no atomics: the bias gradients are bit-reproducible)
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int nblocks, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblocks; b += 4) {
+        s0 += part[(size_t)b * N + n];
+        s1 += part[(size_t)(b + 1) * N + n];
+        s2 += part[(size_t)(b + 2) * N + n];
+        s3 += part[(size_t)(b + 3) * N + n];
+    }
+    for (; b < nblocks; ++b) s0 += part[(size_t)b * N + n];
+    out[n] += (s0 + s1) + (s2 + s3);
 }
 
 // im2row for the patch-embed conv as a GEMM (reference: nn.Conv2d(3,C,p,stride=p), eva_vit_model.py:348,355).
@@ -291,11 +306,17 @@ extern "C" int cs_transpose_bf16(const void* in, long ld_in, void* out, long ld_
     CS_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int cs_colsum_bf16(const void* x, long ldx, float* out, int M, int N, hipStream_t stream) {
-    CS_CHECK_ARG(M > 0 && N > 0, "cs_colsum_bf16: empty input");
-    const int rows_per_block = 64;       // 768 columns x 12608 rows -> 394 workgroups (was 100: latency-bound at 0.7 TB/s)
-    dim3 grid((N + 511) / 512, (M + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, stream, (const __bf16*)x, ldx, out, M, N, rows_per_block);
+constexpr int COLSUM_ROWS = 64;          // rows per block: 768 columns x 12608 rows -> 394 workgroups (100 were latency-bound at 0.7 TB/s)
+extern "C" size_t cs_colsum_workspace(int M, int N) {
+    return (size_t)((M + COLSUM_ROWS - 1) / COLSUM_ROWS) * (size_t)(N > 0 ? N : 0) * sizeof(float);
+}
+extern "C" int cs_colsum_bf16(const void* x, long ldx, float* out, void* workspace, int M, int N, hipStream_t stream) {
+    CS_CHECK_ARG(M > 0 && N > 0 && workspace != nullptr, "cs_colsum_bf16: empty input or no workspace (cs_colsum_workspace bytes)");
+    const int nblocks = (M + COLSUM_ROWS - 1) / COLSUM_ROWS;
+    dim3 grid((N + 511) / 512, nblocks);
+    hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, stream, (const __bf16*)x, ldx, (float*)workspace, M, N, COLSUM_ROWS);
+    CS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nblocks, N, out);
     CS_LAUNCH_CHECK();
     return 0;
 }

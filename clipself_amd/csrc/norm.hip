@@ -138,23 +138,29 @@ enum { DX_BF16 = 0, DX_F32_ASSIGN = 1, DX_F32_ACCUM = 2 };
 
 // Backward.  One wave per row, grid-stride over rows; per-lane partial dgamma/dbeta are reduced across the
 // workgroup's waves in LDS and written as one partial row per workgroup; ln_param_reduce sums them.
-template <typename TX, int DXMODE, int MAXG>
+// COPY (fp32 dx modes): the updated residual-gradient row also leaves as a bf16 copy (the operand of the next dgrad / wgrad GEMMs) and
+// its column sums -- the bias gradient of the linear layer in front of this LayerNorm's residual branch -- ride along as a third
+// partial row: the `cast_f32_bf16` + `colsum_bf16` passes over the stream that used to follow every such LayerNorm backward are gone,
+// and the sums are combined in a fixed order (no atomics).
+template <typename TX, int DXMODE, int MAXG, bool COPY>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, long lddy, const TX* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, void* __restrict__ dx, long lddx,
-                                                     float* __restrict__ part, int M, int C) {
+                                                     __bf16* __restrict__ dxb, long lddxb, float* __restrict__ part, int M, int C) {
+    static_assert(!COPY || DXMODE != DX_BF16, "the bf16 copy exists for the fp32 stream modes");
+    constexpr int NR = COPY ? 3 : 2;               // partial rows: dgamma, dbeta[, column sums of the bf16 copy]
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* red = (float*)smem_raw;                 // [3 waves][2][C]
+    float* red = (float*)smem_raw;                 // [3 waves][NR][Cp]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ng = (C + 255) >> 8;
-    const int Cp = (C + 3) & ~3;                   // partial rows are laid out [2][Cp] so that float4 accesses stay aligned
+    const int Cp = (C + 3) & ~3;                   // partial rows are laid out [NR][Cp] so that float4 accesses stay aligned
     const int clast = (C - 1) & ~3;
-    float dg[MAXG][4], db[MAXG][4], ga[MAXG][4];
+    float dg[MAXG][4], db[MAXG][4], ga[MAXG][4], dc[COPY ? MAXG : 1][4];
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) {
         const int c = (g * 64 + lane) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { dg[g][i] = 0.f; db[g][i] = 0.f; ga[g][i] = 0.f; }
+        for (int i = 0; i < 4; ++i) { dg[g][i] = 0.f; db[g][i] = 0.f; ga[g][i] = 0.f; if (COPY) dc[g][i] = 0.f; }
         if (g < ng && c < C) { const float4 t = *(const float4*)(gamma + c); ga[g][0] = t.x; ga[g][1] = t.y; ga[g][2] = t.z; ga[g][3] = t.w; }
     }
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
@@ -205,6 +211,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
                         o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
                     }
                     *(float4*)p = make_float4(o[0], o[1], o[2], o[3]);
+                    if (COPY) {
+                        U64 t;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            t.e[i] = f2bf(o[i]);
+                            dc[g][i] += (c + i < C) ? bf2f(t.e[i]) : 0.f;      // sums of the ROUNDED values: what a colsum over the copy gives
+                        }
+                        *(uint2*)(dxb + (size_t)row * lddxb + c) = t.u;
+                    }
                 }
             }
         }
@@ -212,58 +227,69 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
     if (part == nullptr) return;
     // cross-wave reduction of dgamma/dbeta: waves 1..3 publish, wave 0 sums (fixed order -> deterministic)
     if (wave > 0) {
-        float* mine = red + (size_t)(wave - 1) * 2 * Cp;
+        float* mine = red + (size_t)(wave - 1) * NR * Cp;
 #pragma unroll
         for (int g = 0; g < MAXG; ++g) {
             const int c = (g * 64 + lane) * 4;
             if (g < ng && c < C) {
                 *(float4*)(mine + c) = make_float4(dg[g][0], dg[g][1], dg[g][2], dg[g][3]);
                 *(float4*)(mine + Cp + c) = make_float4(db[g][0], db[g][1], db[g][2], db[g][3]);
+                if (COPY) *(float4*)(mine + 2 * Cp + c) = make_float4(dc[g][0], dc[g][1], dc[g][2], dc[g][3]);
             }
         }
     }
     __syncthreads();
     if (wave == 0) {
-        float* outp = part + (size_t)blockIdx.x * 2 * Cp;
+        float* outp = part + (size_t)blockIdx.x * NR * Cp;
 #pragma unroll
         for (int g = 0; g < MAXG; ++g) {
             const int c = (g * 64 + lane) * 4;
             if (g < ng && c < C) {
                 float a[4] = {dg[g][0], dg[g][1], dg[g][2], dg[g][3]};
                 float b[4] = {db[g][0], db[g][1], db[g][2], db[g][3]};
+                float cc[4] = {0.f, 0.f, 0.f, 0.f};
+                if (COPY) { cc[0] = dc[g][0]; cc[1] = dc[g][1]; cc[2] = dc[g][2]; cc[3] = dc[g][3]; }
                 for (int w = 0; w < 3; ++w) {
-                    const float4 t = *(const float4*)(red + (size_t)w * 2 * Cp + c);
-                    const float4 u = *(const float4*)(red + (size_t)w * 2 * Cp + Cp + c);
+                    const float4 t = *(const float4*)(red + (size_t)w * NR * Cp + c);
+                    const float4 u = *(const float4*)(red + (size_t)w * NR * Cp + Cp + c);
                     a[0] += t.x; a[1] += t.y; a[2] += t.z; a[3] += t.w;
                     b[0] += u.x; b[1] += u.y; b[2] += u.z; b[3] += u.w;
+                    if (COPY) {
+                        const float4 v = *(const float4*)(red + (size_t)w * NR * Cp + 2 * Cp + c);
+                        cc[0] += v.x; cc[1] += v.y; cc[2] += v.z; cc[3] += v.w;
+                    }
                 }
                 *(float4*)(outp + c) = make_float4(a[0], a[1], a[2], a[3]);
                 *(float4*)(outp + Cp + c) = make_float4(b[0], b[1], b[2], b[3]);
+                if (COPY) *(float4*)(outp + 2 * Cp + c) = make_float4(cc[0], cc[1], cc[2], cc[3]);
             }
         }
     }
 }
 
-// part [nparts][2][C] -> dgamma[C] (+=), dbeta[C] (+=)
+// part [nparts][NR][Cp] -> out0[C] (dgamma), out1[C] (dbeta)[, out2[C] (column sums)], each nullable; += when accumulate
 // 16 columns per workgroup, 16 thread groups split the partial rows (4 loads in flight each), LDS combine in fixed order
 // (deterministic).  96 workgroups for C = 768 instead of 24 with one dependent load chain of 128 per thread.
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int accumulate) {
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nparts, int C, int NR, float* __restrict__ out0,
+                                                              float* __restrict__ out1, float* __restrict__ out2, int accumulate) {
     __shared__ float red[16][16];
     const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int Cp = (C + 3) & ~3;
-    const int c = blockIdx.x * 16 + cl;              // index into a [2][Cp] partial row
-    const bool live = c < 2 * Cp && (c < Cp ? c : c - Cp) < C;
+    const int c = blockIdx.x * 16 + cl;              // index into a [NR][Cp] partial row
+    const int r = c / Cp, cc = c - r * Cp;
+    float* const outs[3] = {out0, out1, out2};
+    const bool live = r < NR && cc < C && outs[r < 3 ? r : 0] != nullptr;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const size_t stride = (size_t)NR * Cp;
     if (live) {
         int p = grp;
         for (; p + 48 < nparts; p += 64) {
-            s0 += part[(size_t)p * 2 * Cp + c];
-            s1 += part[(size_t)(p + 16) * 2 * Cp + c];
-            s2 += part[(size_t)(p + 32) * 2 * Cp + c];
-            s3 += part[(size_t)(p + 48) * 2 * Cp + c];
+            s0 += part[(size_t)p * stride + c];
+            s1 += part[(size_t)(p + 16) * stride + c];
+            s2 += part[(size_t)(p + 32) * stride + c];
+            s3 += part[(size_t)(p + 48) * stride + c];
         }
-        for (; p < nparts; p += 16) s0 += part[(size_t)p * 2 * Cp + c];
+        for (; p < nparts; p += 16) s0 += part[(size_t)p * stride + c];
     }
     red[grp][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -271,7 +297,7 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) s += red[g][cl];
-        float* dst = c < Cp ? dgamma + c : dbeta + (c - Cp);
+        float* dst = outs[r] + cc;
         *dst = accumulate ? *dst + s : s;
     }
 }
@@ -359,29 +385,40 @@ extern "C" int cs_ln_stats_finalize(const float* part, int P, int npp, int C, in
 }
 
 // dx_mode: 0 = write bf16, 1 = write f32, 2 = accumulate into f32 (residual-gradient stream).
-// dgamma/dbeta may be null (frozen LN); otherwise `workspace` must hold cs_layernorm_bwd_workspace(M,C) bytes.
+// dgamma/dbeta may be null (frozen LN); dx_copy (fp32 modes only, nullable): bf16 copy of the dx rows after the write / accumulate, row
+// stride ldcopy, with copy_colsum[C] (nullable) += / = its column sums.  `workspace` must hold cs_layernorm_bwd_workspace(M,C) bytes
+// whenever dgamma or copy_colsum is given.
 extern "C" size_t cs_layernorm_bwd_workspace(int M, int C) {
     const int nwg = min(512, (M + 3) / 4);
-    return (size_t)nwg * 2 * ((C + 3) & ~3) * sizeof(float);
+    return (size_t)nwg * 3 * ((C + 3) & ~3) * sizeof(float);
 }
 extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
                                 const float* rstd, void* dx, int dx_mode, long lddx, float* dgamma, float* dbeta,
-                                int accumulate_params, void* workspace, int M, int C, hipStream_t stream) {
+                                int accumulate_params, void* workspace, void* dx_copy, long ldcopy, float* copy_colsum, int M, int C,
+                                hipStream_t stream) {
     CS_CHECK_ARG(C <= MAXC && (C % 4 == 0 || (ldx >= ((C + 3) & ~3) && lddy >= ((C + 3) & ~3) && lddx >= ((C + 3) & ~3))), "cs_layernorm_bwd: C=%d unsupported", C);
     CS_CHECK_ARG(M > 0, "cs_layernorm_bwd: empty input");
     CS_CHECK_ARG(dx_mode >= 0 && dx_mode <= 2, "cs_layernorm_bwd: bad dx_mode");
     CS_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "cs_layernorm_bwd: dgamma/dbeta must both be given or both null");
-    CS_CHECK_ARG(dgamma == nullptr || workspace != nullptr, "cs_layernorm_bwd: workspace required for dgamma/dbeta");
+    CS_CHECK_ARG(dx_copy == nullptr || (dx_mode != 0 && ldcopy >= ((C + 3) & ~3) && ldcopy % 4 == 0 && ((uintptr_t)dx_copy % 8) == 0),
+                 "cs_layernorm_bwd: the bf16 copy exists for the fp32 dx modes (8-byte aligned rows, ldcopy >= C rounded up to 4)");
+    CS_CHECK_ARG(copy_colsum == nullptr || dx_copy != nullptr, "cs_layernorm_bwd: copy_colsum are the column sums of dx_copy");
+    const bool need_part = dgamma != nullptr || copy_colsum != nullptr;
+    CS_CHECK_ARG(!need_part || workspace != nullptr, "cs_layernorm_bwd: workspace required for dgamma/dbeta / copy_colsum");
     const int nwg = min(512, (M + 3) / 4);
-    float* part = dgamma ? (float*)workspace : nullptr;
-    const size_t lds = (size_t)3 * 2 * ((C + 3) & ~3) * sizeof(float);
+    float* part = need_part ? (float*)workspace : nullptr;
+    const bool copy = dx_copy != nullptr;
+    const int NR = copy ? 3 : 2;
+    const size_t lds = (size_t)3 * NR * ((C + 3) & ~3) * sizeof(float);
     dim3 grid(nwg), block(256);
-#define LNB3(TX, MODE, NG)                                                                                                  \
+#define LNB4(TX, MODE, NG, CP)                                                                                              \
     do {                                                                                                                    \
-        static bool once = (hipFuncSetAttribute((const void*)ln_bwd_kernel<TX, MODE, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * MAXC * 4), true); \
+        static bool once = (hipFuncSetAttribute((const void*)ln_bwd_kernel<TX, MODE, NG, CP>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * MAXC * 4), true); \
         (void)once;                                                                                                         \
-        hipLaunchKernelGGL((ln_bwd_kernel<TX, MODE, NG>), grid, block, lds, stream, (const __bf16*)dy, lddy, (const TX*)x, ldx, gamma, mean, rstd, dx, lddx, part, M, C); \
+        hipLaunchKernelGGL((ln_bwd_kernel<TX, MODE, NG, CP>), grid, block, lds, stream, (const __bf16*)dy, lddy, (const TX*)x, ldx, gamma, mean, rstd, dx, lddx, \
+                           (__bf16*)dx_copy, ldcopy, part, M, C);                                                          \
     } while (0)
+#define LNB3(TX, MODE, NG) do { if (copy) { if constexpr (MODE != DX_BF16) LNB4(TX, MODE, NG, true); } else LNB4(TX, MODE, NG, false); } while (0)
 #define LNB(TX, MODE) do { if (C <= 1024) LNB3(TX, MODE, 4); else if (C <= 2048) LNB3(TX, MODE, 8); else LNB3(TX, MODE, 12); } while (0)
     if (x_dtype == 0) {
         if (dx_mode == 0) LNB(float, DX_BF16); else if (dx_mode == 1) LNB(float, DX_F32_ASSIGN); else LNB(float, DX_F32_ACCUM);
@@ -390,9 +427,11 @@ extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_
     }
 #undef LNB
 #undef LNB3
+#undef LNB4
     CS_LAUNCH_CHECK();
-    if (dgamma) {
-        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * ((C + 3) & ~3) + 15) / 16), dim3(256), 0, stream, part, nwg, C, dgamma, dbeta, accumulate_params);
+    if (need_part) {
+        hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((NR * ((C + 3) & ~3) + 15) / 16), dim3(256), 0, stream, part, nwg, C, NR, dgamma, dbeta,
+                           copy_colsum, accumulate_params);
         CS_LAUNCH_CHECK();
     }
     return 0;

@@ -680,8 +680,10 @@ class EvaEngine:
         self.ops.transpose_bf16(X, Xt)
         return Xt
 
-    def _block_bwd(self, i, s, g, B, N, cos, sin, ws):
-        """g: fp32 [M,C] gradient w.r.t. the block output; updated in place to the gradient w.r.t. its input."""
+    def _block_bwd(self, i, s, g, gb, B, N, cos, sin, ws, next_bias=None):
+        """g: fp32 [M,C] gradient w.r.t. the block output; updated in place to the gradient w.r.t. its input.  gb: its bf16 copy, already
+        summed into this block's w3 bias gradient by the LayerNorm backward that produced it (the final norm's, or norm1's of block i+1);
+        on return gb is the copy of the new g and its column sums have gone to `next_bias` (block i-1's w3 bias gradient, or None)."""
         ops, cfg = self.ops, self.cfg
         C, Hd, Hl, H = cfg.width, self.Hp, cfg.hidden, cfg.heads
         padded = Hd != Hl
@@ -689,49 +691,49 @@ class EvaEngine:
         M = B * N
         G = self.g
         # ---- MLP: x2 = x1 + w3(ffn_ln(silu(x1')*x2')) ------------------------------------------
-        gb = ops.empty((M, C), BF16)
-        ops.cast_f32_bf16(g, gb)
-        ops.colsum_bf16(gb, G[b + "mlp.w3.bias"])
         self._wgrad(gb, s["fln"], self.storage_of(self.grad, b + "mlp.w3.weight"))
         d_fln = ops.empty((M, Hd), BF16)
         ops.gemm_nt(gb, self.wt[(i, "w3")][:, :C], d_fln, epi=EPI_BF16)                     # [M,C] . W3[C,Hd]
         d_hid = (ops.zeros if padded else ops.empty)((M, Hd), BF16)
         ops.layernorm_bwd(d_fln[:, :Hl], s["hid"][:, :Hl], self.p[b + "mlp.ffn_ln.weight"], *s["st4"], d_hid[:, :Hl], DX_BF16,
-                          G[b + "mlp.ffn_ln.weight"], G[b + "mlp.ffn_ln.bias"], True, ws)
+                          G[b + "mlp.ffn_ln.weight"], G[b + "mlp.ffn_ln.bias"], True, ws[0])
         d_x12 = ops.empty((M, 2 * Hd), BF16)
         ops.swiglu_bwd(d_hid, s["x12"], d_x12)
         ob = self.offsets[b + "mlp.w1.bias"][0]
-        ops.colsum_bf16(d_x12, self.grad[ob:ob + 2 * Hd])
+        ops.colsum_bf16(d_x12, self.grad[ob:ob + 2 * Hd], ws[1])
         ow = self.offsets[b + "mlp.w1.weight"][0]
         self._wgrad(d_x12, s["ln2"], self.grad[ow:ow + 2 * Hd * C].view(2 * Hd, C))
         d_ln2 = ops.empty((M, C), BF16)
         ops.gemm_nt(d_x12, self.wt[(i, "w12")][:, :2 * Hd], d_ln2, epi=EPI_BF16)            # [M,2Hd] . W12[2Hd,C]
+        # norm2's backward adds into the stream gradient and hands back its bf16 copy + column sums (= the proj bias gradient)
         ops.layernorm_bwd(d_ln2, s["x1"], self.p[b + "norm2.weight"], *s["st3"], g, DX_F32_ACCUM,
-                          G[b + "norm2.weight"], G[b + "norm2.bias"], True, ws)
+                          G[b + "norm2.weight"], G[b + "norm2.bias"], True, ws[0], dx_copy=gb, copy_colsum=G[b + "attn.proj.bias"])
         # ---- attention branch: x1 = x0 + proj(inner_ln(att)) -------------------------------------
-        ops.cast_f32_bf16(g, gb)
-        ops.colsum_bf16(gb, G[b + "attn.proj.bias"])
         self._wgrad(gb, s["iln"], G[b + "attn.proj.weight"])
         d_iln = ops.empty((M, C), BF16)
         ops.gemm_nt(gb, self.wt[(i, "proj")][:, :C], d_iln, epi=EPI_BF16)
         d_att = ops.empty((M, C), BF16)
         ops.layernorm_bwd(d_iln, s["att"], self.p[b + "attn.inner_attn_ln.weight"], *s["st2"], d_att, DX_BF16,
-                          G[b + "attn.inner_attn_ln.weight"], G[b + "attn.inner_attn_ln.bias"], True, ws)
+                          G[b + "attn.inner_attn_ln.weight"], G[b + "attn.inner_attn_ln.bias"], True, ws[0])
         oq = self.offsets[b + "attn.q_proj.weight"][0]
         d_ln1 = ops.empty((M, C), BF16)
         if s["with_attn"]:
             d_qkv = ops.empty((M, 3 * C), BF16)
-            ops.attn_bwd(s["qkv"], s["att"], d_att, s["lse"], cos, sin, d_qkv, ws, B, N, H, cfg.head_width ** -0.5)
-            ops.colsum_bf16(d_qkv[:, :C], G[b + "attn.q_bias"])        # K has no bias (eva_vit_model.py:178)
-            ops.colsum_bf16(d_qkv[:, 2 * C:], G[b + "attn.v_bias"])
+            ops.attn_bwd(s["qkv"], s["att"], d_att, s["lse"], cos, sin, d_qkv, ws[0], B, N, H, cfg.head_width ** -0.5)
+            # one pass over d_q|d_k|d_v into the adjacent [q_bias; (k: no bias, eva_vit_model.py:178); v_bias] gradient slots; the middle slot
+            # belongs to no parameter and goes back to zero (the flat gradient's norm must be the parameters' gradient norm)
+            obq = self.offsets[b + "attn.q_bias"][0]
+            ops.colsum_bf16(d_qkv, self.grad[obq:obq + 3 * C], ws[1])
+            self.grad[obq + C:obq + 2 * C].zero_()
             self._wgrad(d_qkv, s["ln1"], self.grad[oq:oq + 3 * C * C].view(3 * C, C))
             ops.gemm_nt(d_qkv, self.wt[(i, "qkv")][:, :3 * C], d_ln1, epi=EPI_BF16)
         else:
-            ops.colsum_bf16(d_att, G[b + "attn.v_bias"])
+            ops.colsum_bf16(d_att, G[b + "attn.v_bias"], ws[1])
             self._wgrad(d_att, s["ln1"], G[b + "attn.v_proj.weight"])
             ops.gemm_nt(d_att, self.wt[(i, "qkv")][:, 2 * C:3 * C], d_ln1, epi=EPI_BF16)
         ops.layernorm_bwd(d_ln1, s["x0"], self.p[b + "norm1.weight"], *s["st1"], g, DX_F32_ACCUM,
-                          G[b + "norm1.weight"], G[b + "norm1.bias"], True, ws)
+                          G[b + "norm1.weight"], G[b + "norm1.bias"], True, ws[0], dx_copy=gb if next_bias is not None else None,
+                          copy_colsum=next_bias)
 
     def backward_dense(self, d_dense):
         """d_dense: fp32 [B, N, E] gradient w.r.t. the normalised token map (CLS rows zero).  Accumulates every
@@ -748,21 +750,25 @@ class EvaEngine:
         d_lnf = ops.empty((M, C), BF16)
         ops.gemm_nt(d_feats, self.wt["head"][:, :E], d_lnf, epi=EPI_BF16)                  # dgrad through the head
         g = ops.empty((M, C), F32)
+        gb = ops.empty((M, C), BF16)                  # bf16 copy of g, written by the LayerNorm backwards that update g
         ws_bytes = max(ops.layernorm_bwd_workspace(M, max(C, self.Hp)), ops.attn_bwd_workspace(B, N, cfg.heads))
-        ws = ops.empty((ws_bytes,), torch.uint8)
+        ws = (ops.empty((ws_bytes,), torch.uint8), ops.empty((max(ops.colsum_workspace(M, max(2 * self.Hp, 3 * C)), 4),), torch.uint8))
+        L, first = cfg.layers, self.first_trainable
+        w3_bias = lambda i: self.g[f"{P}blocks.{i}.mlp.w3.bias"] if i >= first else None
         if self.train_all:
             # head (eva_vit_model.py:617) and final norm (:616) train: bias = column sums, weight = dY^T . LN(x), LayerNorm gamma / beta.
             # The CLS rows of d_feats are exact zeros (the dense map drops them, :615), so they add nothing to any of the sums.
-            ops.colsum_bf16(d_feats, self.g[P + "head.bias"])
+            ops.colsum_bf16(d_feats, self.g[P + "head.bias"], ws[1])
             self._wgrad(d_feats, c["lnf"], self.g[P + "head.weight"])
             ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "norm.weight"], *c["stf"], g, DX_F32_ASSIGN,
-                              self.g[P + "norm.weight"], self.g[P + "norm.bias"], True, ws)
+                              self.g[P + "norm.weight"], self.g[P + "norm.bias"], True, ws[0], dx_copy=gb, copy_colsum=w3_bias(L - 1))
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook("head")
-        else:
-            ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "norm.weight"], *c["stf"], g, DX_F32_ASSIGN)   # head and final norm frozen
-        for i in range(cfg.layers - 1, self.first_trainable - 1, -1):
-            self._block_bwd(i, c["saves"].pop(i), g, B, N, c["cos"], c["sin"], ws)
+        else:                                                                                   # head and final norm frozen
+            ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "norm.weight"], *c["stf"], g, DX_F32_ASSIGN, None, None, True, ws[0],
+                              dx_copy=gb if first < L else None, copy_colsum=w3_bias(L - 1))
+        for i in range(L - 1, first - 1, -1):
+            self._block_bwd(i, c["saves"].pop(i), g, gb, B, N, c["cos"], c["sin"], ws, next_bias=w3_bias(i - 1) if i > 0 else None)
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook(i)
         if self.train_all:
@@ -791,7 +797,7 @@ class EvaEngine:
                 (d_pe,) = torch.autograd.grad(out, pe, d_pos[1:].T.reshape(1, C, grid, grid))
             gpos[1:].add_(d_pe.reshape(C, cfg.grid * cfg.grid).T)
         gp = g3[:, 1:, :].to(BF16).reshape(B * (N - 1), C)                      # patch rows, in the im2row matrix's row order
-        ops.colsum_bf16(gp, self.g[P + "patch_embed.proj.bias"])
+        ops.colsum_bf16(gp, self.g[P + "patch_embed.proj.bias"])          # (allocates its own row-block workspace: once per step)
         self._wgrad(gp, patches, self.storage_of(self.grad, P + "patch_embed.proj.weight"))
 
     def roi_pool_backward(self, d_pooled, rois, B, N, g):

@@ -315,31 +315,27 @@ class ClipVitEngine(EvaEngine):
         return dense.view(B, N, E), g
 
     # ------------------------------------------------------------------------------------------ backward
-    def _block_bwd(self, i, s, g, B, N, cos, sin, ws):
-        """g: fp32 [M,C] gradient w.r.t. the block output; updated in place to the gradient w.r.t. its input."""
+    def _block_bwd(self, i, s, g, gb, B, N, cos, sin, ws, next_bias=None):
+        """g: fp32 [M,C] gradient w.r.t. the block output; updated in place to the gradient w.r.t. its input.  gb / next_bias: as in
+        EvaEngine._block_bwd (the bf16 copy of g and its column sums come out of the LayerNorm backwards)."""
         ops, cfg = self.ops, self.cfg
         C, Hd, H = cfg.width, cfg.hidden, cfg.heads
         b = f"{self.prefix}{self.BLOCK_TAG}{i}."
         M = B * N
         G = self.g
         # ---- MLP: x2 = x1 + c_proj(act(c_fc(ln_2 x1))) --------------------------------------------
-        gb = ops.empty((M, C), BF16)
-        ops.cast_f32_bf16(g, gb)
-        ops.colsum_bf16(gb, G[b + "mlp.c_proj.bias"])
         self._wgrad(gb, s["hid"], G[b + "mlp.c_proj.weight"])
         d_hid = ops.empty((M, Hd), BF16)
         ops.gemm_nt(gb, self.wt[(i, "cproj")][:, :C], d_hid, epi=EPI_BF16)                   # [M,C] . c_proj[C,Hd]
         d_fc = ops.empty((M, Hd), BF16)
         ops.gelu_bwd(d_hid, s["fc"], d_fc, cfg.quick_gelu)
-        ops.colsum_bf16(d_fc, G[b + "mlp.c_fc.bias"])
+        ops.colsum_bf16(d_fc, G[b + "mlp.c_fc.bias"], ws[1])
         self._wgrad(d_fc, s["ln2"], G[b + "mlp.c_fc.weight"])
         d_ln2 = ops.empty((M, C), BF16)
         ops.gemm_nt(d_fc, self.wt[(i, "fc")][:, :Hd], d_ln2, epi=EPI_BF16)                   # [M,Hd] . c_fc[Hd,C]
         ops.layernorm_bwd(d_ln2, s["x1"], self.p[b + "ln_2.weight"], *s["st2"], g, DX_F32_ACCUM,
-                          G[b + "ln_2.weight"], G[b + "ln_2.bias"], True, ws)
+                          G[b + "ln_2.weight"], G[b + "ln_2.bias"], True, ws[0], dx_copy=gb, copy_colsum=G[b + "attn.out_proj.bias"])
         # ---- attention branch: x1 = x0 + out_proj(att) ------------------------------------------
-        ops.cast_f32_bf16(g, gb)
-        ops.colsum_bf16(gb, G[b + "attn.out_proj.bias"])
         self._wgrad(gb, s["att"], G[b + "attn.out_proj.weight"])
         d_att = ops.empty((M, C), BF16)
         ops.gemm_nt(gb, self.wt[(i, "proj")][:, :C], d_att, epi=EPI_BF16)
@@ -347,16 +343,17 @@ class ClipVitEngine(EvaEngine):
         Gw, Gb = G[b + "attn.in_proj_weight"], G[b + "attn.in_proj_bias"]
         if s["with_attn"]:
             d_qkv = ops.empty((M, 3 * C), BF16)
-            ops.attn_bwd(s["qkv"], s["att"], d_att, s["lse"], cos, sin, d_qkv, ws, B, N, H, cfg.head_width ** -0.5)
-            ops.colsum_bf16(d_qkv, Gb)                                                       # q, k and v all carry a bias here
+            ops.attn_bwd(s["qkv"], s["att"], d_att, s["lse"], cos, sin, d_qkv, ws[0], B, N, H, cfg.head_width ** -0.5)
+            ops.colsum_bf16(d_qkv, Gb, ws[1])                                                # q, k and v all carry a bias here
             self._wgrad(d_qkv, s["ln1"], Gw)
             ops.gemm_nt(d_qkv, self.wt[(i, "qkv")][:, :3 * C], d_ln1, epi=EPI_BF16)
         else:
-            ops.colsum_bf16(d_att, Gb[2 * C:])                                               # q/k rows keep their zero gradient
+            ops.colsum_bf16(d_att, Gb[2 * C:], ws[1])                                        # q/k rows keep their zero gradient
             self._wgrad(d_att, s["ln1"], Gw[2 * C:])
             ops.gemm_nt(d_att, self.wt[(i, "qkv")][:, 2 * C:3 * C], d_ln1, epi=EPI_BF16)
         ops.layernorm_bwd(d_ln1, s["x0"], self.p[b + "ln_1.weight"], *s["st1"], g, DX_F32_ACCUM,
-                          G[b + "ln_1.weight"], G[b + "ln_1.bias"], True, ws)
+                          G[b + "ln_1.weight"], G[b + "ln_1.bias"], True, ws[0], dx_copy=gb if next_bias is not None else None,
+                          copy_colsum=next_bias)
 
     def backward_dense(self, d_dense):
         ops, cfg, P = self.ops, self.cfg, self.prefix
@@ -371,10 +368,14 @@ class ClipVitEngine(EvaEngine):
         d_lnf = ops.empty((M, C), BF16)
         ops.gemm_nt(d_feats, self.w[P + "proj"], d_lnf, epi=EPI_BF16)                        # [M,E] . proj^T: proj [C,E] is already "W^T"; frozen
         g = ops.empty((M, C), F32)
-        ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "ln_post.weight"], *c["stf"], g, DX_F32_ASSIGN)   # ln_post frozen (transformer.py:405)
+        gb = ops.empty((M, C), BF16)
         ws_bytes = max(ops.layernorm_bwd_workspace(M, C), ops.attn_bwd_workspace(B, N, cfg.heads))
-        ws = ops.empty((ws_bytes,), torch.uint8)
-        for i in range(cfg.layers - 1, self.first_trainable - 1, -1):
-            self._block_bwd(i, c["saves"].pop(i), g, B, N, c["cos"], c["sin"], ws)
+        ws = (ops.empty((ws_bytes,), torch.uint8), ops.empty((max(ops.colsum_workspace(M, max(cfg.hidden, 3 * C)), 4),), torch.uint8))
+        L, first = cfg.layers, self.first_trainable
+        cproj_bias = lambda i: self.g[f"{P}{self.BLOCK_TAG}{i}.mlp.c_proj.bias"] if i >= first else None
+        ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "ln_post.weight"], *c["stf"], g, DX_F32_ASSIGN, None, None, True, ws[0],   # ln_post frozen
+                          dx_copy=gb if first < L else None, copy_colsum=cproj_bias(L - 1))                                    # (transformer.py:405)
+        for i in range(L - 1, first - 1, -1):
+            self._block_bwd(i, c["saves"].pop(i), g, gb, B, N, c["cos"], c["sin"], ws, next_bias=cproj_bias(i - 1) if i > 0 else None)
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook(i)

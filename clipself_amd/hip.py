@@ -42,7 +42,7 @@ SIGNATURES = {
     "cs_layernorm_fwd": (_i, [_vp, _i, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _vp]),
     "cs_layernorm_fwd_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _vp]),
     "cs_layernorm_bwd_workspace": (_sz, [_i, _i]),
-    "cs_layernorm_bwd": (_i, [_vp, _l, _vp, _i, _l, _vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "cs_layernorm_bwd": (_i, [_vp, _l, _vp, _i, _l, _vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _vp, _l, _vp, _i, _i, _vp]),
     "cs_l2norm_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "cs_l2norm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "cs_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
@@ -55,7 +55,8 @@ SIGNATURES = {
     "cs_gelu_bwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _vp]),
     "cs_cast_f32_bf16": (_i, [_vp, _vp, _l, _vp]),
     "cs_transpose_bf16": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
-    "cs_colsum_bf16": (_i, [_vp, _l, _vp, _i, _i, _vp]),
+    "cs_colsum_workspace": (_sz, [_i, _i]),
+    "cs_colsum_bf16": (_i, [_vp, _l, _vp, _vp, _i, _i, _vp]),
     "cs_im2row": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "cs_cls_row": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "cs_roialign_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -300,12 +301,17 @@ class HipOps:
     def layernorm_bwd_workspace(self, M, C) -> int:
         return int(self.lib.cs_layernorm_bwd_workspace(M, C))
 
-    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dx_mode, dgamma=None, dbeta=None, accumulate=False, workspace=None):
-        self._chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace)
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dx_mode, dgamma=None, dbeta=None, accumulate=False, workspace=None,
+                      dx_copy=None, copy_colsum=None):
+        """dx_copy (fp32 dx modes): bf16 copy of the updated dx rows; copy_colsum [C]: (+)= its column sums (a bias gradient)."""
+        self._chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, dx_copy, copy_colsum)
         M, C = x.shape
+        if dx_copy is not None:
+            assert dx_copy.dtype == torch.bfloat16 and dx_copy.shape == (M, C) and dx_copy.stride(1) == 1
         self._ok(self.lib.cs_layernorm_bwd(_p(dy), dy.stride(0), _p(x), _dt(x), x.stride(0), _p(gamma), _p(mean), _p(rstd),
                                            _p(dx), dx_mode, dx.stride(0), _p(dgamma), _p(dbeta), int(accumulate),
-                                           _p(workspace), M, C, self._stream()), "cs_layernorm_bwd")
+                                           _p(workspace), _p(dx_copy), dx_copy.stride(0) if dx_copy is not None else 0, _p(copy_colsum),
+                                           M, C, self._stream()), "cs_layernorm_bwd")
 
     def l2norm_fwd(self, x, y, inv_norm, eps=1e-12):
         self._chk(x, y, inv_norm)
@@ -372,10 +378,18 @@ class HipOps:
         assert out.shape[0] == Cc and out.is_contiguous()
         self._ok(self.lib.cs_transpose_bf16(_p(inp), inp.stride(0), _p(out), out.shape[1], R, Cc, self._stream()), "cs_transpose_bf16")
 
-    def colsum_bf16(self, x, out):
-        self._chk(x, out)
+    def colsum_workspace(self, M, N) -> int:
+        return int(self.lib.cs_colsum_workspace(M, N))
+
+    def colsum_bf16(self, x, out, workspace=None):
+        """out[n] += sum_m x[m, n] in a fixed order (row-block partials through `workspace`, >= colsum_workspace(M, N) bytes; allocated
+        here when not given)."""
+        self._chk(x, out, workspace)
         M, N = x.shape
-        self._ok(self.lib.cs_colsum_bf16(_p(x), x.stride(0), _p(out), M, N, self._stream()), "cs_colsum_bf16")
+        need = self.colsum_workspace(M, N)
+        if workspace is None or workspace.numel() * workspace.element_size() < need:
+            workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+        self._ok(self.lib.cs_colsum_bf16(_p(x), x.stride(0), _p(out), _p(workspace), M, N, self._stream()), "cs_colsum_bf16")
 
     def im2row(self, img, out, p):
         self._chk(img, out)

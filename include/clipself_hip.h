@@ -103,10 +103,13 @@ int cs_ln_stats_finalize(const float* part, int P, int npp, int C, int M, float 
 int cs_layernorm_fwd_f32(const float* x, long ldx, const float* gamma, const float* beta, float* y, long ldy, float* mean, float* rstd,
                          int M, int C, float eps, cs_stream_t stream);
 size_t cs_layernorm_bwd_workspace(int M, int C);
-/* dx_mode 0: bf16 write, 1: f32 write, 2: f32 accumulate (residual gradient stream).  dgamma/dbeta nullable (frozen). */
+/* dx_mode 0: bf16 write, 1: f32 write, 2: f32 accumulate (residual gradient stream).  dgamma/dbeta nullable (frozen).
+ * dx_copy (modes 1 / 2, nullable): bf16 copy of the dx rows after the write / accumulate (row stride ldcopy) -- the operand of the next
+ * dgrad / wgrad GEMMs -- and copy_colsum[C] (nullable) (+)= its column sums = the bias gradient of the linear layer that feeds this
+ * residual branch (autograd of x = x + Linear(..) in Block.forward, eva_vit_model.py:306-307): no cast / column-sum pass of their own. */
 int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
                      const float* rstd, void* dx, int dx_mode, long lddx, float* dgamma, float* dbeta, int accumulate_params,
-                     void* workspace, int M, int C, cs_stream_t stream);
+                     void* workspace, void* dx_copy, long ldcopy, float* copy_colsum, int M, int C, cs_stream_t stream);
 
 /* --- F.normalize(x, dim=-1) of the dense token map: eva_vit_model.py:620 (eps 1e-12) and its backward. */
 int cs_l2norm_fwd(const float* x, float* y, float* inv_norm, int M, int C, float eps, cs_stream_t stream);
@@ -144,7 +147,8 @@ int cs_gelu_bwd(const void* dy, long lddy, const void* x, long ldx, void* dx, lo
 /* --- data movement helpers of the step */
 int cs_cast_f32_bf16(const float* x, void* y, long n, cs_stream_t stream);
 int cs_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int Cc, cs_stream_t stream); /* out[c,r]; zero pad r in [R, ld_out) */
-int cs_colsum_bf16(const void* x, long ldx, float* out, int M, int N, cs_stream_t stream);                    /* out[n] += sum_m x[m,n] (bias grads) */
+size_t cs_colsum_workspace(int M, int N);
+int cs_colsum_bf16(const void* x, long ldx, float* out, void* workspace, int M, int N, cs_stream_t stream);   /* out[n] += sum_m x[m,n] (bias grads); fixed summation order, no atomics */
 int cs_im2row(const void* img, int img_dtype, void* out, int B, int S, int p, int ldo, cs_stream_t stream);    /* PatchEmbed unfold, eva_vit_model.py:355 */
 int cs_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok, int C, cs_stream_t stream);      /* x[b,0,:] = cls + pos[0], :540-543 */
 

@@ -243,7 +243,8 @@ class RefOps:
     def layernorm_bwd_workspace(self, M, C):
         return 4
 
-    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dx_mode, dgamma=None, dbeta=None, accumulate=False, workspace=None):
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dx_mode, dgamma=None, dbeta=None, accumulate=False, workspace=None,
+                      dx_copy=None, copy_colsum=None):
         xh = (x.float() - mean[:, None]) * rstd[:, None]
         g = dy.float()
         gy = g * gamma
@@ -263,6 +264,15 @@ class RefOps:
             else:
                 dgamma.copy_((g * xh).sum(0))
                 dbeta.copy_(g.sum(0))
+        if dx_copy is not None:                                    # bf16 copy of the updated rows + its column sums (a bias gradient)
+            assert dx_mode != DX_BF16
+            dx_copy.copy_(dx.to(torch.bfloat16))
+            if copy_colsum is not None:
+                cs = dx_copy.float().sum(0)
+                if accumulate:
+                    copy_colsum.add_(cs)
+                else:
+                    copy_colsum.copy_(cs)
 
     def l2norm_fwd(self, x, y, inv_norm, eps=1e-12):
         inv = 1.0 / x.norm(dim=-1).clamp_min(eps)
@@ -353,7 +363,10 @@ class RefOps:
         out.zero_()
         out[:, :R] = inp.T
 
-    def colsum_bf16(self, x, out):
+    def colsum_workspace(self, M, N):
+        return 4
+
+    def colsum_bf16(self, x, out, workspace=None):
         out.add_(x.float().sum(0))
 
     def im2row(self, img, out, p):

@@ -376,3 +376,29 @@ def test_cfg3_l14_336_clipself_full_batch():
     r, c = rel(got, ref), one_minus_cos(got, ref)
     _log(f"cfg3 L/14-336 teacher, 6 crops sampled from the 512-crop pass vs oracle: rel-L2 {r:.3e}, max 1-cos {c:.2e}")
     assert r < 1.9e-2 and c < 1e-4
+
+
+def test_cfg1_full_size_step_is_bit_reproducible():
+    """BASELINE configs[1] at full size, twice from the same state and batch: identical loss bits and identical gradient bits.  Round 2's
+    backward added RoIAlign contributions and bias column sums with float atomics (2.8e-4 relative run-to-run differences); the RoIAlign
+    backward is now a gather in box order, the bias sums come out of the LayerNorm backwards / row-block partials in a fixed order, and
+    the split-K weight gradients were already combined in a fixed order."""
+    from clipself_amd.training.clipself import CLIPSelf
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    student, teacher = _pair(cfg, 0)
+    batch = tuple(t.cuda() for t in synthetic_batch(64, 32, 224, 224, seed=4321))
+    args = _args()
+    runs = []
+    for _ in range(2):
+        student.visual.engine.zero_grad()
+        for p in student.parameters():
+            p.grad = None
+        losses, _, _ = CLIPSelf()(batch, student, teacher, None, "cuda", None, False, args)
+        total = sum(losses.values())
+        total.backward()
+        torch.cuda.synchronize()
+        runs.append((total.detach().clone(), student.visual.engine.grad.clone()))
+    assert torch.equal(runs[0][0], runs[1][0])
+    diff = int((runs[0][1] != runs[1][1]).sum())
+    _log(f"cfg1 full-size step twice: loss bits equal, {diff} of {runs[0][1].numel()} gradient elements differ, |grad| {float(runs[0][1].double().norm()):.4e}")
+    assert diff == 0 and float(runs[0][1].abs().sum()) > 0

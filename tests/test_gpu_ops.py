@@ -196,6 +196,25 @@ def test_layernorm_fwd_bwd(hip, ref, C, xdt):
     dxr = torch.empty(M, C)
     ref.layernorm_bwd(dy, x, gamma, mr, rr, dxr, 1)
     check(tag + ".dx_frozen", dxd, dxr, 1e-4)
+    # fp32 stream modes with the bf16 copy of the updated rows and its column sums (the bias gradient that used to need a cast + a
+    # column-sum pass): copy == bf16(dx) exactly, sums == fp32 column sums of the copy, accumulated onto what was there; with and
+    # without parameter gradients; bit-reproducible
+    for mode in (1, 2):
+        for with_params in (True, False):
+            base, cs0 = rnd((M, C), F32, seed=25), rnd((C,), F32, seed=26)
+            dxd, cpy, csd = base.cuda(), torch.full((M, C), float("nan"), dtype=BF, device="cuda"), cs0.cuda()
+            dgd, dbd = (torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")) if with_params else (None, None)
+            hip.layernorm_bwd(dyd, xd, gd, md, rd, dxd, mode, dgd, dbd, True, ws, dx_copy=cpy, copy_colsum=csd)
+            dxr, dgr, dbr, cpr, csr = base.clone(), torch.zeros(C), torch.zeros(C), torch.empty(M, C, dtype=BF), cs0.clone()
+            ref.layernorm_bwd(dy, x, gamma, mr, rr, dxr, mode, dgr, dbr, True, None, dx_copy=cpr, copy_colsum=csr)
+            check(f"{tag}.copy.dx{mode}", dxd, dxr, 1e-4)
+            assert torch.equal(cpy, dxd.to(BF)), f"{tag}: the copy is the rounded stream"
+            check(f"{tag}.copy.colsum{mode}", csd - cs0.cuda(), cpy.float().sum(0), 1e-4)
+            if with_params:
+                check(f"{tag}.copy.dgamma{mode}", dgd, dgr, 1e-4)
+            dx2, cp2, cs2 = base.cuda(), torch.empty_like(cpy), cs0.cuda()
+            hip.layernorm_bwd(dyd, xd, gd, md, rd, dx2, mode, None, None, True, ws, dx_copy=cp2, copy_colsum=cs2)
+            assert torch.equal(cs2, csd) and torch.equal(cp2, cpy)
 
 
 def test_layernorm_strided_rows(hip, ref):
@@ -493,6 +512,14 @@ def test_swiglu_cast_transpose_colsum_im2row(hip, ref):
     cd = base.cuda()
     hip.colsum_bf16(xs.cuda(), cd)
     check("colsum", cd, cr, 1e-4)
+    big = rnd((12608, 768), BF, seed=47).cuda()                       # the step's shape: row-block partials + a fixed-order combine, no atomics
+    outs = []
+    for _ in range(3):
+        o = torch.zeros(768, device="cuda")
+        hip.colsum_bf16(big, o, torch.empty(hip.colsum_workspace(12608, 768), dtype=torch.uint8, device="cuda"))
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    check("colsum.step_shape", outs[0], big.float().sum(0), 1e-4)
 
     for dt in (F32, BF):
         img = rnd((3, 3, 64, 64), F32, seed=46).to(dt)

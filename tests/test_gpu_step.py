@@ -642,6 +642,15 @@ def test_loss_curve_follows_the_reference_over_24_steps(golden_dir):
     _log(f"24-step loss curve: worst |loss - reference| = {worst:.3e}; last {losses[-1]:.4f}")
 
 
+def test_fp8_forward_loss_curve_follows_the_reference_over_24_steps(golden_dir):
+    """The same 24 steps with precision amp_fp8 (e4m3 forward operands through the block-scaled fp8 MFMA, cs_gemm_nt_f8): within 2e-2 of
+    the reference's fp32 curve at every step, same end point within 1e-2 (the bf16 path's bounds)."""
+    from clipself_amd.hip import HipOps
+    from test_loss_curve_cpu import run_curve
+    worst, losses = run_curve(golden_dir, HipOps(), "cuda", fp8=True, bound=2e-2, end_bound=1e-2)
+    _log(f"24-step loss curve, fp8 forward: worst |loss - reference| = {worst:.3e}; last {losses[-1]:.4f}")
+
+
 def test_training_main_reads_coco_files(tmp_path):
     """`--train-data <annotation json> --train-image-root <dir>` as in the reference's scripts: files decoded on the host (read-ahead threads),
     crops / det images produced by cs_crop_resize_u8, CLIPSelf steps through training.main."""

@@ -24,7 +24,7 @@ def _batch(cfg, rec, step):
     return synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"] + step % rec["n_batches"])
 
 
-def run_curve(golden_dir, ops, device):
+def run_curve(golden_dir, ops, device, fp8=False, bound=2e-2, end_bound=1e-2):
     from clipself_amd.open_clip.model import CustomCLIP
     from clipself_amd.training.clipself import CLIPSelf
     from clipself_amd.training.optim import FlatAdamW
@@ -38,6 +38,8 @@ def run_curve(golden_dir, ops, device):
     student.lock_image_tower(unlocked_groups=cfg.layers)
     student.train()
     teacher.eval()
+    if fp8:                                              # precision="amp_fp8": e4m3 operands in the student's forward linears only
+        student.visual.engine.enable_fp8_forward()
     opt = FlatAdamW(student, lr=rec["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=rec["wd"])
     sched = cosine_lr(opt, rec["lr"], rec["warmup"], rec["total"])
     args = SimpleNamespace(device=device, precision="amp", distributed=False, skip_scheduler=False, grad_clip_norm=None, multiscale=False,
@@ -48,8 +50,8 @@ def run_curve(golden_dir, ops, device):
         losses.append(float(out["loss"].detach()))
     ref = g["losses"]
     worst = float(np.abs(np.array(losses) - ref).max())
-    assert worst < 2e-2, (worst, losses, ref.tolist())
-    assert abs(losses[-1] - ref[-1]) < 1e-2 and losses[-1] < 0.25 * losses[0]          # the curve really descends, to the same place
+    assert worst < bound, (worst, losses, ref.tolist())
+    assert abs(losses[-1] - ref[-1]) < end_bound and losses[-1] < 0.25 * losses[0]     # the curve really descends, to the same place
     return worst, losses
 
 
@@ -68,3 +70,13 @@ def test_product_step_follows_the_reference_curve(golden_dir):
     torch.set_num_threads(4)
     worst, losses = run_curve(golden_dir, RefOps(), "cpu")
     print("worst |loss - reference| over 24 steps:", worst)
+
+
+def test_fp8_forward_follows_the_reference_curve(golden_dir):
+    """BASELINE configs[4] "fp8 MFMA weights": the same 24 optimiser steps with the student's forward linears on e4m3 operands (row-wise
+    scales; backward in bf16).  The curve recorded from the fp32 reference is followed within the bf16 path's own bounds (2e-2 at every step,
+    1e-2 at the end); measured 5.2e-3 against 1.1e-3 for bf16 operands (e4m3 carries 3 mantissa bits against bf16's 7)."""
+    from oracle.ops_ref import RefOps
+    torch.set_num_threads(4)
+    worst, losses = run_curve(golden_dir, RefOps(), "cpu", fp8=True, bound=2e-2, end_bound=1e-2)
+    print("fp8 forward: worst |loss - reference| over 24 steps:", worst, "last", losses[-1])
