@@ -39,11 +39,15 @@ __device__ __forceinline__ void store_x4(__bf16* p, const float (&v)[4]) { store
 __device__ __forceinline__ void store_x4(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 
 // ---------------------------------------------------------------------------------------------
-template <typename TX, int MAXG, typename TY = __bf16>
+// Q8 (bf16 output only): the row also leaves as e4m3 bytes with one fp32 scale -- the A operand of the fp8 GEMM that consumes this
+// LayerNorm (cs_gemm_nt_f8), quantised from the ROUNDED bf16 values exactly as cs_quant_rows_fp8 would from y (same amax / 448 scale,
+// same v_cvt_pk_fp8_f32), columns C .. Kp-1 zero: the quantiser's pass over y (read 2 B, write 1 B per element, one launch) disappears.
+template <typename TX, int MAXG, typename TY = __bf16, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, TY* __restrict__ y, long ldy,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                     int M, int C, float eps) {
+                                                     int M, int C, float eps, unsigned char* __restrict__ q8 = nullptr, long ldq = 0,
+                                                     float* __restrict__ q_scale = nullptr, int Kp = 0) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -87,6 +91,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, l
             ga[g] = *(const float4*)(gamma + c);
             be[g] = *(const float4*)(beta + c);
         }
+        float amax = 0.f;
 #pragma unroll
         for (int g = 0; g < MAXG; ++g) {
             const int c = (g * 64 + lane) * 4;
@@ -94,6 +99,31 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, l
                 float o[4] = {(v[g][0] - mean) * rstd * ga[g].x + be[g].x, (v[g][1] - mean) * rstd * ga[g].y + be[g].y,
                               (v[g][2] - mean) * rstd * ga[g].z + be[g].z, (v[g][3] - mean) * rstd * ga[g].w + be[g].w};
                 store_x4(yr + c, o);
+                if (Q8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[g][i] = (c + i < C) ? bf2f(f2bf(o[i])) : 0.f;       // what y holds: the quantiser's input
+                        amax = fmaxf(amax, fabsf(v[g][i]));
+                    }
+                }
+            } else if (Q8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[g][i] = 0.f;
+            }
+        }
+        if (Q8) {
+            amax = wave_max(amax);
+            const float inv = amax > 0.f ? 448.f / amax : 0.f;
+            if (lane == 0) q_scale[row] = amax > 0.f ? amax / 448.f : 1.f;
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g) {
+                const int c = (g * 64 + lane) * 4;
+                if (c < Kp) {                                                  // Kp % 128 == 0: whole 4-byte groups; columns >= C are zero bytes
+                    unsigned w = 0;
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[g][0] * inv, v[g][1] * inv, w, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[g][2] * inv, v[g][3] * inv, w, true);
+                    *(unsigned*)(q8 + (size_t)row * ldq + c) = w;
+                }
             }
         }
     }
@@ -345,19 +375,41 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 
 // C ABI ------------------------------------------------------------------------------------------
 // x_dtype: 0 = f32, 1 = bf16.  mean/rstd may be null (teacher, no backward).
-extern "C" int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, void* y, long ldy,
-                                float* mean, float* rstd, int M, int C, float eps, hipStream_t stream) {
+static int layernorm_fwd_impl(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, void* y, long ldy, float* mean,
+                              float* rstd, int M, int C, float eps, void* q8, long ldq, float* q_scale, hipStream_t stream) {
     // C % 4 != 0 is allowed for zero-padded rows: x, y, gamma, beta must then be readable/writable up to the next multiple of 4
     // (padding zero in x/gamma/beta -> the padding of y comes out zero).
     CS_CHECK_ARG(C <= MAXC && (C % 4 == 0 || (ldx >= ((C + 3) & ~3) && ldy >= ((C + 3) & ~3))), "cs_layernorm_fwd: C=%d unsupported (ld too small for a padded row, or > %d)", C, MAXC);
     CS_CHECK_ARG(M > 0, "cs_layernorm_fwd: empty input");
     dim3 grid((M + ROWS_PER_WG - 1) / ROWS_PER_WG), block(256);
+    if (q8 != nullptr) {
+        const int Kp = (C + 127) / 128 * 128;
+        CS_CHECK_ARG(y != nullptr && q_scale != nullptr && ldq >= Kp && ldq % 4 == 0 && ((uintptr_t)q8 % 4) == 0 && Kp <= 256 * 12,
+                     "cs_layernorm_fwd_q8: needs y, the scale vector and 4-byte aligned e4m3 rows of >= %d bytes", Kp);
+#define LNQ(TX, NG) hipLaunchKernelGGL((ln_fwd_kernel<TX, NG, __bf16, true>), grid, block, 0, stream, (const TX*)x, ldx, gamma, beta, (__bf16*)y, ldy, mean, rstd, M, C, eps, (unsigned char*)q8, ldq, q_scale, Kp)
+        if (x_dtype == 0) { if (Kp <= 1024) LNQ(float, 4); else if (Kp <= 2048) LNQ(float, 8); else LNQ(float, 12); }
+        else { if (Kp <= 1024) LNQ(__bf16, 4); else if (Kp <= 2048) LNQ(__bf16, 8); else LNQ(__bf16, 12); }
+#undef LNQ
+        CS_LAUNCH_CHECK();
+        return 0;
+    }
 #define LNF(TX, NG) hipLaunchKernelGGL((ln_fwd_kernel<TX, NG>), grid, block, 0, stream, (const TX*)x, ldx, gamma, beta, (__bf16*)y, ldy, mean, rstd, M, C, eps)
     if (x_dtype == 0) { if (C <= 1024) LNF(float, 4); else if (C <= 2048) LNF(float, 8); else LNF(float, 12); }
     else { if (C <= 1024) LNF(__bf16, 4); else if (C <= 2048) LNF(__bf16, 8); else LNF(__bf16, 12); }
 #undef LNF
     CS_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                                float* mean, float* rstd, int M, int C, float eps, hipStream_t stream) {
+    return layernorm_fwd_impl(x, x_dtype, ldx, gamma, beta, y, ldy, mean, rstd, M, C, eps, nullptr, 0, nullptr, stream);
+}
+// cs_layernorm_fwd that also emits the e4m3 copy of y for the fp8 GEMM: q8 [M, ldq >= C rounded up to 128] bytes (padding zero) and
+// q_scale [M] -- bit-identical to cs_quant_rows_fp8(y) (BASELINE configs[4], precision amp_fp8).
+extern "C" int cs_layernorm_fwd_q8(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                                   float* mean, float* rstd, void* q8, long ldq, float* q_scale, int M, int C, float eps, hipStream_t stream) {
+    CS_CHECK_ARG(q8 != nullptr, "cs_layernorm_fwd_q8: q8 is required (use cs_layernorm_fwd otherwise)");
+    return layernorm_fwd_impl(x, x_dtype, ldx, gamma, beta, y, ldy, mean, rstd, M, C, eps, q8, ldq, q_scale, stream);
 }
 
 // fp32 in -> fp32 out (y distinct from x): ln_pre of the OpenAI-CLIP ViT, whose output *is* the residual stream

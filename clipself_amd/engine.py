@@ -301,13 +301,25 @@ class EvaEngine:
         if on:
             self.sync_fp8()
 
-    def _linear(self, i, key, X, W, out, bias, extra=None, epi=EPI_BF16, rows=None):
-        """out = X . W^T + bias (+ extra): the bf16 MFMA GEMM, or -- fp8_forward -- the e4m3 GEMM on the quantised copy of X and the weight's
-        e4m3 shadow (`rows` = row range of the stacked weight that W is a slice of)."""
+    def _ln(self, x, gamma, beta, y, mean, rstd, eps):
+        """LayerNorm forward; under fp8_forward also the e4m3 copy of its output (cs_layernorm_fwd_q8) for the linear that consumes it.
+        Returns (q8, scale) or None."""
+        if not self.fp8_forward:
+            self.ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, eps)
+            return None
+        M = x.shape[0]
+        q = self.ops.empty((M, _round_up(y.shape[1], 128)), torch.uint8)
+        sc = self.ops.empty((M,), F32)
+        self.ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, q8=q, q_scale=sc)
+        return q, sc
+
+    def _linear(self, i, key, X, W, out, bias, extra=None, epi=EPI_BF16, rows=None, xq=None):
+        """out = X . W^T + bias (+ extra): the bf16 MFMA GEMM, or -- fp8_forward -- the e4m3 GEMM on the quantised copy of X (xq: already
+        produced by the LayerNorm that wrote X) and the weight's e4m3 shadow (`rows` = row range of the stacked weight that W is a slice of)."""
         if not self.fp8_forward:
             self.ops.gemm_nt(X, W, out, bias=bias, extra=extra, epi=epi)
             return
-        xq, sx = self._fp8_rows(X)
+        xq, sx = xq if xq is not None else self._fp8_rows(X)
         w8, sw = self.w8[(i, key)]
         if rows is not None:
             w8, sw = w8[rows[0]:rows[1]], sw[rows[0]:rows[1]]
@@ -425,7 +437,7 @@ class EvaEngine:
 
         ln1 = ops.empty((M, C), BF16)
         m1, r1 = st()
-        ops.layernorm_fwd(x, self.p[b + "norm1.weight"], self.p[b + "norm1.bias"], ln1, m1, r1, eps)
+        q1 = self._ln(x, self.p[b + "norm1.weight"], self.p[b + "norm1.bias"], ln1, m1, r1, eps)
         wqkv, bqkv = self._qkv_w(b)
         qkv = lse = None
         if with_attn and not keep and inplace and self.fold_sub_ln:
@@ -437,13 +449,13 @@ class EvaEngine:
             return self._block_post_folded(i, b, x, att, part, M)
         if with_attn:
             qkv = ops.empty((M, 3 * C), BF16)
-            self._linear(i, "qkv", ln1, wqkv, qkv, bqkv)
+            self._linear(i, "qkv", ln1, wqkv, qkv, bqkv, xq=q1)
             att = ops.empty((M, C), BF16)
             lse = ops.empty((B * H, N), F32) if keep else None
             ops.attn_fwd(qkv, cos, sin, att, lse, B, N, H, cfg.head_width ** -0.5)
         else:
             att = ops.empty((M, C), BF16)      # v only: every token "attends" to itself (proj_without_attn)
-            self._linear(i, "qkv", ln1, wqkv[2 * C:], att, bqkv[2 * C:], rows=(2 * C, 3 * C))
+            self._linear(i, "qkv", ln1, wqkv[2 * C:], att, bqkv[2 * C:], rows=(2 * C, 3 * C), xq=q1)
         x2 = self._block_post(i, b, x, att, M, st, save, inplace)
         if keep:
             save.update(x0=x, ln1=ln1, st1=(m1, r1), qkv=qkv, lse=lse, att=att, with_attn=with_attn)
@@ -457,28 +469,28 @@ class EvaEngine:
         keep = save is not None
         iln = ops.empty((M, C), BF16)
         m2, r2 = st()
-        ops.layernorm_fwd(att, self.p[b + "attn.inner_attn_ln.weight"], self.p[b + "attn.inner_attn_ln.bias"], iln, m2, r2, eps)
+        q2 = self._ln(att, self.p[b + "attn.inner_attn_ln.weight"], self.p[b + "attn.inner_attn_ln.bias"], iln, m2, r2, eps)
         x1 = x if inplace else ops.empty((M, C), F32)
-        self._linear(i, "proj", iln, self.w[b + "attn.proj.weight"], x1, self.p[b + "attn.proj.bias"], extra=x, epi=EPI_RESID_F32)
+        self._linear(i, "proj", iln, self.w[b + "attn.proj.weight"], x1, self.p[b + "attn.proj.bias"], extra=x, epi=EPI_RESID_F32, xq=q2)
 
         ln2 = ops.empty((M, C), BF16)
         m3, r3 = st()
-        ops.layernorm_fwd(x1, self.p[b + "norm2.weight"], self.p[b + "norm2.bias"], ln2, m3, r3, eps)
+        q3 = self._ln(x1, self.p[b + "norm2.weight"], self.p[b + "norm2.bias"], ln2, m3, r3, eps)
         w12, b12 = self._w12(b)
         hid = ops.empty((M, Hd), BF16)
         x12 = None
         if keep or self.fp8_forward:
             x12 = ops.empty((M, 2 * Hd), BF16)
-            self._linear(i, "w12", ln2, w12, x12, b12)
+            self._linear(i, "w12", ln2, w12, x12, b12, xq=q3)
             ops.swiglu_fwd(x12, hid)
         else:
             ops.gemm_nt(ln2, w12, hid, bias=b12, epi=EPI_SWIGLU_BF16, group=Hd)
         fln = (ops.zeros if padded else ops.empty)((M, Hd), BF16)     # padding columns feed the W3 GEMM: must be exact zeros
         m4, r4 = st()
-        ops.layernorm_fwd(hid[:, :Hl], self.p[b + "mlp.ffn_ln.weight"], self.p[b + "mlp.ffn_ln.bias"], fln[:, :Hl], m4, r4, eps)
+        q4 = self._ln(hid[:, :Hl], self.p[b + "mlp.ffn_ln.weight"], self.p[b + "mlp.ffn_ln.bias"], fln[:, :Hl], m4, r4, eps)
         x2 = x1 if inplace else ops.empty((M, C), F32)
         self._linear(i, "w3", fln, self.storage_of(self.shadow, b + "mlp.w3.weight"), x2, self.p[b + "mlp.w3.bias"], extra=x1,
-                     epi=EPI_RESID_F32)
+                     epi=EPI_RESID_F32, xq=q4)
         if keep:
             save.update(iln=iln, st2=(m2, r2), x1=x1, ln2=ln2, st3=(m3, r3), x12=x12, hid=hid, fln=fln, st4=(m4, r4))
         return x2

@@ -40,6 +40,7 @@ SIGNATURES = {
     "cs_ln_stats_finalize": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "cs_attn_fwd_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_layernorm_fwd": (_i, [_vp, _i, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _vp]),
+    "cs_layernorm_fwd_q8": (_i, [_vp, _i, _l, _vp, _vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _i, _i, _f, _vp]),
     "cs_layernorm_fwd_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _vp]),
     "cs_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "cs_layernorm_bwd": (_i, [_vp, _l, _vp, _i, _l, _vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _vp, _l, _vp, _i, _i, _vp]),
@@ -283,11 +284,22 @@ class HipOps:
         self._ok(self.lib.cs_attn_fwd_stats(_p(qkv), _p(cos), _p(sin), _p(out), _p(lse), _p(stats_part), B, Ntok, H, qkv.stride(0),
                                             out.stride(0), scale, self._stream()), "cs_attn_fwd_stats")
 
-    def layernorm_fwd(self, x, gamma, beta, y, mean=None, rstd=None, eps=1e-6):
+    def layernorm_fwd(self, x, gamma, beta, y, mean=None, rstd=None, eps=1e-6, q8=None, q_scale=None):
+        if q8 is not None:
+            return self.layernorm_fwd_q8(x, gamma, beta, y, q8, q_scale, mean, rstd, eps)
         self._chk(x, gamma, beta, y, mean, rstd)
         M, C = x.shape
         self._ok(self.lib.cs_layernorm_fwd(_p(x), _dt(x), x.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0) if y is not None else 0,
                                            _p(mean), _p(rstd), M, C, eps, self._stream()), "cs_layernorm_fwd")
+
+    def layernorm_fwd_q8(self, x, gamma, beta, y, q8, q_scale, mean=None, rstd=None, eps=1e-6):
+        """LayerNorm forward that also writes the e4m3 copy of y for the fp8 GEMM: q8 [M, Kp] (1-byte elements, Kp >= C rounded up to 128,
+        padding zero) + q_scale [M]; bit-identical to quant_rows_fp8(y)."""
+        self._chk(x, gamma, beta, y, mean, rstd, q8, q_scale)
+        M, C = x.shape
+        assert q8.element_size() == 1 and q8.stride(1) == 1 and q8.shape[1] >= (C + 127) // 128 * 128 and q_scale is not None and y is not None
+        self._ok(self.lib.cs_layernorm_fwd_q8(_p(x), _dt(x), x.stride(0), _p(gamma), _p(beta), _p(y), y.stride(0), _p(mean), _p(rstd),
+                                              _p(q8), q8.stride(0), _p(q_scale), M, C, eps, self._stream()), "cs_layernorm_fwd_q8")
 
     def layernorm_fwd_f32(self, x, gamma, beta, y, mean=None, rstd=None, eps=1e-5):
         """fp32 rows -> fp32 rows (ln_pre of the OpenAI-CLIP ViT: its output is the residual stream)."""

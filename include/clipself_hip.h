@@ -96,6 +96,10 @@ int cs_gemm_nt_ln_split(const void* A, const void* B, const float* bias, const f
  * x_dtype 0=f32 1=bf16; y bf16 (NULL = statistics only); mean/rstd [M] f32 (nullable when no backward is needed). */
 int cs_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, void* y, long ldy,
                      float* mean, float* rstd, int M, int C, float eps, cs_stream_t stream);
+/* the same, and the e4m3 copy of y for cs_gemm_nt_f8 (precision amp_fp8, src/training/region_clip.py:28-67 under BASELINE configs[4]):
+ * q8 [M, ldq >= C rounded up to 128] bytes with zero padding, q_scale [M] = row amax / 448 -- bit-identical to cs_quant_rows_fp8(y) */
+int cs_layernorm_fwd_q8(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, void* y, long ldy,
+                        float* mean, float* rstd, void* q8, long ldq, float* q_scale, int M, int C, float eps, cs_stream_t stream);
 /* part [P][M][2] f32 = per-slice (sum, sum of squares) over npp columns each (slices past C ignored) -> LayerNorm mean/rstd [M]
  * of a C-wide row; producers: cs_gemm_nt_ln epi 3 (npp 32) and cs_attn_fwd_stats (npp 64, P = heads). */
 int cs_ln_stats_finalize(const float* part, int P, int npp, int C, int M, float eps, float* mean, float* rstd, cs_stream_t stream);

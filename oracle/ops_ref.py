@@ -229,13 +229,17 @@ class RefOps:
             mean.copy_(mu[:, 0])
             rstd.copy_(r[:, 0])
 
-    def layernorm_fwd(self, x, gamma, beta, y, mean=None, rstd=None, eps=1e-6):
+    def layernorm_fwd(self, x, gamma, beta, y, mean=None, rstd=None, eps=1e-6, q8=None, q_scale=None):
         xf = x.float()
         mu = xf.mean(-1, keepdim=True)
         var = ((xf - mu) ** 2).mean(-1, keepdim=True)
         r = torch.rsqrt(var + eps)
         if y is not None:
             y.copy_(((xf - mu) * r * gamma + beta).to(torch.bfloat16))
+        if q8 is not None:                                         # the e4m3 copy of y: the row quantiser applied to what y holds
+            qv = q8.view(torch.uint8)
+            Kp = (y.shape[1] + 127) // 128 * 128
+            self.quant_rows_fp8(y, qv[:, :Kp], q_scale)
         if mean is not None:
             mean.copy_(mu[:, 0])
             rstd.copy_(r[:, 0])
@@ -273,6 +277,9 @@ class RefOps:
                     copy_colsum.add_(cs)
                 else:
                     copy_colsum.copy_(cs)
+
+    def layernorm_fwd_q8(self, x, gamma, beta, y, q8, q_scale, mean=None, rstd=None, eps=1e-6):
+        self.layernorm_fwd(x, gamma, beta, y, mean, rstd, eps, q8=q8, q_scale=q_scale)
 
     def l2norm_fwd(self, x, y, inv_norm, eps=1e-12):
         inv = 1.0 / x.norm(dim=-1).clamp_min(eps)

@@ -808,6 +808,32 @@ def test_fp8_quantisation_and_gemm(hip, ref, M, N, K, epi):
     assert float((got - exact).norm() / exact.norm()) < 6e-2
 
 
+@pytest.mark.parametrize("C,ld,xdt", [(768, 768, F32), (768, 768, BF), (2048, 2048, BF), (2730, 2752, BF), (64, 64, F32)])
+def test_layernorm_forward_with_fused_fp8_quantiser(hip, ref, C, ld, xdt):
+    """cs_layernorm_fwd_q8: y unchanged, and its e4m3 copy + row scales are bit-identical to cs_quant_rows_fp8 applied to y afterwards
+    (the pass the fused form removes); padded storage (L/14: 2730 normalised columns in 2752-wide rows) quantises its padding to zero."""
+    M = 300
+    x = torch.zeros(M, ld, dtype=xdt)
+    x[:, :C] = (rnd((M, C), F32, 2.0, seed=91) + 0.3).to(xdt)
+    x[7] = 0                                                      # an all-zero row: scale 1, codes 0
+    gamma, beta = torch.zeros(ld), torch.zeros(ld)
+    gamma[:C], beta[:C] = 1 + rnd((C,), F32, 0.2, seed=92), rnd((C,), F32, 0.2, seed=93)
+    beta[:C] *= 0 if C == 64 else 1
+    Kp = (ld + 127) // 128 * 128
+    xd, gd, bd = both([x, gamma, beta])
+    y0 = torch.zeros(M, ld, dtype=BF, device="cuda")
+    hip.layernorm_fwd(xd[:, :C], gd[:C], bd[:C], y0[:, :C])
+    y1 = torch.zeros(M, ld, dtype=BF, device="cuda")
+    q1, s1 = torch.full((M, Kp), 0x55, dtype=torch.uint8, device="cuda"), torch.empty(M, device="cuda")
+    hip.layernorm_fwd(xd[:, :C], gd[:C], bd[:C], y1[:, :C], q8=q1, q_scale=s1)
+    assert torch.equal(y0, y1)
+    q0, s0 = torch.full((M, Kp), 0xAA, dtype=torch.uint8, device="cuda"), torch.empty(M, device="cuda")
+    hip.quant_rows_fp8(y0, q0, s0)
+    assert torch.equal(s0, s1), "row scales"
+    assert torch.equal(q0, q1), f"{int((q0 != q1).sum())} e4m3 codes differ"
+    assert int(q1[:, C:].abs().max() if C < Kp else 0) == 0
+
+
 @pytest.mark.parametrize("shape,size", [((2, 3, 1024, 1024), 640), ((3, 3, 896, 896), 336), ((1, 3, 64, 64), 96), ((2, 3, 224, 224), 224)])
 def test_multiscale_bilinear_resize_matches_torch(hip, ref, shape, size):
     """--multiscale (src/training/clipself.py:17-27): F.interpolate(images, size, mode='bilinear') as cs_resize_bilinear_f32."""
