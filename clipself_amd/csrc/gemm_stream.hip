@@ -515,7 +515,6 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     unsigned avoff[4], bvoff[4];
     const char *a_src = nullptr, *b_src = nullptr;
     int a_tile = blockIdx.x, a_kt = 0, b_tile = blockIdx.x, b_kt = 0;
-    bool a_ok = true, b_ok = true;
     auto set_a = [&](int tile) {
         int tm, tn;
         tile_of_id(p, tile, ntiles, tm, tn);
@@ -549,20 +548,25 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             bvoff[i] = (unsigned)(rel * p.ldb * ES + chk * 16);
         }
     };
+    // Past the workgroup's last tile a cursor keeps cycling over that tile's K tiles: the DMA of the last two iterations then re-reads
+    // valid memory into slots nobody reads any more, and the K loop issues its eight pieces unconditionally -- no branch inside it, one
+    // basic block for the scheduler, fixed wait counts.
     auto adv_a = [&]() {
         if (++a_kt == ktiles) {
             a_kt = 0;
-            a_tile += G;
-            a_ok = a_tile < ntiles;
-            if (a_ok) set_a(a_tile);
+            if (a_tile + G < ntiles) {
+                a_tile += G;
+                set_a(a_tile);
+            }
         }
     };
     auto adv_b = [&]() {
         if (++b_kt == ktiles) {
             b_kt = 0;
-            b_tile += G;
-            b_ok = b_tile < ntiles;
-            if (b_ok) set_b(b_tile);
+            if (b_tile + G < ntiles) {
+                b_tile += G;
+                set_b(b_tile);
+            }
         }
     };
 #define ISSUE_A(X, SLOT)                                                                                                      \
@@ -580,12 +584,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
     for (int x = 0; x < 4; ++x) ISSUE_B(x, 0);
     adv_b();
-    bool pendA = a_ok;                       // is A(g+1) in flight at the top of iteration g
-    if (a_ok) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) ISSUE_A(x, 1);
-        adv_a();
-    }
+    for (int x = 0; x < 4; ++x) ISSUE_A(x, 1);
+    adv_a();
 
     int curA = 0, gpar = 0;                  // A slot of K tile g, parity of g
     bool after_epi = false;
@@ -623,11 +624,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             constexpr bool ZERO = decltype(zero_tag)::value;
             // In issue order this wave's pending ops are ... A(g), B(g), A(g+1) [, the previous epilogue's S stores]: everything older
             // than A(g+1) must have landed; vmcnt retires in order, so the stores (newest) may stay in flight as well.
-            if (after_epi) {
-                if (pendA) CS_VMCNT(4 + S); else CS_VMCNT(S);
-            } else {
-                if (pendA) CS_VMCNT(4); else CS_VMCNT(0);
-            }
+            if (after_epi) CS_VMCNT(4 + S);
+            else CS_VMCNT(4);
             after_epi = false;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (!CS_ABL(p, 2))                  // build with CS_EXTRA_FLAGS=-DCS_ABLATION_SWITCHES for tools/barrier_cost.py: the run-time test costs 0.35 % of the step
@@ -635,8 +633,6 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             const char* la = smem + curA * A_BYTES + a_base;
             const char* lb = b_ring + gpar * B_BYTES + b_base;
             const int slot_a2 = curA == 0 ? 2 : curA - 1, slot_b1 = gpar ^ 1;
-            const bool iss_b = b_ok, iss_a = a_ok;
-            bool a_iss = false;
             if constexpr (F8) {
                 typedef __attribute__((ext_vector_type(8))) int i32x8;
                 typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -656,8 +652,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                         b8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     }
                     if (s2 == 0) {
-                        if (iss_b) { ISSUE_B(0, slot_b1); ISSUE_B(1, slot_b1); ISSUE_B(2, slot_b1); ISSUE_B(3, slot_b1); }
-                    } else if (iss_a) {
+                        ISSUE_B(0, slot_b1); ISSUE_B(1, slot_b1); ISSUE_B(2, slot_b1); ISSUE_B(3, slot_b1);
+                    } else {
                         ISSUE_A(0, slot_a2); ISSUE_A(1, slot_a2); ISSUE_A(2, slot_a2); ISSUE_A(3, slot_a2);
                     }
 #pragma unroll
@@ -671,48 +667,58 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[j], a8[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
                             }
                         }
-                    if (s2 == 0) {
-                        if (iss_b) adv_b();
-                    } else {
-                        a_iss = iss_a;
-                        if (iss_a) adv_a();
-                    }
                 }
             } else {
+                // fragments of k-step ks+1 are requested before the MFMAs of k-step ks: the wave's own LDS latency hides behind its own
+                // MFMAs (two register sets), not only behind the other wave of the SIMD
+                bf16x8 a[2][FM], b[2][FN];
+                auto frags = [&](int ks, int buf) {
+                    const int off = ((par8 | (ks * 2 + hf)) ^ sw) << 4;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int off = ((par8 | (ks * 2 + hf)) ^ sw) << 4;
-                bf16x8 a[FM], b[FN];
+                    for (int i = 0; i < FM; ++i) a[buf][i] = *(const bf16x8*)(la + i * (16 * 256) + off);
 #pragma unroll
-                for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(la + i * (16 * 256) + off);
+                    for (int j = 0; j < FN; ++j) b[buf][j] = *(const bf16x8*)(lb + j * (16 * 256) + off);
+                };
+                frags(0, 0);
+#ifndef CS_NO_SGB
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#endif
 #pragma unroll
-                for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(lb + j * (16 * 256) + off);
-                if (ks < 2) {                  // two DMA pieces per k-step: B(g+1) first, then A(g+2)
-                    if (iss_b) {
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int cb = ks & 1;
+                    if (ks < 3) frags(ks + 1, cb ^ 1);
+                    if (ks < 2) {                  // two DMA pieces per k-step: B(g+1) first, then A(g+2)
                         if ((ks & 1) == 0) { ISSUE_B(0, slot_b1); ISSUE_B(1, slot_b1); } else { ISSUE_B(2, slot_b1); ISSUE_B(3, slot_b1); }
+                    } else {
+                        if ((ks & 1) == 0) { ISSUE_A(0, slot_a2); ISSUE_A(1, slot_a2); } else { ISSUE_A(2, slot_a2); ISSUE_A(3, slot_a2); }
                     }
-                } else if (iss_a) {
-                    if ((ks & 1) == 0) { ISSUE_A(0, slot_a2); ISSUE_A(1, slot_a2); } else { ISSUE_A(2, slot_a2); ISSUE_A(3, slot_a2); }
-                }
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
+                    for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        if (ZERO && ks == 0) {
-                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], z, 0, 0, 0);
+                        for (int j = 0; j < FN; ++j) {
+                            if (ZERO && ks == 0) {
+                                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][j], a[cb][i], z, 0, 0, 0);
+                            } else {
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cb][j], a[cb][i], acc[i][j], 0, 0, 0);
+                            }
+                        }
+                    // issue order of this k-step: one LDS read (of the next k-step's fragments) or one DMA piece behind every MFMA
+#ifndef CS_NO_SGB
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (m < 6) {
+                            if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         } else {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
                         }
                     }
-                if (ks == 1 && iss_b) adv_b();
-                if (ks == 3) {
-                    a_iss = iss_a;
-                    if (iss_a) adv_a();
+#endif
                 }
             }
-            }
-            pendA = a_iss;
+            adv_b();
+            adv_a();
             curA = curA == 2 ? 0 : curA + 1;
             gpar ^= 1;
         };
@@ -744,6 +750,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             else epi_bf16<epi_act(EPI), LN, CP, F8>(p, acc, lane_e, row0, colw, eo);
         }
     }
+    CS_VMCNT(0);      // the last two iterations' operand DMA (dead data, see adv_a) must not outlive the workgroup's LDS allocation
 #undef ISSUE_A
 #undef ISSUE_B
 }
