@@ -67,34 +67,6 @@ __device__ __forceinline__ void load_rope_tables(float* rt, const float* __restr
     }
 }
 
-// The same in two halves, so that the table reads are the OLDEST loads of the wave (vmcnt retires in order: waiting for them then does
-// not wait for the K / V / Q rows issued behind them) -- g * 32 <= 2 * NT entries per table.
-struct RopeRegs { float v[2][4]; };
-template <int NT>
-__device__ __forceinline__ void fetch_rope_tables(RopeRegs& t, const float* __restrict__ cos_t, const float* __restrict__ sin_t, int g, int tid) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int i = min(tid + it * NT, g * 32 - 1), r = i >> 5, d = i & 31;
-        t.v[it][0] = cos_t[(size_t)(r * g) * HD + d];
-        t.v[it][1] = sin_t[(size_t)(r * g) * HD + d];
-        t.v[it][2] = cos_t[(size_t)r * HD + 32 + d];
-        t.v[it][3] = sin_t[(size_t)r * HD + 32 + d];
-    }
-}
-template <int NT>
-__device__ __forceinline__ void commit_rope_tables(const RopeRegs& t, float* rt, int g, int tid) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int i = tid + it * NT;
-        if (i < g * 32) {
-            rt[i] = t.v[it][0];
-            rt[(g << 5) + i] = t.v[it][1];
-            rt[(2 * g << 5) + i] = t.v[it][2];
-            rt[(3 * g << 5) + i] = t.v[it][3];
-        }
-    }
-}
-
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int c2) {
     bf16x8 r;
 #pragma unroll
@@ -242,9 +214,11 @@ __device__ __forceinline__ void load_q_frags(const AttnArgs& p, const float* rt,
 }
 
 // one key chunk against one 32-query tile: S^T = K Q^T, online-softmax update of (m, l), O^T += V^T P^T
+// t0: first key tile of the chunk inside the LDS images (0 when the images hold only this chunk; the V^T key-block swizzle is a function of
+// the absolute block index, so a chunk of a whole-sequence image cannot be addressed through an offset pointer)
 template <int CH, bool TAIL>
 __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, const bf16x8 (&qf)[4], int key0, int Ntok, float sl2,
-                                             int lane, bool first, float& m, float& l, f32x16 (&o)[2]) {
+                                             int lane, bool first, float& m, float& l, f32x16 (&o)[2], int t0 = 0) {
     const int hf = lane >> 5, l31 = lane & 31;
     // fragment addressing (row = t*32 + l31): LDS row (row>>1), slot ((row&1)*8 | chunk) ^ ((row>>1)&15)
     const int k_base = (l31 >> 1) << 8, par8 = (l31 & 1) << 3, sw = l31 >> 1;
@@ -258,7 +232,7 @@ __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, c
         s[t] = zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kfrag = *(const bf16x8*)(Kl + t * (16 * 256) + k_base + (((par8 | (ks * 2 + hf)) ^ sw) << 4));
+            const bf16x8 kfrag = *(const bf16x8*)(Kl + (t0 + t) * (16 * 256) + k_base + (((par8 | (ks * 2 + hf)) ^ sw) << 4));
             s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], s[t], 0, 0, 0);
         }
     }
@@ -321,7 +295,7 @@ __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, c
         for (int c2 = 0; c2 < 2; ++c2) {
             if (TAIL && t == CH - 1 && c2 == 1 && rem_last <= 16) continue;     // all 16 keys of this step are padding (p = 0)
             const bf16x8 pb = pack8_swapped(s[t], c2);
-            const int kb = t * 4 + c2 * 2 + hf;              // key block (8 keys) this half supplies
+            const int kb = (t0 + t) * 4 + c2 * 2 + hf;       // key block (8 keys) this half supplies
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const int d = dt * 32 + l31;
@@ -367,12 +341,11 @@ __device__ __forceinline__ void store_o(const AttnArgs& p, size_t rowbase, int q
     }
 }
 
-// NW waves per workgroup, QTW 32-query tiles per wave (tile = wave + j*NW).  QTW > 1 requires the whole sequence in one key
-// chunk (Ntok <= CH*32: no state is carried between chunks); it lets 4-wave workgroups stage K/V once for up to 256
-// queries while two workgroups share a CU, so one workgroup's K/V staging overlaps the other's MFMA/softmax phase.
-template <int CH, int NW, int QTW, bool TAIL = false>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
-    constexpr int CHK = CH * 32, NT = NW * 64;
+// Sequences longer than one LDS image (Ntok > 224): eight waves, one 32-query tile per wave, 256 queries per workgroup; the keys are staged
+// chunk by chunk (CH*32 keys) and consumed with the online softmax.
+template <int CH>
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int CHK = CH * 32, NT = 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kl = smem;
     __bf16* Vt = (__bf16*)(smem + CHK * 128);
@@ -383,104 +356,117 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
     const int C = p.H * HD;
     const size_t rowbase = (size_t)b * p.Ntok;
     const float sl2 = p.scale * LOG2E;
-    const int q_wg = blockIdx.x * (NW * QTW * 32);
+    const int q0 = blockIdx.x * 256 + wave * 32, q = q0 + l31, qc = min(q, p.Ntok - 1);
+    const bool active = q0 < p.Ntok;
+    load_rope_tables<NT>(rt, p.cos_t, p.sin_t, p.grid, tid);
+    __syncthreads();
+    bf16x8 qf[4];
+    load_q_frags(p, rt, rowbase, qc, h, hf, qf);
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[2] = {zero16(), zero16()};
+    for (int key0 = 0; key0 < p.Ntok; key0 += CHK) {
+        __syncthreads();
+        stage_k<CHK, NT>(p.qkv, rowbase, p.ldqkv, C + h * HD, key0, p.Ntok, rt, p.grid, p.inv_grid, Kl, tid);
+        stage_vt<CHK, NT>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0, p.Ntok, Vt, tid);
+        __syncthreads();
+        if (active) attend_chunk<CH, false>(Kl, Vt, qf, key0, p.Ntok, sl2, lane, key0 == 0, m, l, o);
+    }
+    if (active && q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
+}
 
-    if (QTW == 1) {
-        const int q0 = q_wg + wave * 32, q = q0 + l31, qc = min(q, p.Ntok - 1);
-        const bool active = q0 < p.Ntok;
-        load_rope_tables<NT>(rt, p.cos_t, p.sin_t, p.grid, tid);
-        __syncthreads();
-        bf16x8 qf[4];
-        load_q_frags(p, rt, rowbase, qc, h, hf, qf);
-        float m = -INFINITY, l = 0.f;
-        f32x16 o[2] = {zero16(), zero16()};
-        for (int key0 = 0; key0 < p.Ntok; key0 += CHK) {
-            __syncthreads();
-            stage_k<CHK, NT>(p.qkv, rowbase, p.ldqkv, C + h * HD, key0, p.Ntok, rt, p.grid, p.inv_grid, Kl, tid);
-            stage_vt<CHK, NT>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0, p.Ntok, Vt, tid);
-            __syncthreads();
-            if (active) attend_chunk<CH, false>(Kl, Vt, qf, key0, p.Ntok, sl2, lane, key0 == 0, m, l, o);
-        }
-        if (active && q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
-    } else {
-        // The kernel is latency-bound (profile: 64 % of wave cycles parked at s_waitcnt/s_barrier), so every global load
-        // of the workgroup -- K rows, the V block, and the Q fragments of BOTH query tiles of this wave -- is issued before
-        // the first dependent instruction; V's flight time then hides behind K's RoPE work, Q's behind the whole staging.
-        // 7 query tiles over 4 waves leave one wave (one SIMD) with a single tile: which one rotates with the unit index, so that over
-        // the units a CU processes every SIMD carries 7/4 tiles per unit instead of SIMDs 0..2 carrying 2
-        const int wrot = (wave + bh) & (NW - 1);
-        constexpr int KI = (CHK * 8 + NT - 1) / NT;
-        U128 kr[KI], vin[8], qraw[QTW][4];
-        RopeRegs tabs;
-        fetch_rope_tables<NT>(tabs, p.cos_t, p.sin_t, p.grid, tid);
-        __builtin_amdgcn_sched_barrier(0);                     // all eight table loads ahead of the K / V / Q rows
-        const __bf16* kbase = p.qkv + C + h * HD;
-        const __bf16* vbase = p.qkv + 2 * C + h * HD;
-        // Branch-free: rows past the sequence re-read its last row (finite; their scores are masked to -inf, so p = 0 exactly and neither
-        // K nor V of a padding key reaches the result).  Predicated loads made hipcc wrap every V load in its own exec-masked block with
-        // an `s_waitcnt vmcnt(0)` behind it -- eight serial HBM round trips per workgroup.
-        const int last = p.Ntok - 1;
+// Eight waves, ONE 32-query tile per wave, whole sequence (<= 224 keys) staged once; the keys are consumed in chunks of three tiles with
+// the online softmax, so a wave needs 48 score registers instead of 112 and fits 128 VGPRs: two workgroups per CU are 16 waves = FOUR per
+// SIMD (the 4-wave / 2-tile form above: two per SIMD at 206 VGPRs).  The forward is bound by dependent latencies (S = K.Q^T -> max ->
+// exp -> P.V per tile; global loads -> LDS images -> barrier per unit), not by MFMA or VALU throughput: twice the waves per SIMD is
+// what hides them.  Same arithmetic per element as the single-chunk form except that the running maximum of the first chunks rescales
+// the output accumulators (exact when the maximum does not change, one fp32 rounding of alpha * o otherwise).
+template <bool TAIL>
+__global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
+    constexpr int CH = 7, CHK = CH * 32, NT = 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kl = smem;
+    __bf16* Vt = (__bf16*)(smem + CHK * 128);
+    float* rt = (float*)(smem + CHK * 128 + HD * VT_LD * 2);      // compact RoPE tables [4][g][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int C = p.H * HD;
+    const size_t rowbase = (size_t)b * p.Ntok;
+    const float sl2 = p.scale * LOG2E;
+    const int last = p.Ntok - 1;
+    // every global load of the workgroup ahead of the first dependent instruction: tables (oldest: vmcnt retires in order), K, V, Q
+    float tab[4];
+    {
+        const int i = min(tid, p.grid * 32 - 1), r = i >> 5, d = i & 31;       // g * 32 <= 448 entries per table
+        tab[0] = p.cos_t[(size_t)(r * p.grid) * HD + d];
+        tab[1] = p.sin_t[(size_t)(r * p.grid) * HD + d];
+        tab[2] = p.cos_t[(size_t)r * HD + 32 + d];
+        tab[3] = p.sin_t[(size_t)r * HD + 32 + d];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int KI = (CHK * 8 + NT - 1) / NT;
+    U128 kr[KI], vin[8], qraw[4];
+    const __bf16* kbase = p.qkv + C + h * HD;
+    const __bf16* vbase = p.qkv + 2 * C + h * HD;
 #pragma unroll
-        for (int it = 0; it < KI; ++it) {
-            const int idx = min(tid + it * NT, CHK * 8 - 1), tok = min(idx >> 3, last);
-            kr[it].u = *(const uint4*)(kbase + (rowbase + tok) * p.ldqkv + (idx & 7) * 8);
-        }
-        const int vkb = tid >> 3, vc = tid & 7;                // one (key block, dim chunk) item per thread (CHK <= NT)
+    for (int it = 0; it < KI; ++it) {      // branch-free: rows past the sequence re-read its last row (masked to p = 0 exactly)
+        const int idx = min(tid + it * NT, CHK * 8 - 1), tok = min(idx >> 3, last);
+        kr[it].u = *(const uint4*)(kbase + (rowbase + tok) * p.ldqkv + (idx & 7) * 8);
+    }
+    const int vkb = min(tid, CHK - 1) >> 3, vc = tid & 7;      // one (key block, dim chunk) item per thread, threads >= 224 repeat the last
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int tok = min(vkb * 8 + i, last);
-            vin[i].u = *(const uint4*)(vbase + (rowbase + tok) * p.ldqkv + vc * 8);
-        }
-        int qcs[QTW];
+    for (int i = 0; i < 8; ++i) {
+        const int tok = min(vkb * 8 + i, last);
+        vin[i].u = *(const uint4*)(vbase + (rowbase + tok) * p.ldqkv + vc * 8);
+    }
+    const int q0 = wave * 32, q = q0 + l31, qc = min(q, last);
 #pragma unroll
-        for (int j = 0; j < QTW; ++j) {
-            qcs[j] = min(q_wg + (wrot + j * NW) * 32 + l31, p.Ntok - 1);
+    for (int ks = 0; ks < 4; ++ks) qraw[ks].u = *(const uint4*)(p.qkv + (rowbase + qc) * p.ldqkv + h * HD + ks * 16 + hf * 8);
+    if (tid < p.grid * 32) {
+        rt[tid] = tab[0];
+        rt[(p.grid << 5) + tid] = tab[1];
+        rt[(2 * p.grid << 5) + tid] = tab[2];
+        rt[(3 * p.grid << 5) + tid] = tab[3];
+    }
+    __syncthreads();
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                qraw[j][ks].u = *(const uint4*)(p.qkv + (rowbase + qcs[j]) * p.ldqkv + h * HD + ks * 16 + hf * 8);
-        }
-        commit_rope_tables<NT>(tabs, rt, p.grid, tid);
-        __syncthreads();
-        // K: rotate + swizzled LDS image
-#pragma unroll
-        for (int it = 0; it < KI; ++it) {
-            const int idx = tid + it * NT, r = idx >> 3, c = idx & 7;
-            if (idx < CHK * 8) {
-                if (r > 0 && r < p.Ntok && !ATT_ABL(p, 2)) rope8_lds(kr[it], rt, p.grid, p.inv_grid, r, c);
-                *(uint4*)(Kl + k_off(r, c)) = kr[it].u;
-            }
-        }
-        // V: 8x8 in-register transpose -> V^T image
-        if (tid < CHK) {
-            const int pos = (vkb ^ vc) * 8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                U128 o;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o.e[i] = vin[i].e[j];
-                *(uint4*)(Vt + (vc * 8 + j) * VT_LD + pos) = o.u;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < QTW; ++j) {
-            const int q0 = q_wg + (wrot + j * NW) * 32;
-            if (q0 < p.Ntok) {
-                const int q = q0 + l31, qc = qcs[j];
-                bf16x8 qf[4];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    if (qc > 0 && !ATT_ABL(p, 2)) rope8_lds(qraw[j][ks], rt, p.grid, p.inv_grid, qc, ks * 2 + hf);
-                    qf[ks] = qraw[j][ks].h;
-                }
-                float m = -INFINITY, l = 0.f;
-                f32x16 o[2] = {zero16(), zero16()};
-                if (!ATT_ABL(p, 1)) attend_chunk<CH, TAIL>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o);
-                else { l = 1.f; m = 0.f; o[0][0] = bf2f(qf[0][0]); }
-                if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
-            }
+    for (int it = 0; it < KI; ++it) {      // K: rotate + swizzled LDS image
+        const int idx = tid + it * NT, r = idx >> 3, c = idx & 7;
+        if (idx < CHK * 8) {
+            if (r > 0 && r < p.Ntok && !ATT_ABL(p, 2)) rope8_lds(kr[it], rt, p.grid, p.inv_grid, r, c);
+            *(uint4*)(Kl + k_off(r, c)) = kr[it].u;
         }
     }
+    if (tid < CHK) {                       // V: 8x8 in-register transpose -> V^T image
+        const int pos = (vkb ^ vc) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            U128 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.e[i] = vin[i].e[j];
+            *(uint4*)(Vt + (vc * 8 + j) * VT_LD + pos) = o.u;
+        }
+    }
+    __syncthreads();
+    if (q0 >= p.Ntok) return;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        if (qc > 0 && !ATT_ABL(p, 2)) rope8_lds(qraw[ks], rt, p.grid, p.inv_grid, qc, ks * 2 + hf);
+        qf[ks] = qraw[ks].h;
+    }
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[2] = {zero16(), zero16()};
+    if (ATT_ABL(p, 1)) { l = 1.f; m = 0.f; o[0][0] = bf2f(qf[0][0]); }
+    else if (TAIL) {                       // 192 < Ntok <= 224 (the 14x14 + CLS grid): two full chunks and the ragged last tile
+        attend_chunk<3, false>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o, 0);
+        attend_chunk<3, false>(Kl, Vt, qf, 96, p.Ntok, sl2, lane, false, m, l, o, 3);
+        attend_chunk<1, true>(Kl, Vt, qf, 192, p.Ntok, sl2, lane, false, m, l, o, 6);
+    } else {
+        attend_chunk<3, false>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o, 0);
+        if (p.Ntok > 96) attend_chunk<3, false>(Kl, Vt, qf, 96, p.Ntok, sl2, lane, false, m, l, o, 3);
+        if (p.Ntok > 192) attend_chunk<1, false>(Kl, Vt, qf, 192, p.Ntok, sl2, lane, false, m, l, o, 6);
+    }
+    if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -813,21 +799,21 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
     const size_t lds = (size_t)CH * 32 * 128 + (size_t)HD * VT_LD * 2 + (size_t)4 * g * 32 * sizeof(float) + lds_pad;
     CS_CHECK_ARG(lds <= 160 * 1024, "cs_attn_fwd: token grid %d too large for the LDS RoPE tables", g);
     if (Ntok <= CH * 32) {
-        // whole sequence in one key chunk: 4-wave workgroups, 2 query tiles per wave, 2 workgroups per CU; when only the last key tile is
+        // whole sequence in one LDS image: eight waves, one query tile each, two workgroups (16 waves) per CU; when only the last key tile is
         // ragged (Ntok > 32 (CH - 1): the 14x14 grid), the variant whose ragged-tile code exists once
-        static bool once = (set_lds(attn_fwd_kernel<CH, 4, 2, false>, 160 * 1024), set_lds(attn_fwd_kernel<CH, 4, 2, true>, 160 * 1024), true);
+        static bool once = (set_lds(attn_fwd8_kernel<false>, 160 * 1024), set_lds(attn_fwd8_kernel<true>, 160 * 1024), true);
         (void)once;
         if (getenv("CS_ATTN_DEBUG")) {
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_fwd_kernel<CH, 4, 2, true>, 256, lds);
-            fprintf(stderr, "[cs_attn] fwd<7,4,2>: %d resident workgroups per CU (lds %zu)\n", nb, lds);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_fwd8_kernel<true>, 512, lds);
+            fprintf(stderr, "[cs_attn] fwd8: %d resident workgroups per CU (lds %zu)\n", nb, lds);
         }
-        if (Ntok > (CH - 1) * 32) hipLaunchKernelGGL((attn_fwd_kernel<CH, 4, 2, true>), dim3((Ntok + 255) / 256, B * H), dim3(256), lds, stream, a);
-        else hipLaunchKernelGGL((attn_fwd_kernel<CH, 4, 2, false>), dim3((Ntok + 255) / 256, B * H), dim3(256), lds, stream, a);
+        if (Ntok > (CH - 1) * 32) hipLaunchKernelGGL((attn_fwd8_kernel<true>), dim3(1, B * H), dim3(512), lds, stream, a);
+        else hipLaunchKernelGGL((attn_fwd8_kernel<false>), dim3(1, B * H), dim3(512), lds, stream, a);
     } else {
-        static bool once = (set_lds(attn_fwd_kernel<CH, 8, 1>, 160 * 1024), true);
+        static bool once = (set_lds(attn_fwd_kernel<CH>, 160 * 1024), true);
         (void)once;
-        hipLaunchKernelGGL((attn_fwd_kernel<CH, 8, 1>), dim3((Ntok + 255) / 256, B * H), dim3(512), lds, stream, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<CH>), dim3((Ntok + 255) / 256, B * H), dim3(512), lds, stream, a);
     }
     CS_LAUNCH_CHECK();
     return 0;

@@ -53,8 +53,9 @@ from .roi_align_ref import roi_align_1x1
 # ----------------------------------------------------------------------------
 class _Round:
     """emulate_bf16 = False | True | "kernel".  True rounds at the generic points listed in the module docstring; "kernel" additionally
-    moves the attention's probability rounding to where the HIP attention kernels round: the UN-normalised exp(s - max) is what goes to
-    the P.V MFMA in bf16 and the fp32 row sum divides afterwards (csrc/attention.hip), instead of rounding softmax(s)."""
+    moves the attention's probability rounding to where the HIP attention kernels round: the UN-normalised exp(s - running max) of the
+    online softmax is what goes to the P.V MFMA in bf16, chunk by chunk, and the fp32 row sum divides afterwards (_online_softmax_pv,
+    csrc/attention.hip), instead of rounding softmax(s)."""
 
     def __init__(self, on):
         self.on = bool(on)
@@ -133,6 +134,26 @@ def stem(sd, cfg, images, rq, prefix="visual."):
     return x + pos_embed_for(sd, cfg, g, prefix), g
 
 
+def _online_softmax_pv(att, v, rq):
+    """softmax(att) @ v as attention.hip computes it: keys in chunks of 96 (<= 224 keys: attn_fwd8_kernel) or 224 (longer sequences),
+    un-normalised probabilities relative to the RUNNING maximum rounded to bf16 for the P.V product, fp32 row sums of the unrounded ones,
+    output accumulators rescaled when the maximum moves.  att [..., Nq, Nk], v [..., Nk, d] -> [..., Nq, d]."""
+    N = att.shape[-1]
+    step = 96 if N <= 224 else 224
+    m = att.new_full(att.shape[:-1] + (1,), float("-inf"))
+    lsum = torch.zeros_like(m)
+    acc = att.new_zeros(att.shape[:-1] + (v.shape[-1],))
+    for lo in range(0, N, step):
+        sc = att[..., lo:lo + step]
+        m_new = torch.maximum(m, sc.amax(dim=-1, keepdim=True))
+        alpha = torch.exp(m - m_new)
+        e = torch.exp(sc - m_new)
+        lsum = lsum * alpha + e.sum(dim=-1, keepdim=True)
+        acc = acc * alpha + rq(e) @ v[..., lo:lo + step, :]
+        m = m_new
+    return acc / lsum
+
+
 def attention(sd, cfg, x, blk, cos, sin, rq):
     """x = norm1 output [B,N,C] (eva_vit_model.py:174-247, math branch)."""
     B, N, C = x.shape
@@ -146,8 +167,7 @@ def attention(sd, cfg, x, blk, cos, sin, rq):
     k = rq(apply_rope(k, cos, sin))
     att = (q * (d ** -0.5)) @ k.transpose(-2, -1)
     if rq.kernel_points:
-        e = torch.exp(att - att.amax(dim=-1, keepdim=True))
-        o = ((rq(e) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, N, C)
+        o = _online_softmax_pv(att, v, rq).transpose(1, 2).reshape(B, N, C)
     else:
         att = att.softmax(dim=-1)
         o = (rq(att) @ v).transpose(1, 2).reshape(B, N, C)
@@ -244,8 +264,7 @@ def frozen_block(sd, cfg, x, i, cos, sin, folded=True, fold_norm1=True, prefix="
     q, k, v = (rq(t).reshape(B, N, H, d).permute(0, 2, 1, 3) for t in (qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]))
     q, k = rq(apply_rope(q, cos, sin)), rq(apply_rope(k, cos, sin))
     att = (q * (d ** -0.5)) @ k.transpose(-2, -1)
-    e = torch.exp(att - att.amax(dim=-1, keepdim=True))          # un-normalised probabilities go to the P.V MFMA in bf16
-    o = rq(((rq(e) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, N, C))
+    o = rq(_online_softmax_pv(att, v, rq).transpose(1, 2).reshape(B, N, C))     # un-normalised probabilities go to the P.V MFMA in bf16
     if folded:
         x = x + _folded_linear(o, o, sd[blk + "attn.inner_attn_ln.weight"], sd[blk + "attn.inner_attn_ln.bias"],
                                sd[blk + "attn.proj.weight"], sd[blk + "attn.proj.bias"], eps, rq)

@@ -31,6 +31,7 @@ def timeit(fn, n=10, warm=2):
 
 def main():
     ops = HipOps()
+    ops.gemm_flags = int(os.environ.get("GEMM_AB_FLAGS", "0"), 0)      # e.g. 0x1000: slab form of the bf16 / SwiGLU epilogues
     crops = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     tag = sys.argv[3] if len(sys.argv) > 3 else os.environ.get("CLIPSELF_HIP_LIB", "default")
