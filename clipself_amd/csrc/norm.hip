@@ -135,32 +135,43 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, l
 // variance = sum of the slices' own centred second moments + the spread of the slice means about the row mean (Chan et al.).
 __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, int P, int npp, int C, int M, float eps,
                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    // 64 rows per workgroup; the four waves split the slices, one coalesced 512-byte read per (slice, wave)
-    __shared__ float red[3][64][3];
-    const int r = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int row = min(blockIdx.x * 64 + r, M - 1);
+    // one row per thread, slices in order, eight 8-byte loads in flight per thread (a wave reads 512 contiguous bytes per slice): the kernel
+    // is a pure stream of P * M * 8 bytes (up to 206 MB for the SwiGLU hidden's 64 slices), so what matters is bytes in flight
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    const float2* src = (const float2*)part + row;
     float s = 0.f, q = 0.f, b = 0.f;                  // sum, within-slice centred squares, sum of s_p^2 / n_p
-    for (int p = w; p < P; p += 4) {
+    int p = 0;
+    for (; p + 8 <= P; p += 8) {
+        float2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(p + j) * M];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = min(npp, C - (p + j) * npp);
+            if (n > 0) {
+                const float t = v[j].x * v[j].x / (float)n;
+                s += v[j].x;
+                q += fmaxf(v[j].y - t, 0.f);
+                b += t;
+            }
+        }
+    }
+    for (; p < P; ++p) {
         const int n = min(npp, C - p * npp);
         if (n <= 0) break;
-        const float2 sq = *(const float2*)(part + ((size_t)p * M + row) * 2);
+        const float2 sq = src[(size_t)p * M];
         const float t = sq.x * sq.x / (float)n;
         s += sq.x;
         q += fmaxf(sq.y - t, 0.f);
         b += t;
     }
-    if (w > 0) { red[w - 1][r][0] = s; red[w - 1][r][1] = q; red[w - 1][r][2] = b; }
-    __syncthreads();
-    if (w == 0 && blockIdx.x * 64 + r < M) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { s += red[i][r][0]; q += red[i][r][1]; b += red[i][r][2]; }
-        const float mean = s / (float)C;
-        // pooled variance = within-slice part + between-slice part; only the latter (slice means against the row mean) can
-        // cancel, and it is a small share of the total unless the row mean dwarfs the row's spread
-        const float m2 = q + fmaxf(b - s * mean, 0.f);
-        mean_out[row] = mean;
-        rstd_out[row] = rsqrtf(m2 / (float)C + eps);
-    }
+    const float mean = s / (float)C;
+    // pooled variance = within-slice part + between-slice part; only the latter (slice means against the row mean) can
+    // cancel, and it is a small share of the total unless the row mean dwarfs the row's spread
+    const float m2 = q + fmaxf(b - s * mean, 0.f);
+    mean_out[row] = mean;
+    rstd_out[row] = rsqrtf(m2 / (float)C + eps);
 }
 
 // dx modes
@@ -431,7 +442,7 @@ extern "C" int cs_layernorm_fwd_f32(const float* x, long ldx, const float* gamma
 extern "C" int cs_ln_stats_finalize(const float* part, int P, int npp, int C, int M, float eps, float* mean, float* rstd, hipStream_t stream) {
     CS_CHECK_ARG(part && mean && rstd && P > 0 && npp > 0 && C > 0 && M > 0 && (long)P * npp >= C,
                  "cs_ln_stats_finalize: bad arguments P=%d npp=%d C=%d M=%d", P, npp, C, M);
-    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 63) / 64), dim3(256), 0, stream, part, P, npp, C, M, eps, mean, rstd);
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, part, P, npp, C, M, eps, mean, rstd);
     CS_LAUNCH_CHECK();
     return 0;
 }
