@@ -572,24 +572,42 @@ class EvaEngine:
         ops.ln_stats_finalize(part_x, 64, C, mean2, rstd2, eps)
         return xb2, (mean2, rstd2)
 
-    def _block_fwd_cls(self, i, x, B, N, cos, sin):
+    @staticmethod
+    def _join_planes(hi, lo):
+        """fp32 values of a split stream (cs_gemm_nt_ln_split: hi | lo = the halves of bits(x) + 0x8000); used on the B CLS rows only."""
+        y = (hi.contiguous().view(torch.int16).to(torch.int32) << 16) | (lo.to(torch.int32) & 0xFFFF)
+        return (y - 0x8000).view(torch.float32)
+
+    def _block_fwd_cls(self, i, x, B, N, cos, sin, xb=None, st=None, lo=None):
         """Last teacher block restricted to what encode_image() consumes: the CLS row.  x fp32 [B*N, C] -> fp32 [B, C].
         forward_features() returns x[:, 0] after the final norm (eva_vit_model.py:505-519), so only the CLS *query* of the
-        last block is live; keys and values still come from every token.  Row-for-row the same arithmetic as _block_fwd."""
+        last block is live; keys and values still come from every token.  Row-for-row the same arithmetic as _block_fwd.
+        With xb / st (/ lo) -- the bf16 operand view, norm1 statistics (and low plane) the previous folded block left -- norm1 is folded into
+        the K|V GEMM like in every other block of the tower (no LayerNorm pass over the 403 456-row stream, the stream never returns to
+        fp32) and only the B CLS rows are rebuilt in fp32 for the query, the residual adds and the MLP."""
         ops, cfg = self.ops, self.cfg
         C, H, eps = cfg.width, cfg.heads, cfg.ln_eps
         b = f"{self.prefix}blocks.{i}."
         M = B * N
-        ln1 = ops.empty((M, C), BF16)
-        ops.layernorm_fwd(x, self.p[b + "norm1.weight"], self.p[b + "norm1.bias"], ln1, None, None, eps)
         wqkv, bqkv = self._qkv_w(b)
         kv = ops.empty((M, 2 * C), BF16)
-        ops.gemm_nt(ln1, wqkv[C:], kv, bias=bqkv[C:], epi=EPI_BF16)
         q = ops.empty((B, C), BF16)
-        ops.gemm_nt(ln1.view(B, N, C)[:, 0, :], wqkv[:C], q, bias=bqkv[:C], epi=EPI_BF16)
+        if xb is not None:
+            Wq, cq, dq = self.fold[i]["qkv"]
+            ops.gemm_nt_ln(xb, Wq[C:], kv, bias=dq[C:], ln_mean=st[0], ln_rstd=st[1], ln_colsum=cq[C:], epi=EPI_BF16)
+            xc = (self._join_planes(xb.view(B, N, C)[:, 0, :], lo.view(B, N, C)[:, 0, :]) if lo is not None
+                  else x.view(B, N, C)[:, 0, :].contiguous())
+            ln1c = ops.empty((B, C), BF16)
+            ops.layernorm_fwd(xc, self.p[b + "norm1.weight"], self.p[b + "norm1.bias"], ln1c, None, None, eps)
+            ops.gemm_nt(ln1c, wqkv[:C], q, bias=bqkv[:C], epi=EPI_BF16)
+        else:
+            ln1 = ops.empty((M, C), BF16)
+            ops.layernorm_fwd(x, self.p[b + "norm1.weight"], self.p[b + "norm1.bias"], ln1, None, None, eps)
+            ops.gemm_nt(ln1, wqkv[C:], kv, bias=bqkv[C:], epi=EPI_BF16)
+            ops.gemm_nt(ln1.view(B, N, C)[:, 0, :], wqkv[:C], q, bias=bqkv[:C], epi=EPI_BF16)
+            xc = x.view(B, N, C)[:, 0, :].contiguous()
         att = ops.empty((B, C), BF16)
         ops.attn_cls_fwd(q, kv, cos, sin, att, B, N, H, cfg.head_width ** -0.5)
-        xc = x.view(B, N, C)[:, 0, :].contiguous()
         return self._block_post(i, b, xc, att, B, lambda: (None, None), None, True)
 
     # ------------------------------------------------------------------------------------------ teacher
@@ -610,12 +628,16 @@ class EvaEngine:
             xb = st = None
             folded = self.fold_sub_ln and self.fold_block_ln
             lo = ops.empty((B * N, cfg.width), torch.int16) if folded and self.split_stream and last > 0 else None
+            cls_folded = folded and last < cfg.layers and last > 0          # the CLS-only block takes the planes + statistics as they are
             for i in range(last):
                 if folded:
-                    xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last, lo=lo)
+                    xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last or cls_folded, lo=lo)
                 else:
                     self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
-            xc = self._block_fwd_cls(last, xf, B, N, cos, sin) if last < cfg.layers else x[:, 0, :]
+            if last < cfg.layers:
+                xc = self._block_fwd_cls(last, xf, B, N, cos, sin, xb if cls_folded else None, st, lo)
+            else:
+                xc = x[:, 0, :]
             cls = ops.empty((B, cfg.width), BF16)
             ops.layernorm_fwd(xc, self.p[P + "norm.weight"], self.p[P + "norm.bias"], cls, None, None, cfg.ln_eps)
             ops.gemm_nt(cls, self.w[P + "head.weight"], out[k0:k0 + B], bias=self.p[P + "head.bias"], epi=EPI_F32)

@@ -242,9 +242,10 @@ def _folded_linear(a_bf16, stats_of, ln_w, ln_b, W, b, eps, rq):
     return rstd * (a_bf16 @ Wf.T - mean * colsum) + d
 
 
-def frozen_block(sd, cfg, x, i, cos, sin, folded=True, fold_norm1=True, prefix="visual."):
+def frozen_block(sd, cfg, x, i, cos, sin, folded=True, fold_norm1=True, prefix="visual.", fold_kv=False):
     """One block of the frozen (teacher) tower with bf16 rounding exactly where the HIP schedule rounds (see
-    encode_image_frozen_schedule).  x fp32 [B, N, C] -> fp32 [B, N, C].  folded=False: the plain schedule of the CLS-only last block;
+    encode_image_frozen_schedule).  x fp32 [B, N, C] -> fp32 [B, N, C].  folded=False: the plain schedule of the CLS-only last block
+    (fold_kv: its keys and values nevertheless come from the folded norm1 GEMM on the split stream, its query from a plain LayerNorm);
     fold_norm1=False: block 0, whose norm1 is a LayerNorm kernel."""
     rq = _Round("kernel")
     eps = cfg.ln_eps
@@ -259,6 +260,9 @@ def frozen_block(sd, cfg, x, i, cos, sin, folded=True, fold_norm1=True, prefix="
     if not (folded and fold_norm1):
         n1 = rq(layer_norm(x, sd[blk + "norm1.weight"], sd[blk + "norm1.bias"], eps))
         qkv = n1 @ rq(wqkv).T + bqkv
+        if fold_kv:
+            kv = _folded_linear(_plane_round(x), x, sd[blk + "norm1.weight"], sd[blk + "norm1.bias"], wqkv, bqkv, eps, rq)
+            qkv = torch.cat([qkv[..., :C], kv[..., C:]], dim=-1)
     else:
         qkv = _folded_linear(_plane_round(x), x, sd[blk + "norm1.weight"], sd[blk + "norm1.bias"], wqkv, bqkv, eps, rq)
     q, k, v = (rq(t).reshape(B, N, H, d).permute(0, 2, 1, 3) for t in (qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]))
@@ -288,7 +292,8 @@ def encode_image_frozen_schedule(sd, cfg, images, prefix="visual.", return_strea
       * operands of every GEMM bf16, accumulation and epilogues fp32, q|k|v / attention output / SwiGLU hidden stored bf16;
       * the four LayerNorms of a block are folded into the following GEMM (_folded_linear): norm1 / norm2 see the residual stream rounded
         half-away-from-zero (the split stream's hi plane) with the statistics of its fp32 values; inner_attn_ln / ffn_ln see the stored
-        bf16 activations with the statistics of those rounded values; block 0 keeps a plain norm1 and the last block is unfolded;
+        bf16 activations with the statistics of those rounded values; block 0 keeps a plain norm1; the last (CLS-only) block is unfolded except for
+        its keys and values, which come from the folded norm1 GEMM on the split stream like everywhere else;
       * SiLU(x1) * x2 is formed from the fp32 accumulators (x1 / x2 are never stored), unlike emulate_bf16=True above, which rounds them
         as the training schedule does; the attention's P.V product takes the un-normalised exp(s - max) in bf16 (_Round("kernel")).
     Against this oracle the kernels' own error is what is left (summation order + the rounding flips it triggers); against
@@ -300,7 +305,7 @@ def encode_image_frozen_schedule(sd, cfg, images, prefix="visual.", return_strea
     L = cfg.layers
     stream = [x]
     for i in range(L):
-        x = frozen_block(sd, cfg, x, i, cos, sin, folded=i < L - 1, fold_norm1=i > 0, prefix=prefix)
+        x = frozen_block(sd, cfg, x, i, cos, sin, folded=i < L - 1, fold_norm1=i > 0, prefix=prefix, fold_kv=(i == L - 1 and L > 1))
         stream.append(x)
     out = rq(layer_norm(x, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], cfg.ln_eps))[:, 0]
     out = out @ rq(sd[prefix + "head.weight"]).T + sd[prefix + "head.bias"]
