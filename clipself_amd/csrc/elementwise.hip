@@ -350,15 +350,15 @@ extern "C" int cs_cls_row(float* x, const float* cls, const float* pos, int B, i
 // ------------------------------------------------------------------------------------------------ fp8 operands (BASELINE configs[4])
 // Row-wise e4m3 quantisation of a bf16 matrix for the fp8 MFMA GEMM (cs_gemm_nt_f8): q[m, k] = RNE_e4m3(x[m, k] * 448 / amax_m),
 // scale[m] = amax_m / 448 (1 for an all-zero row), columns K .. Kp-1 of q zero (the GEMM contracts over Kp, a multiple of 128).
-// One wave per row: the row stays in registers between the amax reduction and the conversion (K <= 4096), v_cvt_pk_fp8_f32 (OCP e4m3fn).
+// One wave per row: the row stays in registers between the amax reduction and the conversion (K <= 8192), v_cvt_pk_fp8_f32 (OCP e4m3fn).
 namespace {
 
+template <int IT>                                           // IT x (64 lanes x 8 elements) columns: 8 -> 4096, 16 -> 8192
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const __bf16* __restrict__ x, long ldx, unsigned char* __restrict__ q, long ldq,
                                                              float* __restrict__ scale, int M, int K, int Kp) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    constexpr int IT = 8;                                  // 8 x (64 lanes x 8 elements) = 4096 columns
     U128 v[IT];
     float amax = 0.f;
 #pragma unroll
@@ -394,10 +394,11 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const __bf16* __res
 // x bf16 [M, K] (row stride ldx elements) -> q e4m3 [M, Kp] (row stride ldq bytes, Kp = K rounded up to 128, padding zeroed), scale f32 [M]
 extern "C" int cs_quant_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int M, int K, hipStream_t stream) {
     const int Kp = (K + 127) / 128 * 128;
-    CS_CHECK_ARG(M > 0 && K > 0 && K % 8 == 0 && K <= 4096, "cs_quant_rows_fp8: K=%d must be a multiple of 8, at most 4096", K);
+    CS_CHECK_ARG(M > 0 && K > 0 && K % 8 == 0 && K <= 8192, "cs_quant_rows_fp8: K=%d must be a multiple of 8, at most 8192", K);
     CS_CHECK_ARG(ldx % 8 == 0 && ldq >= Kp && ldq % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)q % 8) == 0,
                  "cs_quant_rows_fp8: rows must be 16-byte (input) / 8-byte (output) aligned and ldq >= %d", Kp);
-    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, (const __bf16*)x, ldx, (unsigned char*)q, ldq, scale, M, K, Kp);
+    if (K <= 4096) hipLaunchKernelGGL(quant_rows_fp8_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, stream, (const __bf16*)x, ldx, (unsigned char*)q, ldq, scale, M, K, Kp);
+    else hipLaunchKernelGGL(quant_rows_fp8_kernel<16>, dim3((M + 3) / 4), dim3(256), 0, stream, (const __bf16*)x, ldx, (unsigned char*)q, ldq, scale, M, K, Kp);
     CS_LAUNCH_CHECK();
     return 0;
 }

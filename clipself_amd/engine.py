@@ -87,7 +87,7 @@ def is_no_decay(name: str, ndim: int) -> bool:
 
 class EvaEngine:
     BLOCK_TAG = "blocks."                     # state-dict name of the block list below the tower prefix
-    FP8_MAX_ROW = 4096                        # widest row cs_quant_rows_fp8 quantises (one row per wave, held in registers)
+    FP8_MAX_ROW = 8192                        # widest row cs_quant_rows_fp8 quantises (one row per wave, held in registers)
 
     def _layout(self):
         return param_groups_layout(self.cfg, self.prefix)
@@ -162,6 +162,11 @@ class EvaEngine:
         # contraction by the block-scaled fp8 MFMA, fp32 accumulate; backward (dgrad / wgrad) keeps the bf16 operands.  enable_fp8_forward().
         self.fp8_forward = False
         self.w8 = {}
+        # enable_fp8_forward(dgrad=True): the four dgrad GEMMs of a block (dX = dY . W) also contract e4m3 x e4m3 -- dY quantised per token
+        # row, the transposed weight shadows per input-feature row, both scales factor out of the contraction over the output features;
+        # wgrad (contraction over tokens: per-row scales do not factor out) stays bf16
+        self.fp8_dgrad = False
+        self.wt8 = {}
         self.wgrad_tn = True                   # weight gradients from the token-major operands (no transposed copies) where the shape allows
         if trainable:
             self.grad = ops.zeros((self.numel,), F32)
@@ -287,17 +292,33 @@ class EvaEngine:
             o = self.offsets[b + "mlp.w1.weight"][0]
             self.w8[(i, "w12")] = self._fp8_rows(self.shadow[o:o + 2 * Hd * C].view(2 * Hd, C))
             self.w8[(i, "w3")] = self._fp8_rows(self.storage_of(self.shadow, b + "mlp.w3.weight"))
+            if self.fp8_dgrad and i >= self.first_trainable:
+                for key, n in (("qkv", 3 * C), ("proj", C), ("w12", 2 * Hd), ("w3", C)):
+                    self.wt8[(i, key)] = self._fp8_rows(self.wt[(i, key)][:, :n])
 
-    def enable_fp8_forward(self, on: bool = True):
+    def _dgrad(self, i, key, dY, out, cols=None):
+        """out (bf16) = dY . W for the linear `key` of block i, through the transposed shadow (contraction over the output features, or over
+        the column range `cols` of them); with fp8_dgrad on e4m3 operands."""
+        n = dY.shape[1]
+        lo, hi = cols if cols is not None else (0, n)
+        if not self.fp8_dgrad or lo % 128 or (hi - lo) % 8:
+            self.ops.gemm_nt(dY, self.wt[(i, key)][:, lo:hi], out, epi=EPI_BF16)
+            return
+        q, sy = self._fp8_rows(dY)
+        w8, sw = self.wt8[(i, key)]
+        self.ops.gemm_nt_f8(q, w8[:, lo:lo + q.shape[1]], out, sy, sw, epi=EPI_BF16)
+
+    def enable_fp8_forward(self, on: bool = True, dgrad: bool = False):
         if on and not self.trainable:
             raise RuntimeError("fp8 forward operands belong to the training schedule; a frozen tower keeps its bf16 operands "
                                "(teacher targets and evaluation features must not depend on the run's precision flag)")
-        widest = max(self.cfg.width, self.Hp)
+        widest = max(self.cfg.width, self.Hp) if not dgrad else max(3 * self.cfg.width, 2 * self.Hp)
         if on and widest > self.FP8_MAX_ROW:
             raise NotImplementedError(f"amp_fp8: cs_quant_rows_fp8 keeps a row in registers and covers rows up to {self.FP8_MAX_ROW} wide; "
                                       f"this tower's widest GEMM operand is {widest}")
         self.fp8_forward = bool(on)
-        self.w8 = {}
+        self.fp8_dgrad = bool(on and dgrad)
+        self.w8, self.wt8 = {}, {}
         if on:
             self.sync_fp8()
 
@@ -727,7 +748,7 @@ class EvaEngine:
         # ---- MLP: x2 = x1 + w3(ffn_ln(silu(x1')*x2')) ------------------------------------------
         self._wgrad(gb, s["fln"], self.storage_of(self.grad, b + "mlp.w3.weight"))
         d_fln = ops.empty((M, Hd), BF16)
-        ops.gemm_nt(gb, self.wt[(i, "w3")][:, :C], d_fln, epi=EPI_BF16)                     # [M,C] . W3[C,Hd]
+        self._dgrad(i, "w3", gb, d_fln)                                                     # [M,C] . W3[C,Hd]
         d_hid = (ops.zeros if padded else ops.empty)((M, Hd), BF16)
         ops.layernorm_bwd(d_fln[:, :Hl], s["hid"][:, :Hl], self.p[b + "mlp.ffn_ln.weight"], *s["st4"], d_hid[:, :Hl], DX_BF16,
                           G[b + "mlp.ffn_ln.weight"], G[b + "mlp.ffn_ln.bias"], True, ws[0])
@@ -738,14 +759,14 @@ class EvaEngine:
         ow = self.offsets[b + "mlp.w1.weight"][0]
         self._wgrad(d_x12, s["ln2"], self.grad[ow:ow + 2 * Hd * C].view(2 * Hd, C))
         d_ln2 = ops.empty((M, C), BF16)
-        ops.gemm_nt(d_x12, self.wt[(i, "w12")][:, :2 * Hd], d_ln2, epi=EPI_BF16)            # [M,2Hd] . W12[2Hd,C]
+        self._dgrad(i, "w12", d_x12, d_ln2)                                                 # [M,2Hd] . W12[2Hd,C]
         # norm2's backward adds into the stream gradient and hands back its bf16 copy + column sums (= the proj bias gradient)
         ops.layernorm_bwd(d_ln2, s["x1"], self.p[b + "norm2.weight"], *s["st3"], g, DX_F32_ACCUM,
                           G[b + "norm2.weight"], G[b + "norm2.bias"], True, ws[0], dx_copy=gb, copy_colsum=G[b + "attn.proj.bias"])
         # ---- attention branch: x1 = x0 + proj(inner_ln(att)) -------------------------------------
         self._wgrad(gb, s["iln"], G[b + "attn.proj.weight"])
         d_iln = ops.empty((M, C), BF16)
-        ops.gemm_nt(gb, self.wt[(i, "proj")][:, :C], d_iln, epi=EPI_BF16)
+        self._dgrad(i, "proj", gb, d_iln)
         d_att = ops.empty((M, C), BF16)
         ops.layernorm_bwd(d_iln, s["att"], self.p[b + "attn.inner_attn_ln.weight"], *s["st2"], d_att, DX_BF16,
                           G[b + "attn.inner_attn_ln.weight"], G[b + "attn.inner_attn_ln.bias"], True, ws[0])
@@ -760,11 +781,11 @@ class EvaEngine:
             ops.colsum_bf16(d_qkv, self.grad[obq:obq + 3 * C], ws[1])
             self.grad[obq + C:obq + 2 * C].zero_()
             self._wgrad(d_qkv, s["ln1"], self.grad[oq:oq + 3 * C * C].view(3 * C, C))
-            ops.gemm_nt(d_qkv, self.wt[(i, "qkv")][:, :3 * C], d_ln1, epi=EPI_BF16)
+            self._dgrad(i, "qkv", d_qkv, d_ln1)
         else:
             ops.colsum_bf16(d_att, G[b + "attn.v_bias"], ws[1])
             self._wgrad(d_att, s["ln1"], G[b + "attn.v_proj.weight"])
-            ops.gemm_nt(d_att, self.wt[(i, "qkv")][:, 2 * C:3 * C], d_ln1, epi=EPI_BF16)
+            self._dgrad(i, "qkv", d_att, d_ln1, cols=(2 * C, 3 * C))
         ops.layernorm_bwd(d_ln1, s["x0"], self.p[b + "norm1.weight"], *s["st1"], g, DX_F32_ACCUM,
                           G[b + "norm1.weight"], G[b + "norm1.bias"], True, ws[0], dx_copy=gb if next_bias is not None else None,
                           copy_colsum=next_bias)

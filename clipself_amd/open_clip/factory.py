@@ -87,7 +87,7 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
     if jit:
         raise NotImplementedError("torchscript is not supported by the HIP engine")
     cfg = get_tower_cfg(model_name)
-    fp8 = precision in ("fp8", "amp_fp8")
+    fp8 = precision in ("fp8", "amp_fp8", "amp_fp8_dgrad")
     if cfg.arch == "openai":
         if fp8:
             raise NotImplementedError("precision='amp_fp8' exists for the EVA02 towers (RegionCLIP configuration) only")
@@ -109,7 +109,8 @@ def create_model(model_name: str, pretrained: Optional[str] = None, precision: s
         # amp_fp8 applies to the TRAINING forward schedule (the student of configs[4]); frozen towers -- the CLIPSelf teacher, the
         # end-of-epoch evaluation copy -- stay on bf16 operands, so distillation targets and evaluation features do not depend on
         # the precision flag of the run
-        model.visual.engine.enable_fp8_forward()
+        # "amp_fp8_dgrad" (or CLIPSELF_FP8_DGRAD=1): the dgrad GEMMs of the backward contract e4m3 operands as well (wgrad stays bf16)
+        model.visual.engine.enable_fp8_forward(dgrad=precision == "amp_fp8_dgrad" or os.environ.get("CLIPSELF_FP8_DGRAD") == "1")
     return model
 
 

@@ -26,7 +26,7 @@ _TABLE = [
     ("use-bn-sync", "flag", False), ("skip-scheduler", "flag", False), ("lr-scheduler", _S, "cosine"),
     ("lr-cooldown-end", _F, 0.0), ("lr-cooldown-power", _F, 1.0), ("save-frequency", _I, 1), ("save-most-recent", "flag", False),
     ("zeroshot-frequency", _I, 2), ("resume", _S, None),
-    ("precision", None, "amp", dict(choices=["amp", "amp_bf16", "amp_bfloat16", "bf16", "fp16", "fp32", "amp_fp8"])),
+    ("precision", None, "amp", dict(choices=["amp", "amp_bf16", "amp_bfloat16", "bf16", "fp16", "fp32", "amp_fp8", "amp_fp8_dgrad"])),
     ("model", _S, "RN50"), ("pretrained", _S, ""), ("pretrained-image", "flag", False), ("lock-image", "flag", False),
     ("lock-image-unlocked-groups", _I, 3), ("lock-image-freeze-bn-stats", "flag", True),
     ("image-mean", _F, None, dict(nargs="+", metavar="MEAN")), ("image-std", _F, None, dict(nargs="+", metavar="STD")),

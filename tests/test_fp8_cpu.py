@@ -33,13 +33,13 @@ def test_row_quantiser_contract():
     assert float(err.max()) < 2 ** -4 + 1e-6                   # e4m3: 3 mantissa bits -> relative step 2^-3, half of it after rounding
 
 
-def _model(cfg, fp8, seed=2):
+def _model(cfg, fp8, seed=2, dgrad=False):
     m = CustomCLIP(cfg, ops=RefOps(), trainable=True)
     m.visual.engine.load_state(seeded_visual_state(cfg, seed))
     m.lock_image_tower(unlocked_groups=cfg.layers)
     m.train()
     if fp8:
-        m.visual.engine.enable_fp8_forward()
+        m.visual.engine.enable_fp8_forward(dgrad=dgrad)
     return m
 
 
@@ -74,6 +74,36 @@ def test_fp8_forward_tracks_the_bf16_schedule_and_trains():
     assert torch.isfinite(out["fp8"][1]).all()
 
 
+def test_fp8_dgrad_tracks_the_fp8_forward_gradients():
+    """precision "amp_fp8_dgrad": the four dgrad GEMMs of every block contract e4m3 x e4m3 (dY per token row, W^T per input-feature row;
+    wgrad stays bf16).  Same forward as amp_fp8, so the loss is identical; the gradients differ by the quantisation of dY / W^T only."""
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.region_clip import RegionCLIP
+    from clipself_amd.training.train import train_step
+    from test_regionclip_cpu import regionclip_inputs
+    cfg = tiny_cfg()
+    images, bx, nouns = regionclip_inputs(cfg)
+    args = SimpleNamespace(device="cpu", precision="amp_fp8_dgrad", distributed=False, skip_scheduler=True, grad_clip_norm=None,
+                           extract_type="v2", contrast_weight=1.0)
+    out = {}
+    for tag, dgrad in (("fwd", False), ("dgrad", True)):
+        m = _model(cfg, True, dgrad=dgrad)
+        eng = m.visual.engine
+        assert eng.fp8_dgrad == dgrad and (len(eng.wt8) == 4 * (cfg.layers - eng.first_trainable)) == dgrad
+        method = RegionCLIP(SimpleNamespace(), noun_embeddings=nouns)
+        opt = FlatAdamW(m, lr=1e-3, weight_decay=0.1)
+        wt8_before = {k: v[0].clone() for k, v in eng.wt8.items()}
+        losses, _, _ = train_step(m, method, (images, bx), opt, None, 0, None, args)
+        out[tag] = (float(losses["loss"]), eng.grad.clone())
+        if dgrad:
+            assert sum(int(not torch.equal(v[0], wt8_before[k])) for k, v in eng.wt8.items()) == len(wt8_before) > 0, \
+                "every e4m3 W^T shadow is refreshed after the AdamW step"
+    assert out["fwd"][0] == out["dgrad"][0], "same forward"
+    r = rel(out["dgrad"][1], out["fwd"][1])
+    assert 1e-4 < r < 0.2, r                                  # really quantised, and close
+    assert torch.isfinite(out["dgrad"][1]).all()
+
+
 def test_factory_precision_amp_fp8_switches_the_engine():
     from clipself_amd.open_clip import create_model
     m = create_model("EVA02-CLIP-B-16", "eva", precision="amp_fp8", cache_dir=None, ops=RefOps())
@@ -81,6 +111,7 @@ def test_factory_precision_amp_fp8_switches_the_engine():
     assert eng.fp8_forward and len(eng.w8) == 4 * eng.cfg.layers
     q, s = eng.w8[(0, "w3")]
     assert q.dtype == torch.uint8 and q.shape == (768, 2048) and s.shape == (768,)
+    assert not eng.fp8_dgrad and not eng.wt8
     assert not create_model("EVA02-CLIP-B-16", "eva", precision="amp_bf16", cache_dir=None, ops=RefOps()).visual.engine.fp8_forward
 
 

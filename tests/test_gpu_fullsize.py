@@ -242,13 +242,13 @@ def test_cfg4_l14_336_regionclip_fp8_forward(monkeypatch):
     with torch.no_grad():
         want = float(eva_ref.regionclip_loss(dict(sd0), cfg, images, bx, nouns, appeared=appeared))
     losses, models = {}, {}
-    for tag in ("bf16", "fp8"):
+    for tag in ("bf16", "fp8", "fp8+dgrad"):
         m = CustomCLIP(cfg, trainable=True)
         m.visual.engine.load_state(sd0)
         m.lock_image_tower(unlocked_groups=cfg.layers)
         m.train()
-        if tag == "fp8":
-            m.visual.engine.enable_fp8_forward()
+        if tag != "bf16":
+            m.visual.engine.enable_fp8_forward(dgrad=tag == "fp8+dgrad")      # "amp_fp8_dgrad": e4m3 operands in the dgrad GEMMs as well
         out, _, _ = rc.RegionCLIP(SimpleNamespace(), noun_embeddings=nouns)((images, bx), m, None, None, "cuda", None, False, a)
         total = sum(out.values())
         total.backward()
@@ -257,11 +257,15 @@ def test_cfg4_l14_336_regionclip_fp8_forward(monkeypatch):
     _log(f"cfg4 L/14-336 RegionCLIP fp8 forward (2 images): loss fp8 {losses['fp8']:.4f} bf16 {losses['bf16']:.4f} oracle {want:.4f}; "
          f"grad rel fp8-vs-bf16 {rel(models['fp8'].visual.engine.grad, models['bf16'].visual.engine.grad):.3e}")
     assert abs(losses["fp8"] - losses["bf16"]) / losses["bf16"] < 3e-2 and abs(losses["fp8"] - want) / want < 3e-2
+    rd = rel(models["fp8+dgrad"].visual.engine.grad, models["fp8"].visual.engine.grad)
+    _log(f"cfg4 L/14-336 RegionCLIP fp8 forward + dgrad (2 images): loss {losses['fp8+dgrad']:.4f} (same forward); "
+         f"grad rel vs fp8-forward {rd:.3e}, vs bf16 {rel(models['fp8+dgrad'].visual.engine.grad, models['bf16'].visual.engine.grad):.3e}")
+    assert losses["fp8+dgrad"] == losses["fp8"] and 1e-4 < rd < 0.3
     monkeypatch.undo()
     # step time at the full per-GPU batch (32 images x <= 20 boxes), bf16 vs fp8 forward
     images, bx, nouns = _regionclip_batch(cfg, 32, seed=78)
     batch = (images.cuda(), bx.cuda())
-    for tag in ("bf16", "fp8"):
+    for tag in ("bf16", "fp8", "fp8+dgrad"):
         m = models[tag]
         method = rc.RegionCLIP(SimpleNamespace(), noun_embeddings=nouns)
         opt = FlatAdamW(m, lr=1e-5, weight_decay=0.1)

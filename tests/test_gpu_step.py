@@ -651,6 +651,15 @@ def test_fp8_forward_loss_curve_follows_the_reference_over_24_steps(golden_dir):
     _log(f"24-step loss curve, fp8 forward: worst |loss - reference| = {worst:.3e}; last {losses[-1]:.4f}")
 
 
+@pytest.mark.gpu
+def test_fp8_forward_and_dgrad_loss_curve_follows_the_reference_over_24_steps(golden_dir):
+    """precision amp_fp8_dgrad: e4m3 operands in the forward linears and in the four dgrad GEMMs of every block (wgrad in bf16); same bounds."""
+    from clipself_amd.hip import HipOps
+    from test_loss_curve_cpu import run_curve
+    worst, losses = run_curve(golden_dir, HipOps(), "cuda", fp8="dgrad", bound=2e-2, end_bound=1e-2)
+    _log(f"24-step loss curve, fp8 forward + dgrad: worst |loss - reference| = {worst:.3e}; last {losses[-1]:.4f}")
+
+
 def test_training_main_reads_coco_files(tmp_path):
     """`--train-data <annotation json> --train-image-root <dir>` as in the reference's scripts: files decoded on the host (read-ahead threads),
     crops / det images produced by cs_crop_resize_u8, CLIPSelf steps through training.main."""

@@ -38,8 +38,8 @@ def run_curve(golden_dir, ops, device, fp8=False, bound=2e-2, end_bound=1e-2):
     student.lock_image_tower(unlocked_groups=cfg.layers)
     student.train()
     teacher.eval()
-    if fp8:                                              # precision="amp_fp8": e4m3 operands in the student's forward linears only
-        student.visual.engine.enable_fp8_forward()
+    if fp8:                                              # precision="amp_fp8": e4m3 operands in the student's forward linears only;
+        student.visual.engine.enable_fp8_forward(dgrad=fp8 == "dgrad")      # "amp_fp8_dgrad": in its dgrad GEMMs as well
     opt = FlatAdamW(student, lr=rec["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=rec["wd"])
     sched = cosine_lr(opt, rec["lr"], rec["warmup"], rec["total"])
     args = SimpleNamespace(device=device, precision="amp", distributed=False, skip_scheduler=False, grad_clip_norm=None, multiscale=False,
@@ -80,3 +80,12 @@ def test_fp8_forward_follows_the_reference_curve(golden_dir):
     torch.set_num_threads(4)
     worst, losses = run_curve(golden_dir, RefOps(), "cpu", fp8=True, bound=2e-2, end_bound=1e-2)
     print("fp8 forward: worst |loss - reference| over 24 steps:", worst, "last", losses[-1])
+
+
+def test_fp8_forward_and_dgrad_follows_the_reference_curve(golden_dir):
+    """precision "amp_fp8_dgrad": e4m3 operands in the forward linears AND in the four dgrad GEMMs of every block (dY per token row, W^T per
+    input-feature row; wgrad in bf16), 24 optimiser steps against the curve recorded from the fp32 reference, same bounds as above."""
+    from oracle.ops_ref import RefOps
+    torch.set_num_threads(4)
+    worst, losses = run_curve(golden_dir, RefOps(), "cpu", fp8="dgrad", bound=2e-2, end_bound=1e-2)
+    print("worst |loss - reference| over 24 steps, fp8 forward + dgrad:", worst)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """One-GPU timing of BASELINE configs[4]'s shapes: EVA02-CLIP-L-14-336 RegionCLIP (region-text) step, 32 images x <= 20 boxes at 336^2
 against a 4764 x 768 noun bank -- student forward (24 blocks, 577 tokens), RoIAlign, federated BCE, backward, AdamW; with the bf16
-forward and with "fp8 MFMA weights" (precision amp_fp8: forward linears on e4m3 operands).  One JSON line per precision.
+forward and with "fp8 MFMA weights" (precision amp_fp8: forward linears on e4m3 operands; amp_fp8_dgrad: the dgrad GEMMs as well).  One JSON line per precision.
 usage (GPU box): python tools/regionclip_bench.py [steps]"""
 import json
 import sys
@@ -29,7 +29,7 @@ valid = torch.from_numpy((g.random((B, KBOX, 1)) < 0.7).astype(np.float32))
 valid[:, 0] = 1.0
 batch = (images.to(dev), torch.cat([nb[..., :4], labels, valid], dim=-1).to(dev))
 nouns = torch.from_numpy(g.standard_normal((NOUNS, 768)).astype(np.float32))
-for precision in ("amp_bf16", "amp_fp8"):
+for precision in ("amp_bf16", "amp_fp8", "amp_fp8_dgrad"):
     model = create_model(MODEL, "eva", precision=precision, device=dev, cache_dir=None)
     cfg = model.visual.cfg
     model.lock_image_tower(unlocked_groups=cfg.layers)
@@ -52,7 +52,7 @@ for precision in ("amp_bf16", "amp_fp8"):
     blk_na = 4 * N * C * C + 6 * N * C * Hd
     F = (pe + (L - 1) * blk + blk_na + 2 * (N - 1) * C * E) + 2 * ((L - 1) * blk + blk_na) + 2 * (N - 1) * C * E     # S_f + S_b
     print(json.dumps({"metric": "images/sec (RegionCLIP region-text step), ViT-L/14-336", "value": B / dt, "unit": "images/sec", "n_gpus": 1,
-                      "steps": steps, "ms_per_step": 1e3 * dt, "dtype": "fp8 (e4m3 forward operands) + bf16" if precision == "amp_fp8" else "bf16",
+                      "steps": steps, "ms_per_step": 1e3 * dt, "dtype": {"amp_fp8": "fp8 (e4m3 forward operands) + bf16", "amp_fp8_dgrad": "fp8 (e4m3 forward and dgrad operands) + bf16"}.get(precision, "bf16"),
                       "data": "synthetic", "step_tflops": F * B / dt / 1e12,
                       "config": {"workload": f"{MODEL} RegionCLIP, {B} images x <= {KBOX} boxes, {S}^2, {NOUNS} nouns (BASELINE configs[4])",
                                  "precision": precision, "loss_last_step": float(out["loss"].detach())}}), flush=True)
