@@ -45,6 +45,65 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const __bf16* __restric
     }
 }
 
+// The same with the e4m3 copy of the output row for an fp8 dgrad (cs_gemm_nt_f8): one wave per row; the rounded bf16 outputs stay in
+// registers between the amax reduction and v_cvt_pk_fp8_f32, so q8 / q_scale are bit-identical to cs_quant_rows_fp8(dx12) without its
+// pass over the 2*Hd-wide matrix.  q8 row = [dx1 codes | dx2 codes | zero bytes up to Kp].  IT x 512 >= Hd.
+template <int IT>
+__global__ __launch_bounds__(256) void swiglu_bwd_q8_kernel(const __bf16* __restrict__ dh, long lddh, const __bf16* __restrict__ x12, long ldx,
+                                                            __bf16* __restrict__ dx12, long lddx, unsigned char* __restrict__ q8, long ldq,
+                                                            float* __restrict__ q_scale, int M, int Hd, int Kp) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    U128 a[IT], b[IT], g[IT], o1[IT], o2[IT];
+    const int jlast = Hd - 8;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {                       // branch-free loads: lanes past the row end re-read its last vector
+        const int j = min((it * 64 + lane) * 8, jlast);
+        a[it].u = *(const uint4*)(x12 + (size_t)m * ldx + j);
+        b[it].u = *(const uint4*)(x12 + (size_t)m * ldx + Hd + j);
+        g[it].u = *(const uint4*)(dh + (size_t)m * lddh + j);
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int j = (it * 64 + lane) * 8;
+        const bool in = j < Hd;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x1 = bf2f(a[it].e[e]), x2 = bf2f(b[it].e[e]), d = bf2f(g[it].e[e]);
+            const float sig = 1.f / (1.f + __expf(-x1));
+            o1[it].e[e] = f2bf(d * x2 * (sig + x1 * sig * (1.f - sig)));
+            o2[it].e[e] = f2bf(d * x1 * sig);
+            if (in) amax = fmaxf(amax, fmaxf(fabsf(bf2f(o1[it].e[e])), fabsf(bf2f(o2[it].e[e]))));
+        }
+        if (in) {
+            *(uint4*)(dx12 + (size_t)m * lddx + j) = o1[it].u;
+            *(uint4*)(dx12 + (size_t)m * lddx + Hd + j) = o2[it].u;
+        }
+    }
+    amax = wave_max(amax);
+    const float inv = amax > 0.f ? 448.f / amax : 0.f;
+    if (lane == 0) q_scale[m] = amax > 0.f ? amax / 448.f : 1.f;
+    auto cvt8 = [&](const U128& v) {
+        unsigned lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.e[0]) * inv, bf2f(v.e[1]) * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.e[2]) * inv, bf2f(v.e[3]) * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.e[4]) * inv, bf2f(v.e[5]) * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf2f(v.e[6]) * inv, bf2f(v.e[7]) * inv, hi, true);
+        return make_uint2(lo, hi);
+    };
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int j = (it * 64 + lane) * 8;
+        if (j < Hd) {
+            *(uint2*)(q8 + m * ldq + j) = cvt8(o1[it]);
+            *(uint2*)(q8 + m * ldq + Hd + j) = cvt8(o2[it]);
+        }
+    }
+    for (int k = 2 * Hd + lane * 8; k < Kp; k += 512) *(uint2*)(q8 + m * ldq + k) = make_uint2(0u, 0u);      // 2*Hd % 8 == 0, Kp % 128 == 0
+}
+
 // MLP activation of the OpenAI-CLIP ViT blocks (open_clip/transformer.py:209-213): nn.GELU (exact, erf) or QuickGELU
 // x*sigmoid(1.702x) (:31-34, forced for the `openai` weights).  Forward on the bf16 c_fc output kept for backward; fp32 inside.
 template <bool QUICK>
@@ -272,6 +331,21 @@ extern "C" int cs_swiglu_bwd(const void* dh, long lddh, const void* x12, long ld
     CS_CHECK_ARG(Hd % 8 == 0 && ldx % 8 == 0 && lddh % 8 == 0 && lddx % 8 == 0 && M > 0, "cs_swiglu_bwd: Hd/ld must be multiples of 8");
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((long)M * (Hd / 8))), dim3(256), 0, stream, (const __bf16*)dh, lddh, (const __bf16*)x12, ldx,
                        (__bf16*)dx12, lddx, M, Hd);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
+// cs_swiglu_bwd + the e4m3 copy of dx12 for an fp8 dgrad: q8 [M, ldq >= Kp = 2*Hd rounded up to 128] bytes, q_scale [M]; bit-identical to
+// cs_quant_rows_fp8(dx12).  Hd <= 4096.
+extern "C" int cs_swiglu_bwd_q8(const void* dh, long lddh, const void* x12, long ldx, void* dx12, long lddx, void* q8, long ldq, float* q_scale,
+                                int M, int Hd, hipStream_t stream) {
+    const int Kp = (2 * Hd + 127) / 128 * 128;
+    CS_CHECK_ARG(Hd % 8 == 0 && Hd >= 8 && Hd <= 4096 && ldx % 8 == 0 && lddh % 8 == 0 && lddx % 8 == 0 && M > 0, "cs_swiglu_bwd_q8: Hd=%d (%% 8, <= 4096), ld %% 8", Hd);
+    CS_CHECK_ARG(q8 && q_scale && ldq >= Kp && ldq % 8 == 0 && ((uintptr_t)q8 % 8) == 0, "cs_swiglu_bwd_q8: q8 rows of >= %d bytes, 8-byte aligned", Kp);
+    const dim3 grid((M + 3) / 4), block(256);
+#define SWQ(IT) hipLaunchKernelGGL(swiglu_bwd_q8_kernel<IT>, grid, block, 0, stream, (const __bf16*)dh, lddh, (const __bf16*)x12, ldx, (__bf16*)dx12, lddx, \
+                                   (unsigned char*)q8, ldq, q_scale, M, Hd, Kp)
+    if (Hd <= 2048) SWQ(4); else if (Hd <= 3072) SWQ(6); else SWQ(8);
+#undef SWQ
     CS_LAUNCH_CHECK();
     return 0;
 }

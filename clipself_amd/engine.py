@@ -296,7 +296,7 @@ class EvaEngine:
                 for key, n in (("qkv", 3 * C), ("proj", C), ("w12", 2 * Hd), ("w3", C)):
                     self.wt8[(i, key)] = self._fp8_rows(self.wt[(i, key)][:, :n])
 
-    def _dgrad(self, i, key, dY, out, cols=None):
+    def _dgrad(self, i, key, dY, out, cols=None, q=None):
         """out (bf16) = dY . W for the linear `key` of block i, through the transposed shadow (contraction over the output features, or over
         the column range `cols` of them); with fp8_dgrad on e4m3 operands."""
         n = dY.shape[1]
@@ -304,7 +304,7 @@ class EvaEngine:
         if not self.fp8_dgrad or lo % 128 or (hi - lo) % 8:
             self.ops.gemm_nt(dY, self.wt[(i, key)][:, lo:hi], out, epi=EPI_BF16)
             return
-        q, sy = self._fp8_rows(dY)
+        q, sy = q if q is not None else self._fp8_rows(dY)            # q: (codes, scales) already produced by the kernel that wrote dY
         w8, sw = self.wt8[(i, key)]
         self.ops.gemm_nt_f8(q, w8[:, lo:lo + q.shape[1]], out, sy, sw, epi=EPI_BF16)
 
@@ -753,13 +753,18 @@ class EvaEngine:
         ops.layernorm_bwd(d_fln[:, :Hl], s["hid"][:, :Hl], self.p[b + "mlp.ffn_ln.weight"], *s["st4"], d_hid[:, :Hl], DX_BF16,
                           G[b + "mlp.ffn_ln.weight"], G[b + "mlp.ffn_ln.bias"], True, ws[0])
         d_x12 = ops.empty((M, 2 * Hd), BF16)
-        ops.swiglu_bwd(d_hid, s["x12"], d_x12)
+        q12 = None
+        if self.fp8_dgrad and Hd <= 4096:
+            q12 = (ops.empty((M, _round_up(2 * Hd, 128)), torch.uint8), ops.empty((M,), F32))
+            ops.swiglu_bwd(d_hid, s["x12"], d_x12, q8=q12[0], q_scale=q12[1])
+        else:
+            ops.swiglu_bwd(d_hid, s["x12"], d_x12)
         ob = self.offsets[b + "mlp.w1.bias"][0]
         ops.colsum_bf16(d_x12, self.grad[ob:ob + 2 * Hd], ws[1])
         ow = self.offsets[b + "mlp.w1.weight"][0]
         self._wgrad(d_x12, s["ln2"], self.grad[ow:ow + 2 * Hd * C].view(2 * Hd, C))
         d_ln2 = ops.empty((M, C), BF16)
-        self._dgrad(i, "w12", d_x12, d_ln2)                                                 # [M,2Hd] . W12[2Hd,C]
+        self._dgrad(i, "w12", d_x12, d_ln2, q=q12)                                          # [M,2Hd] . W12[2Hd,C]
         # norm2's backward adds into the stream gradient and hands back its bf16 copy + column sums (= the proj bias gradient)
         ops.layernorm_bwd(d_ln2, s["x1"], self.p[b + "norm2.weight"], *s["st3"], g, DX_F32_ACCUM,
                           G[b + "norm2.weight"], G[b + "norm2.bias"], True, ws[0], dx_copy=gb, copy_colsum=G[b + "attn.proj.bias"])

@@ -52,6 +52,7 @@ SIGNATURES = {
     "cs_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_swiglu_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
     "cs_swiglu_bwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _vp]),
+    "cs_swiglu_bwd_q8": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _vp]),
     "cs_gelu_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp]),
     "cs_gelu_bwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _vp]),
     "cs_cast_f32_bf16": (_i, [_vp, _vp, _l, _vp]),
@@ -361,7 +362,17 @@ class HipOps:
         M, Hd = h.shape
         self._ok(self.lib.cs_swiglu_fwd(_p(x12), x12.stride(0), _p(h), h.stride(0), M, Hd, self._stream()), "cs_swiglu_fwd")
 
-    def swiglu_bwd(self, dh, x12, dx12):
+    def swiglu_bwd_q8(self, dh, x12, dx12, q8, q_scale):
+        """swiglu_bwd + the e4m3 copy of dx12 (bytes [M, 2*Hd rounded up to 128] + fp32 row scales) for an fp8 dgrad; = quant_rows_fp8(dx12)."""
+        self._chk(dh, x12, dx12, q8, q_scale)
+        M, Hd = dh.shape
+        assert q_scale is not None and q8.element_size() == 1 and q8.stride(1) == 1 and q8.shape[1] >= (2 * Hd + 127) // 128 * 128
+        self._ok(self.lib.cs_swiglu_bwd_q8(_p(dh), dh.stride(0), _p(x12), x12.stride(0), _p(dx12), dx12.stride(0), _p(q8), q8.stride(0),
+                                           _p(q_scale), M, Hd, self._stream()), "cs_swiglu_bwd_q8")
+
+    def swiglu_bwd(self, dh, x12, dx12, q8=None, q_scale=None):
+        if q8 is not None:
+            return self.swiglu_bwd_q8(dh, x12, dx12, q8, q_scale)
         self._chk(dh, x12, dx12)
         M, Hd = dh.shape
         self._ok(self.lib.cs_swiglu_bwd(_p(dh), dh.stride(0), _p(x12), x12.stride(0), _p(dx12), dx12.stride(0), M, Hd,

@@ -142,6 +142,10 @@ int cs_attn_bwd(const void* qkv, const void* o, const void* dout, const float* l
 /* --- SwiGLU elementwise: eva_vit_model.py:101  hidden = silu(x1) * x2   (x12 = [x1 | x2], each Hd wide) */
 int cs_swiglu_fwd(const void* x12, long ldx, void* h, long ldh, int M, int Hd, cs_stream_t stream);
 int cs_swiglu_bwd(const void* dh, long lddh, const void* x12, long ldx, void* dx12, long lddx, int M, int Hd, cs_stream_t stream);
+/* the same + the e4m3 copy of dx12 (row-wise amax / 448 scales, bytes [dx1 | dx2 | zero padding to a multiple of 128]) for an fp8 dgrad through
+   cs_gemm_nt_f8 -- bit-identical to cs_quant_rows_fp8(dx12), without its pass over the matrix; Hd <= 4096 */
+int cs_swiglu_bwd_q8(const void* dh, long lddh, const void* x12, long ldx, void* dx12, long lddx, void* q8, long ldq, float* q_scale,
+                     int M, int Hd, cs_stream_t stream);
 
 /* --- GELU / QuickGELU elementwise on bf16 [M,N] (training path keeps the c_fc output): src/open_clip/transformer.py:31-34,211
  *     y = act(x); dx = dy * act'(x); quick 0 = nn.GELU (erf), 1 = x*sigmoid(1.702x) */

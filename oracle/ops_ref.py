@@ -355,12 +355,17 @@ class RefOps:
         x1, x2 = x12[:, :Hd].float(), x12[:, Hd:2 * Hd].float()
         h.copy_((F.silu(x1) * x2).to(torch.bfloat16))
 
-    def swiglu_bwd(self, dh, x12, dx12):
+    def swiglu_bwd(self, dh, x12, dx12, q8=None, q_scale=None):
         Hd = dh.shape[1]
         x1, x2, d = x12[:, :Hd].float(), x12[:, Hd:2 * Hd].float(), dh.float()
         sig = torch.sigmoid(x1)
         dx12[:, :Hd] = (d * x2 * (sig + x1 * sig * (1 - sig))).to(torch.bfloat16)
         dx12[:, Hd:2 * Hd] = (d * x1 * sig).to(torch.bfloat16)
+        if q8 is not None:                       # cs_swiglu_bwd_q8: = quant_rows_fp8 of the rounded output
+            self.quant_rows_fp8(dx12[:, :2 * Hd], q8[:, :(2 * Hd + 127) // 128 * 128], q_scale)
+
+    def swiglu_bwd_q8(self, dh, x12, dx12, q8, q_scale):
+        self.swiglu_bwd(dh, x12, dx12, q8, q_scale)
 
     def cast_f32_bf16(self, x, y):
         y.copy_(x.to(torch.bfloat16))

@@ -808,6 +808,26 @@ def test_fp8_quantisation_and_gemm(hip, ref, M, N, K, epi):
     assert float((got - exact).norm() / exact.norm()) < 6e-2
 
 
+@pytest.mark.parametrize("Hd,M", [(2048, 333), (2752, 129), (64, 5), (4096, 17)])
+def test_swiglu_backward_with_fused_fp8_quantiser(hip, ref, Hd, M):
+    """cs_swiglu_bwd_q8: dx12 unchanged, and its e4m3 copy + row scales are bit-identical to cs_quant_rows_fp8 applied to dx12 afterwards."""
+    dh = rnd((M, Hd), BF, 0.5, seed=70)
+    x12 = rnd((M, 2 * Hd), BF, 1.5, seed=71)
+    dh[3] = 0                                                       # an all-zero row: scale 1, codes 0
+    dhd, xd = both([dh, x12])
+    d0 = torch.empty(M, 2 * Hd, dtype=BF, device="cuda")
+    hip.swiglu_bwd(dhd, xd, d0)
+    Kp = (2 * Hd + 127) // 128 * 128
+    d1 = torch.empty_like(d0)
+    q1, s1 = torch.full((M, Kp), 0x55, dtype=torch.uint8, device="cuda"), torch.empty(M, device="cuda")
+    hip.swiglu_bwd(dhd, xd, d1, q8=q1, q_scale=s1)
+    assert torch.equal(d0, d1)
+    q0, s0 = torch.full((M, Kp), 0xAA, dtype=torch.uint8, device="cuda"), torch.empty(M, device="cuda")
+    hip.quant_rows_fp8(d0, q0, s0)
+    assert torch.equal(s0, s1), "row scales"
+    assert torch.equal(q0, q1), f"{int((q0 != q1).sum())} e4m3 codes differ"
+
+
 @pytest.mark.parametrize("C,ld,xdt", [(768, 768, F32), (768, 768, BF), (2048, 2048, BF), (2730, 2752, BF), (64, 64, F32)])
 def test_layernorm_forward_with_fused_fp8_quantiser(hip, ref, C, ld, xdt):
     """cs_layernorm_fwd_q8: y unchanged, and its e4m3 copy + row scales are bit-identical to cs_quant_rows_fp8 applied to y afterwards
