@@ -187,7 +187,11 @@ template <typename TX, int DXMODE, int MAXG, bool COPY>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, long lddy, const TX* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, void* __restrict__ dx, long lddx,
-                                                     __bf16* __restrict__ dxb, long lddxb, float* __restrict__ part, int M, int C) {
+                                                     __bf16* __restrict__ dxb, long lddxb, float* __restrict__ part, int M, int C,
+                                                     unsigned char* __restrict__ q8 = nullptr, long ldq = 0, float* __restrict__ q_scale = nullptr,
+                                                     int Kp = 0) {
+    // q8 (COPY only, nullable): the bf16 copy's row also leaves as e4m3 bytes + one fp32 scale, = cs_quant_rows_fp8 of the copy (the fp8
+    // dgrad's A operand), from the registers that hold the rounded row
     static_assert(!COPY || DXMODE != DX_BF16, "the bf16 copy exists for the fp32 stream modes");
     constexpr int NR = COPY ? 3 : 2;               // partial rows: dgamma, dbeta[, column sums of the bf16 copy]
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -236,9 +240,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
             }
         }
         const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+        float rq[COPY ? MAXG : 1][4];              // the rounded copy, kept for the quantiser
+        float amax = 0.f;
 #pragma unroll
         for (int g = 0; g < MAXG; ++g) {
             const int c = (g * 64 + lane) * 4;
+            if (COPY) { rq[g][0] = rq[g][1] = rq[g][2] = rq[g][3] = 0.f; }
             if (g < ng && c < C) {
                 float o[4];
 #pragma unroll
@@ -257,10 +264,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             t.e[i] = f2bf(o[i]);
-                            dc[g][i] += (c + i < C) ? bf2f(t.e[i]) : 0.f;      // sums of the ROUNDED values: what a colsum over the copy gives
+                            rq[g][i] = (c + i < C) ? bf2f(t.e[i]) : 0.f;
+                            dc[g][i] += rq[g][i];                              // sums of the ROUNDED values: what a colsum over the copy gives
+                            amax = fmaxf(amax, fabsf(rq[g][i]));
                         }
                         *(uint2*)(dxb + (size_t)row * lddxb + c) = t.u;
                     }
+                }
+            }
+        }
+        if (COPY && q8 != nullptr) {               // wave-uniform
+            amax = wave_max(amax);
+            const float inv = amax > 0.f ? 448.f / amax : 0.f;
+            if (lane == 0) q_scale[row] = amax > 0.f ? amax / 448.f : 1.f;
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g) {
+                const int c = (g * 64 + lane) * 4;
+                if (c < Kp) {                      // Kp % 128 == 0: whole 4-byte groups; columns >= C are zero bytes
+                    unsigned w = 0;
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(rq[g][0] * inv, rq[g][1] * inv, w, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(rq[g][2] * inv, rq[g][3] * inv, w, true);
+                    *(unsigned*)(q8 + (size_t)row * ldq + c) = w;
                 }
             }
         }
@@ -455,10 +479,13 @@ extern "C" size_t cs_layernorm_bwd_workspace(int M, int C) {
     const int nwg = min(512, (M + 3) / 4);
     return (size_t)nwg * 3 * ((C + 3) & ~3) * sizeof(float);
 }
-extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
-                                const float* rstd, void* dx, int dx_mode, long lddx, float* dgamma, float* dbeta,
-                                int accumulate_params, void* workspace, void* dx_copy, long ldcopy, float* copy_colsum, int M, int C,
-                                hipStream_t stream) {
+static int layernorm_bwd_impl(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
+                              const float* rstd, void* dx, int dx_mode, long lddx, float* dgamma, float* dbeta,
+                              int accumulate_params, void* workspace, void* dx_copy, long ldcopy, float* copy_colsum, void* q8, long ldq,
+                              float* q_scale, int M, int C, hipStream_t stream) {
+    const int Kp = (C + 127) / 128 * 128;
+    CS_CHECK_ARG(q8 == nullptr || (dx_copy != nullptr && q_scale != nullptr && ldq >= Kp && ldq % 4 == 0 && ((uintptr_t)q8 % 4) == 0 && Kp <= 256 * 12),
+                 "cs_layernorm_bwd_q8: needs dx_copy, the scale vector and 4-byte aligned e4m3 rows of >= %d bytes", Kp);
     CS_CHECK_ARG(C <= MAXC && (C % 4 == 0 || (ldx >= ((C + 3) & ~3) && lddy >= ((C + 3) & ~3) && lddx >= ((C + 3) & ~3))), "cs_layernorm_bwd: C=%d unsupported", C);
     CS_CHECK_ARG(M > 0, "cs_layernorm_bwd: empty input");
     CS_CHECK_ARG(dx_mode >= 0 && dx_mode <= 2, "cs_layernorm_bwd: bad dx_mode");
@@ -479,7 +506,7 @@ extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_
         static bool once = (hipFuncSetAttribute((const void*)ln_bwd_kernel<TX, MODE, NG, CP>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 3 * MAXC * 4), true); \
         (void)once;                                                                                                         \
         hipLaunchKernelGGL((ln_bwd_kernel<TX, MODE, NG, CP>), grid, block, lds, stream, (const __bf16*)dy, lddy, (const TX*)x, ldx, gamma, mean, rstd, dx, lddx, \
-                           (__bf16*)dx_copy, ldcopy, part, M, C);                                                          \
+                           (__bf16*)dx_copy, ldcopy, part, M, C, (unsigned char*)q8, ldq, q_scale, Kp);                     \
     } while (0)
 #define LNB3(TX, MODE, NG) do { if (copy) { if constexpr (MODE != DX_BF16) LNB4(TX, MODE, NG, true); } else LNB4(TX, MODE, NG, false); } while (0)
 #define LNB(TX, MODE) do { if (C <= 1024) LNB3(TX, MODE, 4); else if (C <= 2048) LNB3(TX, MODE, 8); else LNB3(TX, MODE, 12); } while (0)
@@ -498,6 +525,23 @@ extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_
         CS_LAUNCH_CHECK();
     }
     return 0;
+}
+extern "C" int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
+                                const float* rstd, void* dx, int dx_mode, long lddx, float* dgamma, float* dbeta,
+                                int accumulate_params, void* workspace, void* dx_copy, long ldcopy, float* copy_colsum, int M, int C,
+                                hipStream_t stream) {
+    return layernorm_bwd_impl(dy, lddy, x, x_dtype, ldx, gamma, mean, rstd, dx, dx_mode, lddx, dgamma, dbeta, accumulate_params, workspace,
+                              dx_copy, ldcopy, copy_colsum, nullptr, 0, nullptr, M, C, stream);
+}
+// cs_layernorm_bwd whose bf16 copy also leaves as e4m3 bytes q8 [M, ldq >= C rounded up to 128] + fp32 row scales q_scale [M]: the A operand of
+// an fp8 dgrad (cs_gemm_nt_f8), bit-identical to cs_quant_rows_fp8(dx_copy)
+extern "C" int cs_layernorm_bwd_q8(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
+                                   const float* rstd, void* dx, int dx_mode, long lddx, float* dgamma, float* dbeta,
+                                   int accumulate_params, void* workspace, void* dx_copy, long ldcopy, float* copy_colsum, void* q8, long ldq,
+                                   float* q_scale, int M, int C, hipStream_t stream) {
+    CS_CHECK_ARG(q8 != nullptr, "cs_layernorm_bwd_q8: q8 is required (cs_layernorm_bwd is the form without it)");
+    return layernorm_bwd_impl(dy, lddy, x, x_dtype, ldx, gamma, mean, rstd, dx, dx_mode, lddx, dgamma, dbeta, accumulate_params, workspace,
+                              dx_copy, ldcopy, copy_colsum, q8, ldq, q_scale, M, C, stream);
 }
 
 extern "C" int cs_l2norm_fwd(const float* x, float* y, float* inv_norm, int M, int C, float eps, hipStream_t stream) {

@@ -735,10 +735,12 @@ class EvaEngine:
         self.ops.transpose_bf16(X, Xt)
         return Xt
 
-    def _block_bwd(self, i, s, g, gb, B, N, cos, sin, ws, next_bias=None):
+    def _block_bwd(self, i, s, g, gb, B, N, cos, sin, ws, next_bias=None, gq=None):
         """g: fp32 [M,C] gradient w.r.t. the block output; updated in place to the gradient w.r.t. its input.  gb: its bf16 copy, already
         summed into this block's w3 bias gradient by the LayerNorm backward that produced it (the final norm's, or norm1's of block i+1);
-        on return gb is the copy of the new g and its column sums have gone to `next_bias` (block i-1's w3 bias gradient, or None)."""
+        on return gb is the copy of the new g and its column sums have gone to `next_bias` (block i-1's w3 bias gradient, or None).
+        gq (fp8_dgrad): (e4m3 codes, row scales) of gb, written by the same LayerNorm backwards (cs_layernorm_bwd_q8)."""
+        q8a = dict(q8=gq[0], q_scale=gq[1]) if gq is not None else {}
         ops, cfg = self.ops, self.cfg
         C, Hd, Hl, H = cfg.width, self.Hp, cfg.hidden, cfg.heads
         padded = Hd != Hl
@@ -748,7 +750,7 @@ class EvaEngine:
         # ---- MLP: x2 = x1 + w3(ffn_ln(silu(x1')*x2')) ------------------------------------------
         self._wgrad(gb, s["fln"], self.storage_of(self.grad, b + "mlp.w3.weight"))
         d_fln = ops.empty((M, Hd), BF16)
-        self._dgrad(i, "w3", gb, d_fln)                                                     # [M,C] . W3[C,Hd]
+        self._dgrad(i, "w3", gb, d_fln, q=gq)                                               # [M,C] . W3[C,Hd]
         d_hid = (ops.zeros if padded else ops.empty)((M, Hd), BF16)
         ops.layernorm_bwd(d_fln[:, :Hl], s["hid"][:, :Hl], self.p[b + "mlp.ffn_ln.weight"], *s["st4"], d_hid[:, :Hl], DX_BF16,
                           G[b + "mlp.ffn_ln.weight"], G[b + "mlp.ffn_ln.bias"], True, ws[0])
@@ -767,11 +769,11 @@ class EvaEngine:
         self._dgrad(i, "w12", d_x12, d_ln2, q=q12)                                          # [M,2Hd] . W12[2Hd,C]
         # norm2's backward adds into the stream gradient and hands back its bf16 copy + column sums (= the proj bias gradient)
         ops.layernorm_bwd(d_ln2, s["x1"], self.p[b + "norm2.weight"], *s["st3"], g, DX_F32_ACCUM,
-                          G[b + "norm2.weight"], G[b + "norm2.bias"], True, ws[0], dx_copy=gb, copy_colsum=G[b + "attn.proj.bias"])
+                          G[b + "norm2.weight"], G[b + "norm2.bias"], True, ws[0], dx_copy=gb, copy_colsum=G[b + "attn.proj.bias"], **q8a)
         # ---- attention branch: x1 = x0 + proj(inner_ln(att)) -------------------------------------
         self._wgrad(gb, s["iln"], G[b + "attn.proj.weight"])
         d_iln = ops.empty((M, C), BF16)
-        self._dgrad(i, "proj", gb, d_iln)
+        self._dgrad(i, "proj", gb, d_iln, q=gq)
         d_att = ops.empty((M, C), BF16)
         ops.layernorm_bwd(d_iln, s["att"], self.p[b + "attn.inner_attn_ln.weight"], *s["st2"], d_att, DX_BF16,
                           G[b + "attn.inner_attn_ln.weight"], G[b + "attn.inner_attn_ln.bias"], True, ws[0])
@@ -793,7 +795,7 @@ class EvaEngine:
             self._dgrad(i, "qkv", d_att, d_ln1, cols=(2 * C, 3 * C))
         ops.layernorm_bwd(d_ln1, s["x0"], self.p[b + "norm1.weight"], *s["st1"], g, DX_F32_ACCUM,
                           G[b + "norm1.weight"], G[b + "norm1.bias"], True, ws[0], dx_copy=gb if next_bias is not None else None,
-                          copy_colsum=next_bias)
+                          copy_colsum=next_bias, **(q8a if next_bias is not None else {}))
 
     def backward_dense(self, d_dense):
         """d_dense: fp32 [B, N, E] gradient w.r.t. the normalised token map (CLS rows zero).  Accumulates every
@@ -811,6 +813,8 @@ class EvaEngine:
         ops.gemm_nt(d_feats, self.wt["head"][:, :E], d_lnf, epi=EPI_BF16)                  # dgrad through the head
         g = ops.empty((M, C), F32)
         gb = ops.empty((M, C), BF16)                  # bf16 copy of g, written by the LayerNorm backwards that update g
+        gq = (ops.empty((M, _round_up(C, 128)), torch.uint8), ops.empty((M,), F32)) if self.fp8_dgrad and C <= 3072 else None
+        q8a = dict(q8=gq[0], q_scale=gq[1]) if gq is not None else {}
         ws_bytes = max(ops.layernorm_bwd_workspace(M, max(C, self.Hp)), ops.attn_bwd_workspace(B, N, cfg.heads))
         ws = (ops.empty((ws_bytes,), torch.uint8), ops.empty((max(ops.colsum_workspace(M, max(2 * self.Hp, 3 * C)), 4),), torch.uint8))
         L, first = cfg.layers, self.first_trainable
@@ -821,14 +825,14 @@ class EvaEngine:
             ops.colsum_bf16(d_feats, self.g[P + "head.bias"], ws[1])
             self._wgrad(d_feats, c["lnf"], self.g[P + "head.weight"])
             ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "norm.weight"], *c["stf"], g, DX_F32_ASSIGN,
-                              self.g[P + "norm.weight"], self.g[P + "norm.bias"], True, ws[0], dx_copy=gb, copy_colsum=w3_bias(L - 1))
+                              self.g[P + "norm.weight"], self.g[P + "norm.bias"], True, ws[0], dx_copy=gb, copy_colsum=w3_bias(L - 1), **q8a)
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook("head")
         else:                                                                                   # head and final norm frozen
             ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "norm.weight"], *c["stf"], g, DX_F32_ASSIGN, None, None, True, ws[0],
-                              dx_copy=gb if first < L else None, copy_colsum=w3_bias(L - 1))
+                              dx_copy=gb if first < L else None, copy_colsum=w3_bias(L - 1), **(q8a if first < L else {}))
         for i in range(L - 1, first - 1, -1):
-            self._block_bwd(i, c["saves"].pop(i), g, gb, B, N, c["cos"], c["sin"], ws, next_bias=w3_bias(i - 1) if i > 0 else None)
+            self._block_bwd(i, c["saves"].pop(i), g, gb, B, N, c["cos"], c["sin"], ws, next_bias=w3_bias(i - 1) if i > 0 else None, gq=gq)
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook(i)
         if self.train_all:

@@ -44,6 +44,7 @@ SIGNATURES = {
     "cs_layernorm_fwd_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _i, _f, _vp]),
     "cs_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "cs_layernorm_bwd": (_i, [_vp, _l, _vp, _i, _l, _vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _vp, _l, _vp, _i, _i, _vp]),
+    "cs_layernorm_bwd_q8": (_i, [_vp, _l, _vp, _i, _l, _vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _i, _vp, _vp, _l, _vp, _vp, _l, _vp, _i, _i, _vp]),
     "cs_l2norm_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "cs_l2norm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "cs_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
@@ -314,9 +315,24 @@ class HipOps:
     def layernorm_bwd_workspace(self, M, C) -> int:
         return int(self.lib.cs_layernorm_bwd_workspace(M, C))
 
+    def layernorm_bwd_q8(self, dy, x, gamma, mean, rstd, dx, dx_mode, dgamma, dbeta, accumulate, workspace, dx_copy, copy_colsum, q8, q_scale):
+        """layernorm_bwd whose bf16 copy also leaves as e4m3 bytes q8 [M, >= C rounded up to 128] + fp32 row scales (= quant_rows_fp8(dx_copy))."""
+        self._chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, dx_copy, copy_colsum, q8, q_scale)
+        M, C = x.shape
+        assert dx_copy is not None and dx_copy.dtype == torch.bfloat16 and dx_copy.shape == (M, C) and dx_copy.stride(1) == 1
+        assert q8.element_size() == 1 and q8.stride(1) == 1 and q8.shape[1] >= (C + 127) // 128 * 128 and q_scale is not None
+        self._ok(self.lib.cs_layernorm_bwd_q8(_p(dy), dy.stride(0), _p(x), _dt(x), x.stride(0), _p(gamma), _p(mean), _p(rstd),
+                                              _p(dx), dx_mode, dx.stride(0), _p(dgamma), _p(dbeta), int(accumulate),
+                                              _p(workspace), _p(dx_copy), dx_copy.stride(0), _p(copy_colsum), _p(q8), q8.stride(0), _p(q_scale),
+                                              M, C, self._stream()), "cs_layernorm_bwd_q8")
+
     def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dx_mode, dgamma=None, dbeta=None, accumulate=False, workspace=None,
-                      dx_copy=None, copy_colsum=None):
-        """dx_copy (fp32 dx modes): bf16 copy of the updated dx rows; copy_colsum [C]: (+)= its column sums (a bias gradient)."""
+                      dx_copy=None, copy_colsum=None, q8=None, q_scale=None):
+        """dx_copy (fp32 dx modes): bf16 copy of the updated dx rows; copy_colsum [C]: (+)= its column sums (a bias gradient);
+        q8 / q_scale: the e4m3 copy of dx_copy as well (layernorm_bwd_q8)."""
+        if q8 is not None:
+            return self.layernorm_bwd_q8(dy, x, gamma, mean, rstd, dx, dx_mode, dgamma, dbeta, accumulate, workspace, dx_copy, copy_colsum,
+                                         q8, q_scale)
         self._chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, dx_copy, copy_colsum)
         M, C = x.shape
         if dx_copy is not None:

@@ -114,6 +114,12 @@ size_t cs_layernorm_bwd_workspace(int M, int C);
 int cs_layernorm_bwd(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
                      const float* rstd, void* dx, int dx_mode, long lddx, float* dgamma, float* dbeta, int accumulate_params,
                      void* workspace, void* dx_copy, long ldcopy, float* copy_colsum, int M, int C, cs_stream_t stream);
+/* cs_layernorm_bwd whose bf16 copy also leaves as e4m3 bytes (q8 [M, ldq >= C rounded up to 128], zero padding) + fp32 row scales: the A operand
+   of an fp8 dgrad through cs_gemm_nt_f8; bit-identical to cs_quant_rows_fp8(dx_copy).  dx_copy required. */
+int cs_layernorm_bwd_q8(const void* dy, long lddy, const void* x, int x_dtype, long ldx, const float* gamma, const float* mean,
+                        const float* rstd, void* dx, int dx_mode, long lddx, float* dgamma, float* dbeta, int accumulate_params,
+                        void* workspace, void* dx_copy, long ldcopy, float* copy_colsum, void* q8, long ldq, float* q_scale, int M, int C,
+                        cs_stream_t stream);
 
 /* --- F.normalize(x, dim=-1) of the dense token map: eva_vit_model.py:620 (eps 1e-12) and its backward. */
 int cs_l2norm_fwd(const float* x, float* y, float* inv_norm, int M, int C, float eps, cs_stream_t stream);

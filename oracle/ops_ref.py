@@ -247,8 +247,16 @@ class RefOps:
     def layernorm_bwd_workspace(self, M, C):
         return 4
 
+    def layernorm_bwd_q8(self, dy, x, gamma, mean, rstd, dx, dx_mode, dgamma, dbeta, accumulate, workspace, dx_copy, copy_colsum, q8, q_scale):
+        self.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dx_mode, dgamma, dbeta, accumulate, workspace, dx_copy, copy_colsum)
+        C = x.shape[1]
+        self.quant_rows_fp8(dx_copy, q8[:, :(C + 127) // 128 * 128], q_scale)
+
     def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dx_mode, dgamma=None, dbeta=None, accumulate=False, workspace=None,
-                      dx_copy=None, copy_colsum=None):
+                      dx_copy=None, copy_colsum=None, q8=None, q_scale=None):
+        if q8 is not None:
+            return self.layernorm_bwd_q8(dy, x, gamma, mean, rstd, dx, dx_mode, dgamma, dbeta, accumulate, workspace, dx_copy, copy_colsum,
+                                         q8, q_scale)
         xh = (x.float() - mean[:, None]) * rstd[:, None]
         g = dy.float()
         gy = g * gamma

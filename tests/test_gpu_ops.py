@@ -808,6 +808,35 @@ def test_fp8_quantisation_and_gemm(hip, ref, M, N, K, epi):
     assert float((got - exact).norm() / exact.norm()) < 6e-2
 
 
+@pytest.mark.parametrize("C,mode", [(768, 2), (1024, 1), (64, 2), (2048, 2)])
+def test_layernorm_backward_with_fused_fp8_quantiser(hip, ref, C, mode):
+    """cs_layernorm_bwd_q8: dx, the bf16 copy, its column sums and the parameter gradients unchanged; the copy's e4m3 codes + row scales are
+    bit-identical to cs_quant_rows_fp8 applied to the copy afterwards."""
+    M = 517
+    x, dy = rnd((M, C), F32, 2.0, seed=80), rnd((M, C), BF, 0.3, seed=81)
+    gamma = 1 + rnd((C,), F32, 0.2, seed=82)
+    dy[11] = 0
+    mean = x.mean(-1)
+    rstd = torch.rsqrt(x.var(-1, unbiased=False) + 1e-6)
+    xd, dyd, gd, md, rd = both([x, dy, gamma, mean, rstd])
+    ws = torch.empty(hip.layernorm_bwd_workspace(M, C), dtype=torch.uint8, device="cuda")
+    Kp = (C + 127) // 128 * 128
+    outs = []
+    for fused in (False, True):
+        dx = torch.full((M, C), 0.25, device="cuda")
+        dx[11] = 0
+        cp, cs = torch.empty(M, C, dtype=BF, device="cuda"), torch.zeros(C, device="cuda")
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        q, sc = torch.full((M, Kp), 0x55, dtype=torch.uint8, device="cuda"), torch.empty(M, device="cuda")
+        kw = dict(q8=q, q_scale=sc) if fused else {}
+        hip.layernorm_bwd(dyd, xd, gd, md, rd, dx, mode, dg, db, True, ws, dx_copy=cp, copy_colsum=cs, **kw)
+        if not fused:
+            hip.quant_rows_fp8(cp, q, sc)
+        outs.append((dx, cp, cs, dg, db, q, sc))
+    for a, b, name in zip(outs[0], outs[1], ("dx", "copy", "colsum", "dgamma", "dbeta", "codes", "scales")):
+        assert torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("Hd,M", [(2048, 333), (2752, 129), (64, 5), (4096, 17)])
 def test_swiglu_backward_with_fused_fp8_quantiser(hip, ref, Hd, M):
     """cs_swiglu_bwd_q8: dx12 unchanged, and its e4m3 copy + row scales are bit-identical to cs_quant_rows_fp8 applied to dx12 afterwards."""
