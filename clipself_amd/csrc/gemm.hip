@@ -648,8 +648,10 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
         return best;
     };
     double c1, c2, c3;
-    // measured microseconds per K tile of one resident workgroup set (r01 profiles): 256x256 2.2, 256x128 1.4, 2 x 128x128 1.9
-    const int sp[4] = {0, best_split(128, 128, 2, 1.9, c1), best_split(256, 128, 1, 1.4, c2), best_split(256, 256, 1, 2.2, c3)};
+    // measured microseconds per K tile of one resident workgroup set: 256x256 1.4 (the streaming kernel: 1.3-1.45 on M = 18 464 / 12 608 rows,
+    // round 3), 256x128 0.95, 2 x 128x128 1.3.  Round 1's figures (2.2 / 1.4 / 1.9) sent the N = 1024, K = 3072 / 5504 dgrads of the L/14
+    // student to the 256x128 kernel: 297 / 145 us against 232 / 132 us on the streaming kernel.
+    const int sp[4] = {0, best_split(128, 128, 2, 1.3, c1), best_split(256, 128, 1, 0.95, c2), best_split(256, 256, 1, 1.4, c3)};
     int cfg = force_cfg;
     if (cfg == 0) {
         if (a.M < 256 || ncols < 256) c3 = 1e30;
