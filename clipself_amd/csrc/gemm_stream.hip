@@ -13,6 +13,10 @@
 //   * The operand ring runs CONTINUOUSLY across output tiles: K tile g of the workgroup's tile sequence lives in A slot g % 3 /
 //     B slot g & 1, and iteration g issues B(g+1) and A(g+2) whatever tile they belong to, so the first operands of the next output
 //     tile are in flight two K tiles before the current tile's epilogue and there is no per-tile prologue, no extra barrier.
+//   * The K step is ONE basic block with a fixed issue order (round 3): the eight DMA pieces are issued unconditionally (past its last tile
+//     a cursor keeps cycling over that tile's K tiles: valid memory, slots nobody reads), the cursor advance sits behind the MFMAs, and the
+//     six ds_read_b128 of k-step ks+1 go one behind each of the first six MFMAs of k-step ks (two fragment register sets,
+//     sched_group_barrier); left to itself hipcc clusters reads and MFMAs into runs of 2-4 with lgkmcnt(0) between them.
 //   * The epilogue's stores are never waited for: vmcnt retires in order on gfx9, so the first K tile after an epilogue waits
 //     vmcnt(4 + S) with S = the fixed number of store instructions an epilogue issues (buffer stores with out-of-range offsets for
 //     masked rows / columns keep that count exact).
