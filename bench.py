@@ -342,7 +342,7 @@ def main():
         step += 1
     sync()
     if distributed:
-        model.reset_stats()
+        model.collect_stats(True)               # per-bucket issue -> completion events and the exposed wait, for the timed steps only
     timer.on = True
     t0 = time.perf_counter()
     last = None

@@ -167,6 +167,9 @@ class EvaEngine:
         # wgrad (contraction over tokens: per-row scales do not factor out) stays bf16
         self.fp8_dgrad = False
         self.wt8 = {}
+        # (leading blocks, CUs): encode_image()'s persistent GEMMs leave that many compute units free in its first blocks -- set by
+        # CLIPSelf.prefetch_teacher in data-parallel runs, where those blocks run beside the student's gradient all-reduce
+        self.rccl_window = (0, 0)
         self.wgrad_tn = True                   # weight gradients from the token-major operands (no transposed copies) where the shape allows
         if trainable:
             self.grad = ops.zeros((self.numel,), F32)
@@ -650,11 +653,16 @@ class EvaEngine:
             folded = self.fold_sub_ln and self.fold_block_ln
             lo = ops.empty((B * N, cfg.width), torch.int16) if folded and self.split_stream and last > 0 else None
             cls_folded = folded and last < cfg.layers and last > 0          # the CLS-only block takes the planes + statistics as they are
+            win, cus = self.rccl_window if hasattr(ops, "reserve_compute_units") else (0, 0)
             for i in range(last):
+                if win and k0 == 0 and i in (0, win):
+                    ops.reserve_compute_units(cus if i < win else 0)
                 if folded:
                     xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last or cls_folded, lo=lo)
                 else:
                     self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
+            if win and k0 == 0:
+                ops.reserve_compute_units(0)
             if last < cfg.layers:
                 xc = self._block_fwd_cls(last, xf, B, N, cos, sin, xb if cls_folded else None, st, lo)
             else:

@@ -77,7 +77,10 @@ class CLIPSelf:
         device = torch.device(device)
         if device.type != "cuda":
             return
+        window = (0, 0)
         if distributed:
+            # the first blocks of a prefetched pass run beside the student's gradient buckets: their GEMMs leave RCCL's CUs free
+            window = getattr(dist_model, "prefetch_window", (0, 0))
             dist_model = dist_model.module
         _, normed_boxes, image_crops = batch
         boxes_d = normed_boxes.to(device=device, dtype=torch.float32, non_blocking=True)
@@ -90,8 +93,15 @@ class CLIPSelf:
             self._side = torch.cuda.Stream(device=device, priority=0 if distributed else -1)
         side = self._side
         side.wait_stream(main)
+        eng = getattr(getattr(dist_model, "visual", None), "engine", None)
         with torch.cuda.stream(side), torch.no_grad():
-            feats = dist_model.encode_image(crops, normalize=False)
+            if eng is not None:
+                eng.rccl_window = window
+            try:
+                feats = dist_model.encode_image(crops, normalize=False)
+            finally:
+                if eng is not None:
+                    eng.rccl_window = (0, 0)
         crops.record_stream(side)
         self._pending = (image_crops, feats, side)
 

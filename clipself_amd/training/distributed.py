@@ -75,16 +75,26 @@ def all_gather_object(args, obj, dst=0):
 
 
 def rccl_reserved_cus() -> int:
-    """Compute units the persistent GEMM kernels leave free in data-parallel runs (CLIPSELF_RCCL_CUS, default 16 of 256).  The GEMMs
-    of the step are persistent kernels that own every CU they are launched on for milliseconds; RCCL's ring kernels (a few
+    """Compute units the persistent GEMM kernels leave free while gradient buckets are in flight (CLIPSELF_RCCL_CUS, default 16 of 256).
+    The GEMMs of the step are persistent kernels that own every CU they are launched on for milliseconds; RCCL's ring kernels (a few
     workgroups per channel) need somewhere to run beside them if the gradient all-reduce is to overlap with backward."""
     return max(0, min(64, int(os.environ.get("CLIPSELF_RCCL_CUS", "16"))))
 
 
-def _reserve_for_collectives(module):
-    ops = getattr(getattr(getattr(module, "visual", None), "engine", None), "ops", None)
-    if ops is not None and hasattr(ops, "reserve_compute_units") and (dist.get_world_size() > 1 or os.environ.get("CLIPSELF_FORCE_DIST") == "1"):
-        ops.reserve_compute_units(rccl_reserved_cus())
+def rccl_teacher_window() -> int:
+    """Leading blocks of a PREFETCHED teacher pass whose GEMMs leave the reserved CUs free (CLIPSELF_RCCL_TEACHER_BLOCKS, default 3).  The
+    teacher's pass over the next batch starts on the side stream when the student's backward does, so its first blocks run beside the
+    gradient buckets (B/16: 12 buckets over an ~11 ms backward, one teacher block = ~6.5 ms); the later blocks and an inline teacher pass
+    run while nothing is in flight and keep all 256 CUs."""
+    return max(0, int(os.environ.get("CLIPSELF_RCCL_TEACHER_BLOCKS", "3")))
+
+
+def _data_parallel_active() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("CLIPSELF_FORCE_DIST") == "1")
+
+
+def _ops_of(module):
+    return getattr(getattr(getattr(module, "visual", None), "engine", None), "ops", None)
 
 
 def grad_bucket_dtype() -> torch.dtype:
@@ -101,9 +111,13 @@ class StudentDataParallel(torch.nn.Module):
     """`.module`-carrying wrapper (the reference's methods unwrap it: clipself.py:8-10) that (1) broadcasts rank 0's
     parameters once and (2) arms the engine's per-block grad-ready hook with asynchronous bucket all-reduces.
 
-    `stats` counts what a step exchanged (buckets, bytes on the wire per rank) and how long the optimizer had to wait for the outstanding
-    buckets (`finish_grad_sync`: device events around the waits on a GPU, wall clock on CPU) -- bench.py prints them, so that a scaling
-    number can be read against its communication volume and exposed wait."""
+    The student's persistent GEMMs give up `rccl_reserved_cus()` compute units only between the first bucket of a step and
+    `finish_grad_sync` -- the window in which RCCL's kernels have something to do; the student forward keeps the whole chip.
+
+    `collect_stats(True)` (bench.py; off in training runs, where nothing would drain them) records what a step exchanged: buckets, bytes
+    on the wire per rank, the time the optimizer stood behind unfinished buckets (`finish_grad_sync`), and per bucket the time from its
+    issue (the block's backward done on the compute stream) to its completion on the collective's stream -- device events on a GPU, wall
+    clock on CPU -- so that a scaling number can be read against its communication volume without a profiler."""
 
     def __init__(self, module, process_group=None, bucket_dtype=None):
         super().__init__()
@@ -116,13 +130,23 @@ class StudentDataParallel(torch.nn.Module):
         with torch.no_grad():
             dist.broadcast(module.logit_scale.data, src=0, group=process_group)
         eng.sync_shadow()
-        _reserve_for_collectives(module)
+        self._reserve = rccl_reserved_cus() if _data_parallel_active() else 0
         self._pending = []
         self._wire = None                      # bf16 staging buffer of the flat gradient (bucket_dtype == bf16)
-        self.stats = dict(steps=0, buckets=0, bytes=0, wait_ms=0.0)
-        self._wait_events = []
+        self._collect = False
+        self._observer = None                  # side stream that waits for each bucket's completion (statistics only)
+        self.reset_stats()
         if eng.trainable:
             eng.grad_ready_hook = self._on_block_ready
+
+    def collect_stats(self, on: bool = True):
+        self._collect = bool(on)
+        self.reset_stats()
+
+    def _set_reserve(self, n):
+        ops = _ops_of(self.module)
+        if ops is not None and hasattr(ops, "reserve_compute_units"):
+            ops.reserve_compute_units(n)
 
     def _on_block_ready(self, block):
         eng = self.module.visual.engine
@@ -138,62 +162,101 @@ class StudentDataParallel(torch.nn.Module):
                 eng.ops.cast_f32_bf16(g, buf)
             else:
                 buf.copy_(g)
+        if not self._pending and self._reserve:
+            self._set_reserve(self._reserve)               # first bucket of the step: the remaining backward GEMMs leave room for RCCL
+        mark = None
+        if self._collect:
+            if g.is_cuda:
+                mark = torch.cuda.Event(enable_timing=True)
+                mark.record()
+            else:
+                import time
+                mark = time.perf_counter()
         work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((work, lo, hi))
+        done = None
+        if self._collect and g.is_cuda:
+            if self._observer is None:
+                self._observer = torch.cuda.Stream(device=g.device)
+            with torch.cuda.stream(self._observer):
+                work.wait()                                # the OBSERVER stream waits for this bucket; the compute stream does not
+                done = torch.cuda.Event(enable_timing=True)
+                done.record()
+        self._pending.append((work, lo, hi, str(block), mark, done))
         self.stats["buckets"] += 1
         self.stats["bytes"] += buf.numel() * buf.element_size()
 
     def finish_grad_sync(self):
         """Make the current stream wait for every outstanding bucket (call before the optimizer step)."""
+        import time
         eng = self.module.visual.engine
         on_gpu = eng.grad.is_cuda
-        if on_gpu:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        else:
-            import time
-            t0 = time.perf_counter()
-        for work, lo, hi in self._pending:
+        ev = None
+        if self._collect:
+            if on_gpu:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            else:
+                t0 = time.perf_counter()
+        for work, lo, hi, name, mark, done in self._pending:
             work.wait()
             if self.bucket_dtype != torch.float32:
                 eng.grad[lo:hi].copy_(self._wire[lo:hi])          # back to the fp32 accumulator AdamW reads
+            if self._collect:
+                if on_gpu:
+                    self._bucket_events.append((name, mark, done))
+                else:
+                    self.stats["bucket_ms"].setdefault(name, []).append(1e3 * (time.perf_counter() - mark))
         self._pending.clear()
-        if on_gpu:
-            e1.record()
-            self._wait_events.append((e0, e1))
-        else:
-            self.stats["wait_ms"] += 1e3 * (time.perf_counter() - t0)
+        if self._reserve:
+            self._set_reserve(0)                           # nothing in flight any more: AdamW's successors get the whole chip back
+        if self._collect:
+            if on_gpu:
+                ev[1].record()
+                self._wait_events.append(ev)
+            else:
+                self.stats["wait_ms"] += 1e3 * (time.perf_counter() - t0)
         self.stats["steps"] += 1
 
     def reset_stats(self):
-        self.stats = dict(steps=0, buckets=0, bytes=0, wait_ms=0.0)
+        self.stats = dict(steps=0, buckets=0, bytes=0, wait_ms=0.0, bucket_ms={})
         self._wait_events = []
+        self._bucket_events = []
 
     def comm_summary(self):
         """Per-step communication figures of this rank since the last reset_stats(): buckets, bytes handed to the all-reduce, exposed wait
-        (the time the stream that runs AdamW stood behind unfinished buckets).  Synchronises the device events."""
-        if self._wait_events:
+        (the time the stream that runs AdamW stood behind unfinished buckets) and -- with collect_stats(True) -- per bucket the mean time from
+        issue to completion.  Synchronises the device events."""
+        if self._wait_events or self._bucket_events:
             torch.cuda.synchronize()
             self.stats["wait_ms"] += sum(a.elapsed_time(b) for a, b in self._wait_events)
-            self._wait_events = []
+            for name, mark, done in self._bucket_events:
+                self.stats["bucket_ms"].setdefault(name, []).append(mark.elapsed_time(done))
+            self._wait_events, self._bucket_events = [], []
         n = max(self.stats["steps"], 1)
-        return dict(allreduce_buckets_per_step=self.stats["buckets"] / n, allreduce_bytes_per_step=self.stats["bytes"] / n,
-                    grad_sync_wait_ms=self.stats["wait_ms"] / n, grad_bucket_dtype="fp32" if self.bucket_dtype == torch.float32 else "bf16",
-                    rccl_reserved_cus=rccl_reserved_cus() if (self.world > 1 or os.environ.get("CLIPSELF_FORCE_DIST") == "1") else 0)
+        out = dict(allreduce_buckets_per_step=self.stats["buckets"] / n, allreduce_bytes_per_step=self.stats["bytes"] / n,
+                   grad_sync_wait_ms=self.stats["wait_ms"] / n, grad_bucket_dtype="fp32" if self.bucket_dtype == torch.float32 else "bf16",
+                   rccl_reserved_cus=self._reserve, rccl_reserved_window="first bucket .. finish_grad_sync"
+                   if self._reserve else "none", stats_collected=self._collect)
+        if self.stats["bucket_ms"]:
+            # issue order = reverse layer order; value = mean ms from "block's backward done" to "all-reduce of its bucket done"
+            out["bucket_issue_to_done_ms"] = {k: round(sum(v) / len(v), 3) for k, v in self.stats["bucket_ms"].items()}
+        return out
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
 
 
 class FrozenDataParallel(torch.nn.Module):
-    """Teacher wrapper: parameters broadcast once, no gradient traffic (main.py:191-192)."""
+    """Teacher wrapper: parameters broadcast once, no gradient traffic (main.py:191-192).  A teacher pass that is PREFETCHED beside the
+    student's backward leaves the reserved CUs free in its first `rccl_teacher_window()` blocks (engine.rccl_window, applied by
+    CLIPSelf.prefetch_teacher); an inline pass runs while no bucket is in flight and reserves nothing."""
 
     def __init__(self, module, process_group=None):
         super().__init__()
         self.module = module
         dist.broadcast(module.visual.engine.master, src=0, group=process_group)
         module.visual.engine.sync_shadow()
-        _reserve_for_collectives(module)
+        self.prefetch_window = (rccl_teacher_window(), rccl_reserved_cus()) if _data_parallel_active() else (0, 0)
 
     def forward(self, *a, **k):
         return self.module(*a, **k)

@@ -64,11 +64,16 @@ def _worker(rank, world, port, out_dir, device, family="eva02", clip=None, bucke
     if lock:
         student.lock_image_tower(unlocked_groups=cfg.layers)
     model, dist_model = StudentDataParallel(student), FrozenDataParallel(teacher)
+    # the CU reservation of the persistent GEMMs is a HipOps feature; record what the wrapper asks for, and when
+    reserve_log = []
+    student.visual.engine.ops.reserve_compute_units = lambda n: reserve_log.append((n, len(model._pending)))
+    model.collect_stats(True)
     opt = FlatAdamW(student, lr=1e-3, weight_decay=0.1, grad_divisor=float(world))
     batch = synthetic_batch(2, 3, cfg.image_size, cfg.image_size, seed=40 + rank)
     train_step(model, CLIPSelf(), batch, opt, None, 0, dist_model, _args(True, device, clip))
     eng = student.visual.engine
     torch.save({"grad": eng.grad.cpu().clone(), "master": eng.master.cpu().clone(), "comm": model.comm_summary(),
+                "reserve_log": reserve_log, "window": dist_model.prefetch_window,
                 "bucket_elems": sum(hi - lo for lo, hi in eng.block_ranges[eng.first_trainable:])
                 + (sum(hi - lo for lo, hi in (eng.stem_range, eng.head_range)) if eng.train_all else 0)},
                os.path.join(out_dir, f"rank{rank}.pt"))
@@ -87,7 +92,15 @@ def run_two_rank_equivalence(device, tmp_path, tol, family="eva02", clip=None, b
     cfg0 = _cfg(family)
     assert comm["allreduce_buckets_per_step"] == cfg0.layers + (0 if lock else 2) and comm["grad_bucket_dtype"] == bucket     # + head, stem
     assert comm["allreduce_bytes_per_step"] == r0["bucket_elems"] * (4 if bucket == "fp32" else 2)
-    assert comm["grad_sync_wait_ms"] >= 0.0 and comm["rccl_reserved_cus"] == 16
+    assert comm["grad_sync_wait_ms"] >= 0.0 and comm["rccl_reserved_cus"] == 16 and comm["stats_collected"]
+    # per-bucket issue -> completion times, in issue order (reverse layer order; "head" first and "stem" last for an unlocked tower)
+    names = list(comm["bucket_issue_to_done_ms"])
+    assert names == ([] if lock else ["head"]) + [str(i) for i in range(cfg0.layers - 1, -1, -1)] + ([] if lock else ["stem"]), names
+    assert all(v >= 0.0 for v in comm["bucket_issue_to_done_ms"].values())
+    # CUs are withheld from the persistent GEMMs only while buckets are in flight: reserved when the first bucket of the step is issued
+    # (nothing pending yet), given back by finish_grad_sync (nothing pending any more)
+    assert r0["reserve_log"] == [(16, 0), (0, 0)], r0["reserve_log"]
+    assert tuple(r0["window"]) == (3, 16)
 
     from clipself_amd.init import synthetic_batch
     from clipself_amd.training.clipself import CLIPSelf
@@ -143,3 +156,31 @@ def test_two_rank_unlocked_tower(tmp_path):
     """Training without --lock-image under data parallel: the stem and head slices of the flat gradient travel as two more buckets
     ("head" is ready first, "stem" last) and the step still equals one process on the union batch."""
     run_two_rank_equivalence("cpu", tmp_path, 1e-3, lock=False)
+
+
+def test_stats_are_not_collected_unless_asked(tmp_path):
+    """A training run (training/main.py) never drains the wrapper's statistics, so without collect_stats(True) no timing event or
+    per-bucket record may be kept from one step to the next (two live device events per step, forever)."""
+    world, port = 1, _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", CLIPSELF_FORCE_DIST="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from clipself_amd.init import synthetic_batch
+        from clipself_amd.training.clipself import CLIPSelf
+        from clipself_amd.training.distributed import FrozenDataParallel, StudentDataParallel
+        from clipself_amd.training.optim import FlatAdamW
+        from clipself_amd.training.train import train_step
+        cfg = _cfg("eva02")
+        student, teacher, seeded = _build(cfg, "cpu")
+        student.lock_image_tower(unlocked_groups=cfg.layers)
+        model, dist_model = StudentDataParallel(student), FrozenDataParallel(teacher)
+        opt = FlatAdamW(student, lr=1e-3, weight_decay=0.1)
+        batch = synthetic_batch(2, 3, cfg.image_size, cfg.image_size, seed=40)
+        for step in range(3):
+            train_step(model, CLIPSelf(), batch, opt, None, step, dist_model, _args(True, "cpu"))
+            assert model._wait_events == [] and model._bucket_events == [] and model.stats["bucket_ms"] == {} and not model._pending
+        comm = model.comm_summary()
+        assert comm["allreduce_buckets_per_step"] == cfg.layers and not comm["stats_collected"] and "bucket_issue_to_done_ms" not in comm
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("CLIPSELF_FORCE_DIST", None)

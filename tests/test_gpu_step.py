@@ -339,6 +339,9 @@ def test_bench_rccl_single_rank_path():
     assert "data_parallel" not in b
     assert dp["allreduce_buckets_per_step"] == 12 and dp["grad_bucket_dtype"] == "fp32" and dp["ranks_seen"] == 1
     assert 3.3e8 < dp["allreduce_bytes_per_step"] < 3.5e8 and dp["grad_sync_wait_ms"] >= 0.0 and dp["rccl_reserved_cus"] == 16
+    # per-bucket issue -> completion (device events on an observer stream), reverse layer order, and the window the CUs are withheld in
+    assert list(dp["bucket_issue_to_done_ms"]) == [str(i) for i in range(11, -1, -1)] and all(v >= 0 for v in dp["bucket_issue_to_done_ms"].values())
+    assert dp["stats_collected"] and dp["rccl_reserved_window"].startswith("first bucket")
 
 
 def test_teacher_prefetch_on_side_stream_equals_inline():
