@@ -98,15 +98,16 @@ __device__ float axis_weight_at(float start, float extent, int grid, int size, i
 // box order, what every box of that image sends to them:  dfeat[b, r, c, :] += sum_k Wy_k[r] Wx_k[c] dpooled[k, :] / count_k.
 // No atomics, a fixed summation order -> the gradient is bit-reproducible (torchvision's backward, and round 2's scatter kernel, add with
 // float atomics in arrival order: 2.8e-4 relative run-to-run differences on the step's gradients).
-constexpr int RB_CELLS = 16, RB_EPT = 4;          // cells per workgroup; channels per thread (E <= 256 * RB_EPT)
+constexpr int RB_CELLS = 16, RB_EPT = 4;          // cells per workgroup; channels per thread (256 * RB_EPT channels per workgroup, wider maps: more workgroups)
 __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(const float* __restrict__ dpooled, const float* __restrict__ rois,
                                                                   float* __restrict__ dfeat, int K, int Ntok, int gh_map, int gw_map, int E,
-                                                                  int tok_off) {
+                                                                  int tok_off, int cell_groups) {
     __shared__ int list[256];
     __shared__ int wave_cnt[4];
     __shared__ float Wxs[RB_CELLS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int c0 = blockIdx.x * RB_CELLS, r = blockIdx.y, b = blockIdx.z;
+    const int cg = blockIdx.x % cell_groups, ch0 = (blockIdx.x / cell_groups) * (256 * RB_EPT);      // cell group, first channel of this workgroup
+    const int c0 = cg * RB_CELLS, r = blockIdx.y, b = blockIdx.z;
     float acc[RB_CELLS][RB_EPT];
 #pragma unroll
     for (int c = 0; c < RB_CELLS; ++c)
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(const float* _
             float gv[RB_EPT];
 #pragma unroll
             for (int j = 0; j < RB_EPT; ++j) {
-                const int ch = tid + 256 * j;
+                const int ch = ch0 + tid + 256 * j;
                 gv[j] = ch < E ? dpooled[(size_t)list[n] * E + ch] * inv_count : 0.f;
             }
 #pragma unroll
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(const float* _
         float* cell = dfeat + ((size_t)b * Ntok + tok_off + (size_t)r * gw_map + min(c0 + c, gw_map - 1)) * E;
 #pragma unroll
         for (int j = 0; j < RB_EPT; ++j) {
-            const int ch = tid + 256 * j;
+            const int ch = ch0 + tid + 256 * j;
             if (c0 + c < gw_map && ch < E && acc[c][j] != 0.f) cell[ch] += acc[c][j];
         }
     }
@@ -234,10 +235,11 @@ extern "C" int cs_roialign_bwd(const float* dpooled, const float* rois, float* d
                                int tok_off, hipStream_t stream) {
     CS_CHECK_ARG(grid_h > 0 && grid_w > 0 && grid_h <= MAXGRID && grid_w <= MAXGRID, "cs_roialign_bwd: bad grid");
     CS_CHECK_ARG(tok_off + grid_h * grid_w <= Ntok, "cs_roialign_bwd: grid does not fit the token map");
-    CS_CHECK_ARG(B > 0 && B <= 65535 && E > 0 && E <= 256 * RB_EPT, "cs_roialign_bwd: B=%d images (1..65535), E=%d channels (<= %d)", B, E, 256 * RB_EPT);
+    CS_CHECK_ARG(B > 0 && B <= 65535 && E > 0, "cs_roialign_bwd: B=%d images (1..65535), E=%d channels", B, E);
     if (K == 0) return 0;
-    hipLaunchKernelGGL(roialign_bwd_gather_kernel, dim3((grid_w + RB_CELLS - 1) / RB_CELLS, grid_h, B), dim3(256), 0, stream, dpooled, rois,
-                       dfeat, K, Ntok, grid_h, grid_w, E, tok_off);
+    const int cell_groups = (grid_w + RB_CELLS - 1) / RB_CELLS, chunks = (E + 256 * RB_EPT - 1) / (256 * RB_EPT);     // E > 1024 (bigG-class heads): channel chunks
+    hipLaunchKernelGGL(roialign_bwd_gather_kernel, dim3(cell_groups * chunks, grid_h, B), dim3(256), 0, stream, dpooled, rois,
+                       dfeat, K, Ntok, grid_h, grid_w, E, tok_off, cell_groups);
     CS_LAUNCH_CHECK();
     return 0;
 }

@@ -140,6 +140,7 @@ class EvaEngine:
         self.wt = {}
         self.first_trainable = cfg.layers      # no block trainable until lock()/unlock is applied
         self.train_all = False                 # stem + final norm + head train as well (set_trainable_all: training without --lock-image)
+        self.flags_version = 0                 # bumped whenever the trainable / decay flag bytes are rewritten (_set_flags)
         self.grad_ready_hook = None            # callable(block_index) fired when a block's grads are complete
         self._ctx = None
         self._wgrad_ws = None
@@ -380,7 +381,16 @@ class EvaEngine:
             n64 = _round_up(n, 64)            # a tensor that ends its 64-aligned allocation group short of a flag granule (tiny head.bias)
             assert o % 64 == 0 and (n % 64 == 0 or o + n64 <= nxt), f"{name}: flag granularity"
             self.flags[o // 64:(o + n64) // 64] = 1 | (0 if is_no_decay(name, len(self.logical[name])) else 2)
+        self.flags_version += 1
+        # shadows that only trainable blocks need: drop those of blocks that are frozen now (one bf16 + one e4m3 copy of a block's weights
+        # each), build the missing ones of blocks that train now
+        for key in [k for k in self.wt if isinstance(k, tuple) and k[0] < self.first_trainable]:
+            del self.wt[key]
+        for key in [k for k in self.wt8 if k[0] < self.first_trainable]:
+            del self.wt8[key]
         self.sync_transposed()
+        if self.fp8_forward and self.fp8_dgrad:
+            self.sync_fp8(range(self.first_trainable, self.cfg.layers))
 
     def trainable_names(self):
         if self.train_all:

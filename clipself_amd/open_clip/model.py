@@ -155,10 +155,12 @@ class EVAVisionTower(_Node):
 
     @property
     def _active_cpu(self):
-        key = id(self.engine.flags)
-        if getattr(self, "_active_key", None) != (key, self.engine.first_trainable):
+        # the flag bytes are rewritten in place by every lock() / unlock(): key on the engine's flag version, not on the buffer's identity
+        # (lock(all blocks) and unlock() share first_trainable == 0 but differ in the stem / head flags)
+        key = (id(self.engine.flags), self.engine.flags_version)
+        if getattr(self, "_active_key", None) != key:
             self._active_cache = (self.engine.flags & 1).cpu().numpy()
-            self._active_key = (key, self.engine.first_trainable)
+            self._active_key = key
         return self._active_cache
 
     # ---- forward paths ---------------------------------------------------------------------------------

@@ -171,7 +171,7 @@ int cs_cls_row(float* x, const float* cls, const float* pos, int B, int Ntok, in
 int cs_roialign_fwd(const float* feat, const float* rois, float* pooled, int K, int Ntok, int grid_h, int grid_w, int E,
                     int tok_off, cs_stream_t stream);
 /* backward: dfeat [B, Ntok, E] += the boxes' gradients; a gather per map cell over the image's boxes in ascending box order (no atomics:
- * bit-reproducible, unlike torchvision's atomicAdd scatter); E <= 1024 */
+ * bit-reproducible, unlike torchvision's atomicAdd scatter); any E: 1024 channels per workgroup, wider maps take more workgroups) */
 int cs_roialign_bwd(const float* dpooled, const float* rois, float* dfeat, int K, int B, int Ntok, int grid_h, int grid_w, int E,
                     int tok_off, cs_stream_t stream);
 

@@ -547,7 +547,7 @@ def _boxes(K, B, seed, wild=False):
     return torch.cat([b, xy0, xy1], dim=1)
 
 
-@pytest.mark.parametrize("grid,E", [(14, 512), (4, 64), (24, 768)])
+@pytest.mark.parametrize("grid,E", [(14, 512), (4, 64), (24, 768), (14, 1280)])      # 1280: wider than one workgroup's 1024 channels
 def test_roialign_fwd_bwd(hip, ref, grid, E):
     B, K = 3, 40
     Ntok = grid * grid + 1

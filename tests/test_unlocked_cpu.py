@@ -124,3 +124,36 @@ def test_lock_after_unlock_and_back():
     assert eng.train_all and named["visual.pos_embed"].requires_grad and bool((eng.flags & 1).bool()[o // 64])
     assert eng.bucket_range("stem") == (0, eng.block_ranges[0][0]) and eng.bucket_range("head")[0] == eng.block_ranges[-1][1]
     assert set(eng.trainable_names()) == set(eng.public_names())
+
+
+def test_lock_all_blocks_then_unlock_reattaches_stem_and_head_gradients():
+    """lock(unlocked_groups=L) and unlock() both start training at block 0 but differ in the stem / head flags, which live in a buffer that is
+    rewritten in place: the cached "which parameters does the dense path reach" mask must follow the flag version, or the
+    stem / head parameters never get a .grad attached while the engine's AdamW still updates them.  The transposed / e4m3 shadows that only
+    trainable blocks need follow the lock state as well."""
+    cfg = tiny_cfg()
+    student, teacher = build_pair(cfg, 5)
+    eng = student.visual.engine
+    L = cfg.layers
+    named = dict(student.named_parameters())
+    batch = synthetic_batch(2, 3, cfg.image_size, cfg.image_size, seed=9)
+    opt = FlatAdamW(student, lr=1e-3, weight_decay=0.1)
+
+    student.lock_image_tower(unlocked_groups=L)
+    train_step(student, CLIPSelf(), batch, opt, None, 0, teacher, _args())
+    assert all(named[n].grad is None for n in STEM_HEAD)
+    assert named["visual.blocks.0.mlp.w3.weight"].grad is not None
+
+    student.visual.unlock()
+    train_step(student, CLIPSelf(), batch, opt, None, 1, teacher, _args())
+    for n in STEM_HEAD:
+        assert named[n].grad is not None and float(named[n].grad.abs().sum()) > 0.0, n
+
+    # shadows follow the lock state: frozen blocks drop their W^T copies, re-trained ones get them back
+    student.lock_image_tower(unlocked_groups=1)
+    assert sorted({k[0] for k in eng.wt if isinstance(k, tuple)}) == [L - 1]
+    eng.enable_fp8_forward(True, dgrad=True)
+    assert sorted({k[0] for k in eng.wt8}) == [L - 1]
+    student.lock_image_tower(unlocked_groups=L)
+    assert sorted({k[0] for k in eng.wt if isinstance(k, tuple)}) == list(range(L)) == sorted({k[0] for k in eng.wt8})
+    train_step(student, CLIPSelf(), batch, opt, None, 2, teacher, _args())       # fp8 dgrad of the newly trainable blocks finds its shadows
