@@ -154,6 +154,17 @@ class EvaEngine:
         # ... and, in encode_image(), the block LayerNorms norm1 / norm2 as well: the residual GEMMs also emit a bf16 copy of the new
         # stream and its row statistics, the q|k|v and W1|W2 GEMMs apply the normalisation in their epilogues (_teacher_block_folded)
         self.fold_block_ln = not trainable
+        # Guard of that fold.  The folded norm1 / norm2 contract the UN-centred bf16 row and remove the mean afterwards in fp32
+        # (rstd * (bf16(x) . W gamma - mean * colsum)): the bf16 rounding of x is relative to |x|, not to |x - mean|, so the error of the
+        # normalised row grows like sqrt(1 + (mean / sigma)^2).  Measured against the plain schedule on weights with trained-like statistics
+        # (oracle/stress_weights.py, profiles/r04_parity.md): outlier channels x200 alone -- folded is CLOSER to fp32 than the plain bf16
+        # schedule; |mean| / sigma = 2 -- equal; 3 -- 1.6x; 5 -- 2.8x.  So the first encode_image() after a weight load measures
+        # mean_rows(|row mean| / row sigma) of the stream entering every block on a few crops (block_fold_statistic, one host read-back)
+        # and keeps norm1 / norm2 as LayerNorm kernels when it exceeds block_fold_limit; the sub-LayerNorm folds are never worse than
+        # the plain schedule (their input is a stored bf16 tensor either way) and stay.
+        self.block_fold_guard = not trainable
+        self.block_fold_limit = 2.0
+        self.block_fold_ratio = None           # the measured statistic (None: not measured since the last weight load)
         # ... with the residual stream between those GEMMs held as two 16-bit planes (bf16 view + remainder, exact; cs_gemm_nt_ln_split):
         # 8 instead of 10 bytes of HBM traffic per stream element and residual GEMM
         self.split_stream = not trainable
@@ -222,6 +233,7 @@ class EvaEngine:
         """bf16 MFMA operands from the fp32 masters (after a load; AdamW refreshes them itself each step)."""
         self.ops.cast_f32_bf16(self.master, self.shadow)
         self._pos_cache.clear()
+        self.block_fold_ratio = None
         if self.trainable:
             self.sync_transposed()
         if self.fold_sub_ln:
@@ -645,12 +657,48 @@ class EvaEngine:
         return self._block_post(i, b, xc, att, B, lambda: (None, None), None, True)
 
     # ------------------------------------------------------------------------------------------ teacher
+    def block_fold_statistic(self, images, crops: int = 16):
+        """max over blocks of mean over rows of |row mean| / row sigma of the residual stream entering the block, on the first `crops`
+        images through the plain block schedule.  One-time calibration after a weight load (a few torch reductions and one host read-back,
+        not part of the step)."""
+        with torch.no_grad():
+            img = images[:crops]
+            B = img.shape[0]
+            x, g = self._stem(img)
+            N = g * g + 1
+            cos, sin = self.rope_tables(g)
+            xf = x.view(B * N, self.cfg.width)
+            worst = xf.new_zeros(())
+            for i in range(self.cfg.layers):
+                worst = torch.maximum(worst, (xf.mean(-1).abs() / xf.std(-1).clamp_min(1e-30)).mean())
+                if i + 1 < self.cfg.layers:
+                    self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
+            return float(worst)
+
+    def block_folds_active(self, images=None) -> bool:
+        """Whether encode_image() folds norm1 / norm2 into the q|k|v and W1|W2 GEMMs: the switch, and -- with the guard armed -- the
+        calibration of the current weights (measured on `images` when it has not been yet)."""
+        if not self.fold_block_ln:
+            return False
+        if not self.block_fold_guard:
+            return True
+        if self.block_fold_ratio is None:
+            if images is None:
+                return True
+            self.block_fold_ratio = self.block_fold_statistic(images)
+            if self.block_fold_ratio > self.block_fold_limit:
+                import logging
+                logging.warning("frozen tower: mean |row mean| / row sigma of the residual stream = %.2f > %.1f -- norm1 / norm2 stay "
+                                "LayerNorm kernels (the folded form would lose precision on these weights)", self.block_fold_ratio, self.block_fold_limit)
+        return self.block_fold_ratio <= self.block_fold_limit
+
     def encode_image(self, images, chunk: int = 256):
         """Frozen-teacher path: full ViT, final LN on the CLS row, head.  [K,3,S,S] -> fp32 [K,E].
         Activation-free: crops are streamed in chunks, blocks update the residual stream in place."""
         ops, cfg, P = self.ops, self.cfg, self.prefix
         K = images.shape[0]
         out = ops.empty((K, cfg.embed_dim), F32)
+        fold_blocks = self.fold_sub_ln and self.block_folds_active(images)
         for k0 in range(0, K, chunk):
             img = images[k0:k0 + chunk]
             B = img.shape[0]
@@ -660,7 +708,7 @@ class EvaEngine:
             xf = x.view(B * N, cfg.width)
             last = cfg.layers - 1 if self.cls_only_last_block else cfg.layers
             xb = st = None
-            folded = self.fold_sub_ln and self.fold_block_ln
+            folded = self.fold_sub_ln and fold_blocks
             lo = ops.empty((B * N, cfg.width), torch.int16) if folded and self.split_stream and last > 0 else None
             cls_folded = folded and last < cfg.layers and last > 0          # the CLS-only block takes the planes + statistics as they are
             win, cus = self.rccl_window if hasattr(ops, "reserve_compute_units") else (0, 0)

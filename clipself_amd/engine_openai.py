@@ -84,6 +84,7 @@ class ClipVitEngine(EvaEngine):
     def sync_shadow(self):
         self.ops.cast_f32_bf16(self.master, self.shadow)
         self._pos_cache.clear()
+        self.block_fold_ratio = None
         self.sync_transposed()
         if self.fold_block_ln:
             self._build_folds()
@@ -265,6 +266,7 @@ class ClipVitEngine(EvaEngine):
         ops, cfg, P = self.ops, self.cfg, self.prefix
         K = images.shape[0]
         out = ops.empty((K, cfg.embed_dim), F32)
+        fold_blocks = self.block_folds_active(images)          # the switch + the row-statistics guard of the current weights (EvaEngine)
         for k0 in range(0, K, chunk):
             img = images[k0:k0 + chunk]
             B = img.shape[0]
@@ -275,7 +277,7 @@ class ClipVitEngine(EvaEngine):
             last = cfg.layers - 1 if self.cls_only_last_block else cfg.layers
             xb = st = None
             for i in range(last):
-                if self.fold_block_ln:
+                if fold_blocks:
                     xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last)
                 else:
                     self._block_fwd(i, xf, B, N, cos, sin, True, None, True)

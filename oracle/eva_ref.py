@@ -242,11 +242,12 @@ def _folded_linear(a_bf16, stats_of, ln_w, ln_b, W, b, eps, rq):
     return rstd * (a_bf16 @ Wf.T - mean * colsum) + d
 
 
-def frozen_block(sd, cfg, x, i, cos, sin, folded=True, fold_norm1=True, prefix="visual.", fold_kv=False):
+def frozen_block(sd, cfg, x, i, cos, sin, folded=True, fold_norm1=True, prefix="visual.", fold_kv=False, fold_block=True):
     """One block of the frozen (teacher) tower with bf16 rounding exactly where the HIP schedule rounds (see
     encode_image_frozen_schedule).  x fp32 [B, N, C] -> fp32 [B, N, C].  folded=False: the plain schedule of the CLS-only last block
     (fold_kv: its keys and values nevertheless come from the folded norm1 GEMM on the split stream, its query from a plain LayerNorm);
-    fold_norm1=False: block 0, whose norm1 is a LayerNorm kernel."""
+    fold_norm1=False: block 0, whose norm1 is a LayerNorm kernel; fold_block=False: norm1 and norm2 are LayerNorm kernels in every block
+    (the schedule the engine's row-statistics guard falls back to, engine.block_folds_active) and only the sub-LayerNorms are folded."""
     rq = _Round("kernel")
     eps = cfg.ln_eps
     B, N, C = x.shape
@@ -257,7 +258,7 @@ def frozen_block(sd, cfg, x, i, cos, sin, folded=True, fold_norm1=True, prefix="
     w12 = torch.cat([sd[blk + "mlp.w1.weight"], sd[blk + "mlp.w2.weight"]])
     b12 = torch.cat([sd[blk + "mlp.w1.bias"], sd[blk + "mlp.w2.bias"]])
     Hd = sd[blk + "mlp.w1.weight"].shape[0]
-    if not (folded and fold_norm1):
+    if not (folded and fold_norm1 and fold_block):
         n1 = rq(layer_norm(x, sd[blk + "norm1.weight"], sd[blk + "norm1.bias"], eps))
         qkv = n1 @ rq(wqkv).T + bqkv
         if fold_kv:
@@ -272,7 +273,10 @@ def frozen_block(sd, cfg, x, i, cos, sin, folded=True, fold_norm1=True, prefix="
     if folded:
         x = x + _folded_linear(o, o, sd[blk + "attn.inner_attn_ln.weight"], sd[blk + "attn.inner_attn_ln.bias"],
                                sd[blk + "attn.proj.weight"], sd[blk + "attn.proj.bias"], eps, rq)
-        x12 = _folded_linear(_plane_round(x), x, sd[blk + "norm2.weight"], sd[blk + "norm2.bias"], w12, b12, eps, rq)
+        if fold_block:
+            x12 = _folded_linear(_plane_round(x), x, sd[blk + "norm2.weight"], sd[blk + "norm2.bias"], w12, b12, eps, rq)
+        else:
+            x12 = rq(layer_norm(x, sd[blk + "norm2.weight"], sd[blk + "norm2.bias"], eps)) @ rq(w12).T + b12
     else:
         o = rq(layer_norm(o, sd[blk + "attn.inner_attn_ln.weight"], sd[blk + "attn.inner_attn_ln.bias"], eps))
         x = x + (o @ rq(sd[blk + "attn.proj.weight"]).T + sd[blk + "attn.proj.bias"])
@@ -286,7 +290,7 @@ def frozen_block(sd, cfg, x, i, cos, sin, folded=True, fold_norm1=True, prefix="
     return x + (h @ rq(sd[blk + "mlp.w3.weight"]).T + sd[blk + "mlp.w3.bias"])
 
 
-def encode_image_frozen_schedule(sd, cfg, images, prefix="visual.", return_stream=False):
+def encode_image_frozen_schedule(sd, cfg, images, prefix="visual.", return_stream=False, fold_block=True):
     """encode_image() with bf16 rounding exactly where the frozen (teacher) schedule of the HIP path rounds -- an independent restatement of
     that schedule's ARITHMETIC, not of its code (clipself_amd/engine.py: _teacher_block_folded, _block_fwd_cls):
       * operands of every GEMM bf16, accumulation and epilogues fp32, q|k|v / attention output / SwiGLU hidden stored bf16;
@@ -298,14 +302,16 @@ def encode_image_frozen_schedule(sd, cfg, images, prefix="visual.", return_strea
         as the training schedule does; the attention's P.V product takes the un-normalised exp(s - max) in bf16 (_Round("kernel")).
     Against this oracle the kernels' own error is what is left (summation order + the rounding flips it triggers); against
     encode_image(emulate_bf16=True) the different rounding points alone move the features by ~5e-3 (profiles/r03_parity.md).
-    return_stream: also the fp32 residual stream in front of every block ([L + 1] tensors, the last one is the tower's output stream)."""
+    return_stream: also the fp32 residual stream in front of every block ([L + 1] tensors, the last one is the tower's output stream).
+    fold_block=False: the schedule with norm1 / norm2 as LayerNorm kernels (sub-LayerNorms still folded), see frozen_block."""
     rq = _Round("kernel")
     x, g = stem(sd, cfg, images, rq, prefix)
     cos, sin = rope_tables(g, cfg.head_width, cfg.pt_hw_seq_len)
     L = cfg.layers
     stream = [x]
     for i in range(L):
-        x = frozen_block(sd, cfg, x, i, cos, sin, folded=i < L - 1, fold_norm1=i > 0, prefix=prefix, fold_kv=(i == L - 1 and L > 1))
+        x = frozen_block(sd, cfg, x, i, cos, sin, folded=i < L - 1, fold_norm1=i > 0, prefix=prefix,
+                         fold_kv=(i == L - 1 and L > 1 and fold_block), fold_block=fold_block)
         stream.append(x)
     out = rq(layer_norm(x, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], cfg.ln_eps))[:, 0]
     out = out @ rq(sd[prefix + "head.weight"]).T + sd[prefix + "head.bias"]

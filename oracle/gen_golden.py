@@ -464,6 +464,69 @@ def gen_b16(oc):
     print("b16 losses", out["losses"], "grad_none", none, census)
 
 
+B16_CURVE = dict(B16, seed_w=0, seed_b=5000, steps=24, n_batches=4, lr=5e-5, warmup=4, total=24)
+
+
+def gen_b16_curve(oc):
+    """Loss curve of the real reference at a real tower size: EVA02-CLIP-B-16 at BASELINE cfg-1 shape (2 images x 8 boxes, 224^2), 24 optimiser
+    steps of train.py:80-122 with the AdamW groups of main.py:198-213, 4 distinct batches cycled, warm-up + cosine decay, an lr at which the
+    loss moves by tens of percent (the shipped recipe's 1e-5 with 1000 warm-up steps moves nothing in 24 steps)."""
+    from training.clipself import CLIPSelf
+    from training.scheduler import cosine_lr
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    rec = B16_CURVE
+    student, teacher = _build(oc, cfg, rec["seed_w"]), _build(oc, cfg, rec["seed_w"])
+    student.lock_image_tower(unlocked_groups=cfg.layers)
+    student.train()
+    teacher.eval()
+    opt, _ = _optimizer(student, rec["lr"], rec["wd"])
+    sched = cosine_lr(opt, rec["lr"], rec["warmup"], rec["total"])
+    method, args = CLIPSelf(), SimpleNamespace(multiscale=False, extract_type="v2", cosine_weight=1.0)
+    losses, lrs = [], []
+    for step in range(rec["steps"]):
+        batch = synthetic_batch(rec["batch"], rec["boxes"], 224, 224, seed=rec["seed_b"] + step % rec["n_batches"])
+        lrs.append(sched(step))
+        opt.zero_grad()
+        out, _, _ = method(batch, student, teacher, None, "cpu", None, False, args)
+        total = sum(out.values())
+        total.backward()
+        opt.step()
+        with torch.no_grad():
+            student.logit_scale.clamp_(0, math.log(100))
+        losses.append(float(total.detach()))
+        print("b16 curve step", step, losses[-1], flush=True)
+    np.savez_compressed(GOLD / "b16_curve.npz", losses=np.array(losses, np.float64), lrs=np.array(lrs, np.float64),
+                        recipe=np.array(json.dumps(rec)))
+
+
+STRESS = dict(seed_w=0, seed_b=1234, batch=2, boxes=8, crops=4, row_offset_sigmas=(5.0, 1.5))
+
+
+def gen_stress(oc):
+    """The real reference on weights with trained-like activation statistics (oracle/stress_weights.py: outlier channels x50..x200 and rows
+    with |mean| / sigma = 5, resp. 1.5): teacher features of a few crops, student RoI features, the loss -- what pins the fp32 oracle in the
+    regime the folded LayerNorms of the frozen schedule are sensitive to."""
+    from oracle.stress_weights import trained_statistics_state
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    rec = STRESS
+    blob = {"recipe": np.array(json.dumps(rec))}
+    for ros in rec["row_offset_sigmas"]:
+        model = oc.create_model(cfg.name, "eva", cache_dir=None, device="cpu", precision="fp32")
+        res = model.load_state_dict(trained_statistics_state(cfg, rec["seed_w"], row_offset_sigmas=ros), strict=False)
+        assert not res.unexpected_keys
+        model.eval()
+        images, boxes, crops = synthetic_batch(rec["batch"], rec["boxes"], 224, 224, seed=rec["seed_b"])
+        flat = crops.flatten(0, 1)[:rec["crops"]]
+        with torch.no_grad():
+            t = model.encode_image(flat, normalize=False)
+            s = model.encode_pseudo_boxes(images, [b[:, :4] for b in boxes], normalize=False, extract_type="v2")
+        tag = f"ros{ros:g}/"
+        blob[tag + "teacher"] = t.numpy()
+        blob[tag + "student_roi"] = s.numpy()
+        print("stress", ros, "teacher norm", float(t.norm()), "student norm", float(s.norm()), flush=True)
+    np.savez_compressed(GOLD / "b16_stress.npz", **blob)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
@@ -489,6 +552,12 @@ def main():
         if "--tiny-only" not in sys.argv:
             gen_vitb16(oc)
         return
+    if "--b16-curve-only" in sys.argv:
+        gen_b16_curve(oc)
+        return
+    if "--stress-only" in sys.argv:
+        gen_stress(oc)
+        return
     if "--params-only" in sys.argv:
         gen_params(oc)
         gen_schedules(oc)
@@ -505,6 +574,8 @@ def main():
     if "--tiny-only" not in sys.argv:
         gen_b16(oc)
         gen_vitb16(oc)
+        gen_b16_curve(oc)
+        gen_stress(oc)
 
 
 if __name__ == "__main__":

@@ -15,8 +15,8 @@ from clipself_amd.init import seeded_visual_state, synthetic_batch
 from oracle import eva_ref
 
 
-def _load(golden_dir):
-    g = np.load(golden_dir / "tiny_curve.npz")
+def _load(golden_dir, name="tiny_curve.npz"):
+    g = np.load(golden_dir / name)
     return g, json.loads(str(g["recipe"]))
 
 
@@ -24,14 +24,17 @@ def _batch(cfg, rec, step):
     return synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"] + step % rec["n_batches"])
 
 
-def run_curve(golden_dir, ops, device, fp8=False, bound=2e-2, end_bound=1e-2):
+def run_curve(golden_dir, ops, device, fp8=False, bound=2e-2, end_bound=1e-2, golden="tiny_curve.npz", cfg=None, descends_to=0.25):
+    """24 optimiser steps of the recipe stored in `golden` through train_step(); asserts |loss - reference| < bound at every step and
+    < end_bound at the end, and that the curve descends below descends_to x its first point.  Returns (worst absolute deviation, losses,
+    worst RELATIVE deviation)."""
     from clipself_amd.open_clip.model import CustomCLIP
     from clipself_amd.training.clipself import CLIPSelf
     from clipself_amd.training.optim import FlatAdamW
     from clipself_amd.training.scheduler import cosine_lr
     from clipself_amd.training.train import train_step
-    g, rec = _load(golden_dir)
-    cfg = tiny_cfg()
+    g, rec = _load(golden_dir, golden)
+    cfg = cfg or tiny_cfg()
     student, teacher = CustomCLIP(cfg, ops=ops, trainable=True), CustomCLIP(cfg, ops=ops, trainable=False)
     for m in (student, teacher):
         m.visual.engine.load_state(seeded_visual_state(cfg, rec["seed_w"]))
@@ -51,7 +54,9 @@ def run_curve(golden_dir, ops, device, fp8=False, bound=2e-2, end_bound=1e-2):
     ref = g["losses"]
     worst = float(np.abs(np.array(losses) - ref).max())
     assert worst < bound, (worst, losses, ref.tolist())
-    assert abs(losses[-1] - ref[-1]) < end_bound and losses[-1] < 0.25 * losses[0]     # the curve really descends, to the same place
+    assert abs(losses[-1] - ref[-1]) < end_bound and losses[-1] < descends_to * losses[0]     # the curve really descends, to the same place
+    if golden != "tiny_curve.npz":
+        return worst, losses, float((np.abs(np.array(losses) - ref) / ref).max())
     return worst, losses
 
 
@@ -89,3 +94,20 @@ def test_fp8_forward_and_dgrad_follows_the_reference_curve(golden_dir):
     torch.set_num_threads(4)
     worst, losses = run_curve(golden_dir, RefOps(), "cpu", fp8="dgrad", bound=2e-2, end_bound=1e-2)
     print("worst |loss - reference| over 24 steps, fp8 forward + dgrad:", worst)
+
+
+def test_oracle_reproduces_the_head_of_the_b16_reference_curve(golden_dir):
+    """tests/golden/b16_curve.npz: 24 optimiser steps of the real reference on EVA02-CLIP-B-16 at BASELINE cfg-1 shape (2 images x 8 boxes,
+    224^2; oracle/gen_golden.py --b16-curve-only; loss 0.786 -> 0.425).  The fp32 oracle reproduces the first 5 points here (a step of the
+    real tower costs seconds on CPU; the HIP path runs all 24 in tests/test_gpu_step.py)."""
+    from clipself_amd.config import get_tower_cfg
+    g, rec = _load(golden_dir, "b16_curve.npz")
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    n = 5
+    student, teacher = seeded_visual_state(cfg, rec["seed_w"]), seeded_visual_state(cfg, rec["seed_w"])
+    log, _ = eva_ref.train_steps(student, teacher, cfg, [_batch(cfg, rec, s) for s in range(n)], lr=rec["lr"], wd=rec["wd"],
+                                 warmup=rec["warmup"], total_steps=rec["total"])
+    assert np.allclose([l["lr"] for l in log], g["lrs"][:n], rtol=1e-12)
+    got, ref = np.array([l["loss"] for l in log]), g["losses"][:n]
+    print("b16 curve head: oracle", got.tolist(), "reference", ref.tolist())
+    assert np.abs(got - ref).max() < 2e-4 and ref[4] < 0.75 * ref[0]          # the fifth step (first one at the full lr) moves the loss by 0.17

@@ -1,0 +1,71 @@
+"""Trained-like activation statistics (oracle/stress_weights.py) on CPU: the fixture has the statistics it claims, the fp32 oracle is pinned on
+the REAL reference's outputs for these weights (tests/golden/b16_stress.npz, oracle/gen_golden.py --stress-only), and the engine's
+row-statistics guard (engine.block_folds_active) keeps norm1 / norm2 as LayerNorm kernels exactly when the folded form would lose precision.
+The HIP kernels run the same fixture teacher-forced in tests/test_gpu_parity.py::test_b16_trained_statistics_stress."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from clipself_amd.config import get_tower_cfg, tiny_cfg
+from clipself_amd.init import synthetic_batch
+from oracle import eva_ref
+from oracle.stress_weights import calibration_images, row_statistics, trained_statistics_state
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def test_oracle_is_pinned_on_the_reference_for_trained_statistics(golden_dir):
+    torch.set_num_threads(8)
+    g = np.load(golden_dir / "b16_stress.npz")
+    rec = json.loads(str(g["recipe"]))
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    images, boxes, crops = synthetic_batch(rec["batch"], rec["boxes"], 224, 224, seed=rec["seed_b"])
+    flat = crops.flatten(0, 1)[:rec["crops"]]
+    for ros in rec["row_offset_sigmas"]:
+        sd = trained_statistics_state(cfg, rec["seed_w"], row_offset_sigmas=ros)
+        with torch.no_grad():
+            x0, _ = eva_ref.stem(sd, cfg, calibration_images(cfg), eva_ref._Round(False))
+            t = eva_ref.encode_image(sd, cfg, flat)
+            s = eva_ref.encode_pseudo_boxes(sd, cfg, images, [b[:, :4] for b in boxes])
+        ratio, outlier = row_statistics(x0)
+        assert abs(ratio - ros) < 0.02 and outlier > 100, (ratio, outlier)          # |row mean| / sigma as asked for; channels > 100x the typical deviation
+        rt, rs = rel(t, g[f"ros{ros:g}/teacher"]), rel(s, g[f"ros{ros:g}/student_roi"])
+        print(f"ros {ros}: |mean|/sigma {ratio:.2f}, largest / median deviation {outlier:.0f}; oracle vs reference teacher {rt:.1e}, student RoI {rs:.1e}")
+        assert rt < 2e-5 and rs < 2e-5
+
+
+@pytest.mark.parametrize("ros,expect_folded", [(0.0, True), (1.5, True), (5.0, False)])
+def test_row_statistics_guard_of_the_folded_block_layernorms(ros, expect_folded):
+    """engine.block_folds_active on the tiny tower through the per-kernel CPU references: outlier channels alone and |mean| / sigma = 1.5 keep
+    every LayerNorm folded; |mean| / sigma = 5 trips the guard and encode_image() then equals the schedule with LayerNorm kernels for norm1 /
+    norm2 (bit for bit: it IS that schedule)."""
+    from clipself_amd.open_clip.model import CustomCLIP
+    from oracle.ops_ref import RefOps
+    cfg = tiny_cfg()
+    sd = trained_statistics_state(cfg, 2, row_offset_sigmas=ros)
+    teacher = CustomCLIP(cfg, ops=RefOps(), trainable=False)
+    eng = teacher.visual.engine
+    eng.load_state(sd)
+    _, _, crops = synthetic_batch(3, 4, cfg.image_size, cfg.image_size, seed=8)
+    flat = crops.flatten(0, 1)
+    assert eng.block_fold_ratio is None
+    with torch.no_grad():
+        got = teacher.encode_image(flat)
+        assert eng.block_fold_ratio is not None and eng.block_folds_active() == expect_folded, eng.block_fold_ratio
+        want = eva_ref.encode_image(sd, cfg, flat)
+        eng.block_fold_guard = False                                 # the fully folded schedule regardless of the statistics
+        forced = teacher.encode_image(flat)
+        eng.fold_block_ln = False                                    # norm1 / norm2 as LayerNorm kernels
+        plain = teacher.encode_image(flat)
+    nrm = lambda t: torch.nn.functional.normalize(t.double(), dim=-1)
+    d_got, d_forced, d_plain = (rel(nrm(t), nrm(want)) for t in (got, forced, plain))
+    print(f"tiny, ros {ros}: statistic {eng.block_fold_ratio:.2f}; normalised features vs fp32 oracle: served {d_got:.2e}, all folded {d_forced:.2e}, "
+          f"norm1 / norm2 unfolded {d_plain:.2e}")
+    assert torch.equal(got, forced if expect_folded else plain)        # (the precision comparison needs depth: B/16, tests/test_gpu_parity.py)
+    eng.load_state(sd)
+    assert eng.block_fold_ratio is None                              # a weight load re-arms the calibration
