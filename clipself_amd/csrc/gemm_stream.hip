@@ -13,6 +13,7 @@
 //   * The operand ring runs CONTINUOUSLY across output tiles: K tile g of the workgroup's tile sequence lives in A slot g % 3 /
 //     B slot g & 1, and iteration g issues B(g+1) and A(g+2) whatever tile they belong to, so the first operands of the next output
 //     tile are in flight two K tiles before the current tile's epilogue and there is no per-tile prologue, no extra barrier.
+//   * Round 4: asymmetric DMA roles -- waves 0-3 issue the B tile (k-steps 0-1), waves 4-7 the A tile (k-steps 2-3); see ROLES below.
 //   * The K step is ONE basic block with a fixed issue order (round 3): the eight DMA pieces are issued unconditionally (past its last tile
 //     a cursor keeps cycling over that tile's K tiles: valid memory, slots nobody reads), the cursor advance sits behind the MFMAs, and the
 //     six ds_read_b128 of k-step ks+1 go one behind each of the first six MFMAs of k-step ks (two fragment register sets,
@@ -512,11 +513,22 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     const int a_base = ((wm * TM + l31) >> 1) << 8, b_base = ((wn * TN + l31) >> 1) << 8;
     const int par8 = (l31 & 1) << 3, sw = l31 >> 1;
     const int G = gridDim.x;
+#ifndef CS_NO_DMA_ROLES
+    // Round 4: the two waves of a SIMD (w and w + 4) take different DMA roles.  Waves 0-3 put the whole B tile of K tile g+1 in flight
+    // during the first two k-steps of iteration g (8 pieces each), waves 4-7 the whole A tile of K tile g+2 during the last two.  Issuing
+    // a DMA piece stalls its wave for ~100 cycles beside LDS reads; with every wave issuing two pieces in every k-step (round 3) the two
+    // waves of a SIMD stall together and the matrix pipe idles, now the stalled wave's partner has a k-step of MFMAs and LDS reads only.
+    // Same tiles, same accumulation order: bit-identical outputs; step 704.7 -> 717.5 images/s on one box (profiles/r04_c_dma_roles.md).
+    constexpr bool ROLES = !F8;
+#else
+    constexpr bool ROLES = false;
+#endif
+    const bool role_a = ROLES && wave >= 4;
 
     // DMA cursors: position (tile, K tile) of the next A / B operand tile to put in flight.  A piece's source address is
     // wave-uniform base (operand + first row of the tile, advanced by 128 bytes per K tile: SGPRs) + a per-lane 32-bit byte offset
     // that is constant for the whole tile -> no vector address arithmetic in the K loop.
-    unsigned avoff[4], bvoff[4];
+    unsigned avoff[ROLES ? 8 : 4], bvoff[ROLES ? 1 : 4];           // ROLES: avoff holds the 8 pieces of the wave's ONE operand
     const char *a_src = nullptr, *b_src = nullptr;
     int a_tile = blockIdx.x, a_kt = 0, b_tile = blockIdx.x, b_kt = 0;
     auto set_a = [&](int tile) {
@@ -524,9 +536,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         tile_of_id(p, tile, ntiles, tm, tn);
         a_src = (const char*)p.A + (size_t)tm * BM * p.lda * ES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < (ROLES ? 8 : 4); ++i) {
             int tr, chk;
-            lane_source(wave * 4 + i, lane, tr, chk);
+            lane_source(ROLES ? (wave & 3) * 8 + i : wave * 4 + i, lane, tr, chk);
             avoff[i] = (unsigned)(min(tr, p.M - 1 - tm * BM) * p.lda * ES + chk * 16);
         }
     };
@@ -539,9 +551,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             b_src = (const char*)p.B + (size_t)tn * BN * p.ldb * ES;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < (ROLES ? 8 : 4); ++i) {
             int tr, chk;
-            lane_source(wave * 4 + i, lane, tr, chk);
+            lane_source(ROLES ? (wave & 3) * 8 + i : wave * 4 + i, lane, tr, chk);
             int rel;
             if (SWI) {
                 const int hrel = (tr >> 6) * 32 + (tr & 31);                                  // hidden unit relative to tn*128
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             } else {
                 rel = min(tr, p.N - 1 - tn * BN);
             }
-            bvoff[i] = (unsigned)(rel * p.ldb * ES + chk * 16);
+            (ROLES ? avoff : bvoff)[i] = (unsigned)(rel * p.ldb * ES + chk * 16);
         }
     };
     // Past the workgroup's last tile a cursor keeps cycling over that tile's K tiles: the DMA of the last two iterations then re-reads
@@ -580,17 +592,42 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + (size_t)b_kt * (BK * 2) + bvoff[X]), \
                                      (__attribute__((address_space(3))) void*)(b_ring + (SLOT) * B_BYTES + (wave * 4 + (X)) * 1024), 16, 0, 0)
 
-    set_a(a_tile);
-    set_b(b_tile);
+    // ROLES: piece X (0..7) of the wave's own operand tile -- LDS rows ((wave & 3) * 8 + X) * 4 .. + 3 of the slot
+#define ISSUE_RA(X, SLOT)                                                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + (size_t)a_kt * (BK * 2) + avoff[X]), \
+                                     (__attribute__((address_space(3))) void*)(smem + (SLOT) * A_BYTES + ((wave & 3) * 8 + (X)) * 1024), 16, 0, 0)
+#define ISSUE_RB(X, SLOT)                                                                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + (size_t)b_kt * (BK * 2) + avoff[X]), \
+                                     (__attribute__((address_space(3))) void*)(b_ring + (SLOT) * B_BYTES + ((wave & 3) * 8 + (X)) * 1024), 16, 0, 0)
+
+    if constexpr (ROLES) {
+        if (role_a) {
+            set_a(a_tile);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) ISSUE_A(x, 0);
-    adv_a();
+            for (int x = 0; x < 8; ++x) ISSUE_RA(x, 0);
+            adv_a();
 #pragma unroll
-    for (int x = 0; x < 4; ++x) ISSUE_B(x, 0);
-    adv_b();
+            for (int x = 0; x < 8; ++x) ISSUE_RA(x, 1);
+            adv_a();
+        } else {
+            set_b(b_tile);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) ISSUE_A(x, 1);
-    adv_a();
+            for (int x = 0; x < 8; ++x) ISSUE_RB(x, 0);
+            adv_b();
+        }
+    } else {
+        set_a(a_tile);
+        set_b(b_tile);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ISSUE_A(x, 0);
+        adv_a();
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ISSUE_B(x, 0);
+        adv_b();
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ISSUE_A(x, 1);
+        adv_a();
+    }
 
     int curA = 0, gpar = 0;                  // A slot of K tile g, parity of g
     bool after_epi = false;
@@ -624,12 +661,16 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         };
 
         // ZERO: first K tile of the output tile -- its first k-step accumulates onto the inline constant 0 (no 128 v_mov per tile)
-        auto ktile = [&](auto zero_tag) {
+        auto ktile = [&](auto zero_tag, auto role_tag) {
             constexpr bool ZERO = decltype(zero_tag)::value;
+            constexpr int ROLE = decltype(role_tag)::value;         // 0: every wave issues 4 + 4 pieces; 1: B loader (waves 0-3); 2: A loader (4-7)
             // In issue order this wave's pending ops are ... A(g), B(g), A(g+1) [, the previous epilogue's S stores]: everything older
             // than A(g+1) must have landed; vmcnt retires in order, so the stores (newest) may stay in flight as well.
-            if (after_epi) CS_VMCNT(4 + S);
-            else CS_VMCNT(4);
+            // ROLES: a B loader's pending ops are B(g) [, stores]; an A loader's A(g), A(g+1) [, stores] -- 8 pieces each.
+            constexpr int KEEP = ROLE == 0 ? 4 : ROLE == 1 ? 0 : 8;
+            constexpr int SS = S + KEEP > 63 ? 63 - KEEP : S;
+            if (after_epi) CS_VMCNT(KEEP + SS);
+            else CS_VMCNT(KEEP);
             after_epi = false;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (!CS_ABL(p, 2))                  // build with CS_EXTRA_FLAGS=-DCS_ABLATION_SWITCHES for tools/barrier_cost.py: the run-time test costs 0.35 % of the step
@@ -691,7 +732,13 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                 for (int ks = 0; ks < 4; ++ks) {
                     const int cb = ks & 1;
                     if (ks < 3) frags(ks + 1, cb ^ 1);
-                    if (ks < 2) {                  // two DMA pieces per k-step: B(g+1) first, then A(g+2)
+                    if constexpr (ROLE == 1) {     // B(g+1): all 8 pieces in k-steps 0 and 1
+                        if (ks == 0) { ISSUE_RB(0, slot_b1); ISSUE_RB(1, slot_b1); ISSUE_RB(2, slot_b1); ISSUE_RB(3, slot_b1); }
+                        if (ks == 1) { ISSUE_RB(4, slot_b1); ISSUE_RB(5, slot_b1); ISSUE_RB(6, slot_b1); ISSUE_RB(7, slot_b1); }
+                    } else if constexpr (ROLE == 2) {     // A(g+2): all 8 pieces in k-steps 2 and 3
+                        if (ks == 2) { ISSUE_RA(0, slot_a2); ISSUE_RA(1, slot_a2); ISSUE_RA(2, slot_a2); ISSUE_RA(3, slot_a2); }
+                        if (ks == 3) { ISSUE_RA(4, slot_a2); ISSUE_RA(5, slot_a2); ISSUE_RA(6, slot_a2); ISSUE_RA(7, slot_a2); }
+                    } else if (ks < 2) {           // two DMA pieces per k-step: B(g+1) first, then A(g+2)
                         if ((ks & 1) == 0) { ISSUE_B(0, slot_b1); ISSUE_B(1, slot_b1); } else { ISSUE_B(2, slot_b1); ISSUE_B(3, slot_b1); }
                     } else {
                         if ((ks & 1) == 0) { ISSUE_A(0, slot_a2); ISSUE_A(1, slot_a2); } else { ISSUE_A(2, slot_a2); ISSUE_A(3, slot_a2); }
@@ -709,25 +756,42 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                         }
                     // issue order of this k-step: one LDS read (of the next k-step's fragments) or one DMA piece behind every MFMA
 #ifndef CS_NO_SGB
+                    const bool DMA4 = (ROLE == 1 && ks < 2) || (ROLE == 2 && ks >= 2);      // this k-step carries four pieces of this wave
 #pragma unroll
                     for (int m = 0; m < 8; ++m) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (m < 6) {
-                            if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (ROLE == 0) {
+                            if (m < 6) {
+                                if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            } else {
+                                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                            }
                         } else {
-                            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                            if (m < 6 && ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            if (DMA4 && ks < 3 && m >= 6) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);     // behind the reads: 2 + 2
+                            if (DMA4 && ks == 3 && m >= 2 && m < 6) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // no reads in the last k-step
                         }
                     }
 #endif
                 }
             }
-            adv_b();
-            adv_a();
+            if (ROLE != 2) adv_b();
+            if (ROLE != 1) adv_a();
             curA = curA == 2 ? 0 : curA + 1;
             gpar ^= 1;
         };
-        ktile(std::true_type{});
-        for (int kt = 1; kt < ktiles; ++kt) ktile(std::false_type{});
+        if constexpr (ROLES) {
+            if (role_a) {
+                ktile(std::true_type{}, std::integral_constant<int, 2>{});
+                for (int kt = 1; kt < ktiles; ++kt) ktile(std::false_type{}, std::integral_constant<int, 2>{});
+            } else {
+                ktile(std::true_type{}, std::integral_constant<int, 1>{});
+                for (int kt = 1; kt < ktiles; ++kt) ktile(std::false_type{}, std::integral_constant<int, 1>{});
+            }
+        } else {
+            ktile(std::true_type{}, std::integral_constant<int, 0>{});
+            for (int kt = 1; kt < ktiles; ++kt) ktile(std::false_type{}, std::integral_constant<int, 0>{});
+        }
         if (CS_ABL(p, 4)) continue;            // timing ablation (tools/gemm_bench.py): no epilogue, results are wrong
         after_epi = true;
         // Everything the epilogue derives from the lane id (swizzled slab addresses, store offsets, ds_bpermute sources: ~80 values) is
@@ -757,6 +821,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     CS_VMCNT(0);      // the last two iterations' operand DMA (dead data, see adv_a) must not outlive the workgroup's LDS allocation
 #undef ISSUE_A
 #undef ISSUE_B
+#undef ISSUE_RA
+#undef ISSUE_RB
 }
 
 template <int EPI, bool LN, bool AUX, bool SLAB>

@@ -6,6 +6,7 @@ batch = (images [B,3,S,S], normed_boxes [B,max_boxes,5] = (x0,y0,x1,y1 in [0,1],
 The teacher forward, the student dense forward, RoIAlign, both L2 normalisations, the cosine loss and the whole
 backward run as HIP kernels; the tensors handed back (`loss_cosine`) are ordinary autograd leaves of that path.
 """
+import os
 import random
 
 import torch
@@ -90,7 +91,8 @@ class CLIPSelf:
         if self._side is None:
             # single GPU: the teacher is the long pole, let it win CUs.  Data parallel: normal priority, so that RCCL's kernels
             # (launched at default priority) are not starved behind 3 ms persistent GEMMs
-            self._side = torch.cuda.Stream(device=device, priority=0 if distributed else -1)
+            prio = os.environ.get("CLIPSELF_TEACHER_STREAM_PRIORITY")
+            self._side = torch.cuda.Stream(device=device, priority=int(prio) if prio is not None else (0 if distributed else -1))
         side = self._side
         side.wait_stream(main)
         eng = getattr(getattr(dist_model, "visual", None), "engine", None)
