@@ -524,6 +524,16 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     constexpr bool ROLES = false;
 #endif
     const bool role_a = ROLES && wave >= 4;
+#ifndef CS_NO_MID_BARRIER
+    // Round 4.  The per-K-tile barrier sits between k-steps 2 and 3 of the tile (register epilogues only): when a wave leaves it, the fragments of
+    // k-step 3 are in its registers, so the eight MFMAs of that k-step start at once and the first fragments of the NEXT K tile are read
+    // behind them -- no wave ever sits behind a barrier with nothing but LDS latency in front of its next MFMA.  Operand lead: B(g+2)
+    // goes out in k-step 3 of iteration g (its slot, B(g)'s, is free once every wave has passed the barrier of iteration g), A(g+2) in
+    // k-steps 0-1.  Bit-identical outputs; q|k|v 1500 -> 1473 us, W1|W2 2308 -> 2288 us, step +0.4 % (profiles/r04_f_mid_barrier.txt).
+    constexpr bool MID = ROLES && !SLAB;
+#else
+    constexpr bool MID = false;
+#endif
 
     // DMA cursors: position (tile, K tile) of the next A / B operand tile to put in flight.  A piece's source address is
     // wave-uniform base (operand + first row of the tile, advanced by 128 bytes per K tile: SGPRs) + a per-lane 32-bit byte offset
@@ -614,6 +624,15 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
             for (int x = 0; x < 8; ++x) ISSUE_RB(x, 0);
             adv_b();
+            if constexpr (MID) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) ISSUE_RB(x, 1);
+                adv_b();
+            }
+        }
+        if constexpr (MID) {               // K tile 0 landed everywhere before the first fragment read (both roles: one tile of 8 pieces stays in flight)
+            CS_VMCNT(8);
+            __builtin_amdgcn_s_barrier();
         }
     } else {
         set_a(a_tile);
@@ -780,7 +799,106 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             curA = curA == 2 ? 0 : curA + 1;
             gpar ^= 1;
         };
-        if constexpr (ROLES) {
+        // ---- MID: barrier between k-steps 2 and 3 (see above); fragment sets live across the K tiles of the output tile
+        bf16x8 fa[2][MID ? FM : 1], fb[2][MID ? FN : 1];
+        auto ktile_mid = [&](auto zero_tag, auto role_tag) {
+            constexpr bool ZERO = decltype(zero_tag)::value;
+            constexpr int ROLE = decltype(role_tag)::value;         // 1: B loader (waves 0-3), 2: A loader (waves 4-7)
+            const int nextA = curA == 2 ? 0 : curA + 1;
+            const char* la = smem + curA * A_BYTES + a_base;
+            const char* lb = b_ring + gpar * B_BYTES + b_base;
+            const char* la_n = smem + nextA * A_BYTES + a_base;
+            const char* lb_n = b_ring + (gpar ^ 1) * B_BYTES + b_base;
+            const int slot_a2 = curA == 0 ? 2 : curA - 1, slot_b2 = gpar;      // A(g+2) -> slot of A(g-1); B(g+2) -> slot of B(g)
+            auto frags = [&](const char* pa, const char* pb, int ks, int buf) {
+                const int off = ((par8 | (ks * 2 + hf)) ^ sw) << 4;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) fa[buf][i] = *(const bf16x8*)(pa + i * (16 * 256) + off);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) fb[buf][j] = *(const bf16x8*)(pb + j * (16 * 256) + off);
+            };
+            auto mfmas = [&](int cb, bool zero) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        if (zero) {
+                            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][j], fa[cb][i], z, 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][j], fa[cb][i], acc[i][j], 0, 0, 0);
+                        }
+                    }
+            };
+            if (ZERO) {                    // first K tile of an output tile: its first fragments were not prefetched across the epilogue
+                frags(la, lb, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const int cb = ks & 1;
+                frags(la, lb, ks + 1, cb ^ 1);
+                if constexpr (ROLE == 2) {                 // A(g+2): 4 + 4 pieces in k-steps 0 and 1
+                    if (ks == 0) { ISSUE_RA(0, slot_a2); ISSUE_RA(1, slot_a2); ISSUE_RA(2, slot_a2); ISSUE_RA(3, slot_a2); }
+                    if (ks == 1) { ISSUE_RA(4, slot_a2); ISSUE_RA(5, slot_a2); ISSUE_RA(6, slot_a2); ISSUE_RA(7, slot_a2); }
+                }
+                mfmas(cb, ZERO && ks == 0);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (ROLE == 2 && ks < 2 && m >= 6) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+                }
+            }
+            // K tile g+1 landed everywhere, every wave is done reading the LDS images of K tile g.  Pending ops of a B loader: B(g+1)
+            // [, the stores of an epilogue that ran since]; of an A loader: A(g+1) [, those stores], A(g+2).
+            {
+                constexpr int KEEP = ROLE == 1 ? 0 : 8;
+                constexpr int SS = S + KEEP > 63 ? 63 - KEEP : S;
+                if (after_epi) CS_VMCNT(KEEP + SS);
+                else CS_VMCNT(KEEP);
+                after_epi = false;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            // k-step 0 of K tile g+1 (past the output tile's last K tile: read, not used) and -- B loaders -- all 8 pieces of B(g+2), in the
+            // order they are to issue: the compiler keeps LDS reads and LDS-DMA writes in program order (it cannot tell their slots apart)
+            {
+                const int off = ((par8 | hf) ^ sw) << 4;
+#define CS_MID_STEP(X, LOAD)                         \
+                LOAD;                                \
+                if constexpr (ROLE == 1) ISSUE_RB(X, slot_b2);
+                CS_MID_STEP(0, fa[0][0] = *(const bf16x8*)(la_n + 0 * (16 * 256) + off))
+                CS_MID_STEP(1, fa[0][1] = *(const bf16x8*)(la_n + 1 * (16 * 256) + off))
+                CS_MID_STEP(2, fa[0][2] = *(const bf16x8*)(la_n + 2 * (16 * 256) + off))
+                CS_MID_STEP(3, fa[0][3] = *(const bf16x8*)(la_n + 3 * (16 * 256) + off))
+                CS_MID_STEP(4, fb[0][0] = *(const bf16x8*)(lb_n + 0 * (16 * 256) + off))
+                CS_MID_STEP(5, fb[0][1] = *(const bf16x8*)(lb_n + 1 * (16 * 256) + off))
+                CS_MID_STEP(6, (void)0)
+                CS_MID_STEP(7, (void)0)
+#undef CS_MID_STEP
+            }
+            mfmas(1, false);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (ROLE == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+            if (ROLE == 1) adv_b();
+            else adv_a();
+            curA = nextA;
+            gpar ^= 1;
+        };
+        if constexpr (MID) {
+            if (role_a) {
+                ktile_mid(std::true_type{}, std::integral_constant<int, 2>{});
+                for (int kt = 1; kt < ktiles; ++kt) ktile_mid(std::false_type{}, std::integral_constant<int, 2>{});
+            } else {
+                ktile_mid(std::true_type{}, std::integral_constant<int, 1>{});
+                for (int kt = 1; kt < ktiles; ++kt) ktile_mid(std::false_type{}, std::integral_constant<int, 1>{});
+            }
+        } else if constexpr (ROLES) {
             if (role_a) {
                 ktile(std::true_type{}, std::integral_constant<int, 2>{});
                 for (int kt = 1; kt < ktiles; ++kt) ktile(std::false_type{}, std::integral_constant<int, 2>{});
