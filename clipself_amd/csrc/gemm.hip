@@ -846,13 +846,22 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // 32-byte column group g of token row t sits at group g ^ tn_swz(t): the two 16-lane groups of a half-wave read the same four tokens at
 // adjacent column groups, so the four tokens must land on every second group (g ^ (t & 7) leaves a 2-way conflict: measured 2-5 % slower)
 __device__ __forceinline__ int tn_swz(int tok) { return (tok & 3) << 1; }
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int tok, int colbyte) {
+// The transposing reads go out as inline asm (round 4).  Through the builtin, hipcc (ROCm 7.2) cannot tell the read's LDS slot from the
+// slots the pending LDS-DMA pieces write and drains the DMA queue -- s_waitcnt vmcnt(0) -- in front of the first read that follows a DMA
+// issue: the K loop then waited for the burst it had just issued (B(kt+1), A(kt+2)) before touching K tile kt, i.e. no operand prefetch
+// at all.  An asm read is invisible to that bookkeeping; its completion is counted by hand (tr_wait: lgkmcnt(0) naming the fragment
+// registers, so that no MFMA that consumes them is scheduled above the wait -- cdna_hip_programming.md 5.7 form (ii)).
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+struct TrFrag { s16x4 lo, hi; };
+__device__ __forceinline__ void tr_read(TrFrag& f, const char* tile, int tok, int colbyte) {
     // rows tok .. tok+3 and tok+4 .. tok+7 of the lane's column; colbyte = logical byte offset of the lane's 8-byte segment in the row
     const int a0 = tok * 512 + (colbyte ^ (tn_swz(tok) << 5)), a1 = (tok + 4) * 512 + (colbyte ^ (tn_swz(tok + 4) << 5));
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + a0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + a1));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)tile;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(base + (unsigned)a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(base + (unsigned)a1));
+}
+__device__ __forceinline__ bf16x8 tr_join(const TrFrag& f) {
+    const s16x8 v = __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
 
@@ -875,32 +884,39 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
     const int drow = lane >> 5, pc = lane & 31;
     // Ragged edges: columns past the operand's width re-read its last 8 columns (they only reach output rows / columns the epilogue masks);
     // token rows past the end re-read the last token, and those rows of the dY image are zeroed in LDS before they are read (last K tile only).
-    unsigned acol[4], bcol[4], aoff[4], boff[4];
+    // Round 4 (as in gemm_stream.hip): the two waves of a SIMD take different DMA roles -- waves 0-3 issue the 8 pieces of the X (B) tile
+    // right behind the barrier, waves 4-7 the 8 pieces of the dY (A) tile behind the last fragment reads of the K tile -- so that a wave
+    // stalled in its DMA burst sits beside a partner that is issuing MFMAs.  One operand per wave: ooff / ocol describe ITS 8 pieces.
+    const bool role_a = wave >= 4;
+    const int piece0 = (wave & 3) * 8;
+    unsigned ocol[8], ooff[8];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int row = 2 * (wave * 4 + x) + drow;
+    for (int x = 0; x < 8; ++x) {
+        const int row = 2 * (piece0 + x) + drow;
         const int lc = ((((pc >> 1) ^ tn_swz(row)) << 1) | (pc & 1));   // logical 16-byte chunk this LDS position holds
-        acol[x] = (unsigned)(RAGGED ? min(n0 + lc * 8, p.M - 8) : n0 + lc * 8) * 2u;
-        bcol[x] = (unsigned)(RAGGED ? min(k0 + lc * 8, p.N - 8) : k0 + lc * 8) * 2u;
-        aoff[x] = (unsigned)row * (unsigned)p.lda * 2u + acol[x];       // full tiles: one 32-bit offset per piece
-        boff[x] = (unsigned)row * (unsigned)p.ldb * 2u + bcol[x];
+        const unsigned ca = (unsigned)(RAGGED ? min(n0 + lc * 8, p.M - 8) : n0 + lc * 8) * 2u;
+        const unsigned cb = (unsigned)(RAGGED ? min(k0 + lc * 8, p.N - 8) : k0 + lc * 8) * 2u;
+        ocol[x] = role_a ? ca : cb;
+        ooff[x] = (unsigned)row * (unsigned)(role_a ? p.lda : p.ldb) * 2u + ocol[x];      // full tiles: one 32-bit offset per piece
     }
     const int ktiles_all = (p.K + 63) >> 6;
     const int kt_begin = blockIdx.y * p.ktiles_per_split, kt_end = min(kt_begin + p.ktiles_per_split, ktiles_all);
-    auto issue = [&](const __bf16* base, int ld, const unsigned (&off)[4], const unsigned (&col)[4], int kt, char* dst) {
-        const char* src = (const char*)base + (size_t)kt * 64 * ld * 2;
+    // the wave's 8 pieces of ITS operand tile kt (dY for waves 4-7, X for waves 0-3) into the slot at dst
+    auto issue = [&](int kt, char* dst) {
+        const int ld = role_a ? p.lda : p.ldb;
+        const char* src = (const char*)(role_a ? p.A : p.B) + (size_t)kt * 64 * ld * 2;
         const int rmax = p.K - 1 - kt * 64;                     // last valid token row of this tile (wave-uniform)
         if (!RAGGED || rmax >= 63) {
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off[x]),
-                                                 (__attribute__((address_space(3))) void*)(dst + (wave * 4 + x) * 1024), 16, 0, 0);
+            for (int x = 0; x < 8; ++x)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ooff[x]),
+                                                 (__attribute__((address_space(3))) void*)(dst + (piece0 + x) * 1024), 16, 0, 0);
         } else {                                                // ragged last tile
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int row = min(2 * (wave * 4 + x) + drow, rmax);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)row * ld * 2 + col[x]),
-                                                 (__attribute__((address_space(3))) void*)(dst + (wave * 4 + x) * 1024), 16, 0, 0);
+            for (int x = 0; x < 8; ++x) {
+                const int row = min(2 * (piece0 + x) + drow, rmax);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)row * ld * 2 + ocol[x]),
+                                                 (__attribute__((address_space(3))) void*)(dst + (piece0 + x) * 1024), 16, 0, 0);
             }
         }
     };
@@ -911,24 +927,26 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    if (kt_begin < kt_end) {
-        issue(p.A, p.lda, aoff, acol, kt_begin, smem);
-        issue(p.B, p.ldb, boff, bcol, kt_begin, b_ring);
+    // in flight at the top of K tile kt -- A loaders: dY(kt), dY(kt+1); B loaders: X(kt)
+    if (role_a) {
+        if (kt_begin < kt_end) issue(kt_begin, smem);
+        if (kt_begin + 1 < kt_end) issue(kt_begin + 1, smem + T_BYTES);
+    } else if (kt_begin < kt_end) {
+        issue(kt_begin, b_ring);
     }
-    if (kt_begin + 1 < kt_end) issue(p.A, p.lda, aoff, acol, kt_begin + 1, smem + T_BYTES);
     // lane's 8-byte segment inside a 32-column block: column 16*g1 + 4*(li&3); tokens of its 16-lane group: 8*hf + (li>>2)
     const int segbyte = (16 * g1 + 4 * (li & 3)) * 2, trow = 8 * hf + (li >> 2);
     int cur = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (role_a && kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // dY(kt) landed, dY(kt+1) may still fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int i0 = kt - kt_begin;
-        // one burst behind the barrier: spreading the pieces over the k-steps makes hipcc drain the DMA queue (vmcnt(0)) in front of every
-        // transposing read that follows a DMA issue -- measured 115.9 -> 136.9 us on the W1|W2 shape
-        if (kt + 1 < kt_end) issue(p.B, p.ldb, boff, bcol, kt + 1, b_ring + ((i0 + 1) & 1) * T_BYTES);
-        if (kt + 2 < kt_end) issue(p.A, p.lda, aoff, acol, kt + 2, smem + ((i0 + 2) % 3) * T_BYTES);
+        // B loaders: one burst behind the barrier.  (Spreading pieces over the k-steps makes hipcc drain the DMA queue -- vmcnt(0) -- in
+        // front of every transposing read that follows a DMA issue: measured 115.9 -> 136.9 us on the W1|W2 shape; the A loaders' burst
+        // therefore sits behind the LAST fragment reads of the K tile, below.)
+        if (!role_a && kt + 1 < kt_end) issue(kt + 1, b_ring + ((i0 + 1) & 1) * T_BYTES);
         const char* ta = smem + cur * T_BYTES;
         const char* tb = b_ring + (i0 & 1) * T_BYTES;
         // ragged last token tile: the rows of the missing tokens hold copies of the last token -- zero them in the dY image (wave-uniform
@@ -941,21 +959,32 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
         }
         // fragments of k-step ts+1 are requested before the MFMAs of k-step ts (two register sets): the transposing reads otherwise sit
         // directly in front of the MFMAs that consume them
-        bf16x8 a[2][FM], b[2][FN];
+        TrFrag a[2][FM], b[2][FN];
         auto load_frags = [&](int set, int ts) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i) a[set][i] = tr_frag(ta, 16 * ts + trow, (wm * TM + i * 32) * 2 + segbyte);
+            for (int i = 0; i < FM; ++i) tr_read(a[set][i], ta, 16 * ts + trow, (wm * TM + i * 32) * 2 + segbyte);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) b[set][j] = tr_frag(tb, 16 * ts + trow, (wn * TN + j * 32) * 2 + segbyte);
+            for (int j = 0; j < FN; ++j) tr_read(b[set][j], tb, 16 * ts + trow, (wn * TN + j * 32) * 2 + segbyte);
+        };
+        // every asm read issued so far has landed; the fragment registers of `set` are operands of the wait, so their consumers stay below it
+        auto tr_wait = [&](int set) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(a[set][0].lo), "+v"(a[set][0].hi), "+v"(a[set][1].lo), "+v"(a[set][1].hi), "+v"(a[set][2].lo), "+v"(a[set][2].hi),
+                           "+v"(a[set][3].lo), "+v"(a[set][3].hi), "+v"(b[set][0].lo), "+v"(b[set][0].hi), "+v"(b[set][1].lo), "+v"(b[set][1].hi));
         };
         load_frags(0, 0);
+        tr_wait(0);
 #pragma unroll
         for (int ts = 0; ts < 4; ++ts) {
             if (ts < 3) load_frags((ts + 1) & 1, ts + 1);
+            // A loaders: dY(kt+2) goes to the slot of dY(kt-1), free since this K tile's barrier; no LDS read of this K tile follows
+            if (ts == 3 && role_a && kt + 2 < kt_end) issue(kt + 2, smem + ((i0 + 2) % 3) * T_BYTES);
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ts & 1][i], b[ts & 1][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(a[ts & 1][i]), tr_join(b[ts & 1][j]), acc[i][j], 0, 0, 0);
+            if (ts < 3) tr_wait((ts + 1) & 1);
         }
         cur = cur == 2 ? 0 : cur + 1;
     }

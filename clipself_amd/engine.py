@@ -278,15 +278,17 @@ class EvaEngine:
     def sync_transposed(self, blocks=None):
         """W^T shadows for the dgrad GEMMs (dx = dy . W needs W with the contraction dimension contiguous)."""
         cfg, C, Hd = self.cfg, self.cfg.width, self.Hp
+        pairs = []
         for i in (range(self.first_trainable, cfg.layers) if blocks is None else blocks):
             b = f"{self.prefix}blocks.{i}."
             o = self.offsets[b + "attn.q_proj.weight"][0]
-            self.ops.transpose_bf16(self.shadow[o:o + 3 * C * C].view(3 * C, C), self._wt_alloc((i, "qkv"), 3 * C, C))
-            self.ops.transpose_bf16(self.w[b + "attn.proj.weight"], self._wt_alloc((i, "proj"), C, C))
+            pairs.append((self.shadow[o:o + 3 * C * C].view(3 * C, C), self._wt_alloc((i, "qkv"), 3 * C, C)))
+            pairs.append((self.w[b + "attn.proj.weight"], self._wt_alloc((i, "proj"), C, C)))
             o = self.offsets[b + "mlp.w1.weight"][0]
-            self.ops.transpose_bf16(self.shadow[o:o + 2 * Hd * C].view(2 * Hd, C), self._wt_alloc((i, "w12"), 2 * Hd, C))
-            self.ops.transpose_bf16(self.storage_of(self.shadow, b + "mlp.w3.weight"), self._wt_alloc((i, "w3"), C, Hd))
-        self.ops.transpose_bf16(self.w[self.prefix + "head.weight"], self._wt_alloc("head", self.cfg.embed_dim, C))
+            pairs.append((self.shadow[o:o + 2 * Hd * C].view(2 * Hd, C), self._wt_alloc((i, "w12"), 2 * Hd, C)))
+            pairs.append((self.storage_of(self.shadow, b + "mlp.w3.weight"), self._wt_alloc((i, "w3"), C, Hd)))
+        pairs.append((self.w[self.prefix + "head.weight"], self._wt_alloc("head", self.cfg.embed_dim, C)))
+        self.ops.transpose_bf16_batched(pairs)          # one launch (49 matrices per step for B/16)
 
     # ------------------------------------------------------------------------------------------ fp8 forward operands
     def _fp8_rows(self, X):

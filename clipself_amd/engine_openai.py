@@ -71,15 +71,15 @@ class ClipVitEngine(EvaEngine):
     def sync_transposed(self, blocks=None):
         """proj^T [E,C] for the forward head GEMM (every tower), and W^T shadows of the trainable blocks for the dgrad GEMMs."""
         cfg, C, Hd = self.cfg, self.cfg.width, self.cfg.hidden
-        self.ops.transpose_bf16(self.w[self.prefix + "proj"], self._wt_alloc("head_fwd", C, cfg.embed_dim))
-        if not self.trainable:
-            return
-        for i in (range(self.first_trainable, cfg.layers) if blocks is None else blocks):
-            b = f"{self.prefix}{self.BLOCK_TAG}{i}."
-            self.ops.transpose_bf16(self.w[b + "attn.in_proj_weight"], self._wt_alloc((i, "qkv"), 3 * C, C))
-            self.ops.transpose_bf16(self.w[b + "attn.out_proj.weight"], self._wt_alloc((i, "proj"), C, C))
-            self.ops.transpose_bf16(self.w[b + "mlp.c_fc.weight"], self._wt_alloc((i, "fc"), Hd, C))
-            self.ops.transpose_bf16(self.w[b + "mlp.c_proj.weight"], self._wt_alloc((i, "cproj"), C, Hd))
+        pairs = [(self.w[self.prefix + "proj"], self._wt_alloc("head_fwd", C, cfg.embed_dim))]
+        if self.trainable:
+            for i in (range(self.first_trainable, cfg.layers) if blocks is None else blocks):
+                b = f"{self.prefix}{self.BLOCK_TAG}{i}."
+                pairs.append((self.w[b + "attn.in_proj_weight"], self._wt_alloc((i, "qkv"), 3 * C, C)))
+                pairs.append((self.w[b + "attn.out_proj.weight"], self._wt_alloc((i, "proj"), C, C)))
+                pairs.append((self.w[b + "mlp.c_fc.weight"], self._wt_alloc((i, "fc"), Hd, C)))
+                pairs.append((self.w[b + "mlp.c_proj.weight"], self._wt_alloc((i, "cproj"), C, Hd)))
+        self.ops.transpose_bf16_batched(pairs)
 
     def sync_shadow(self):
         self.ops.cast_f32_bf16(self.master, self.shadow)

@@ -58,6 +58,7 @@ SIGNATURES = {
     "cs_gelu_bwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _vp]),
     "cs_cast_f32_bf16": (_i, [_vp, _vp, _l, _vp]),
     "cs_transpose_bf16": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
+    "cs_transpose_bf16_batched": (_i, [_vp, _i, _i, _vp]),
     "cs_colsum_workspace": (_sz, [_i, _i]),
     "cs_colsum_bf16": (_i, [_vp, _l, _vp, _vp, _i, _i, _vp]),
     "cs_im2row": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
@@ -416,6 +417,26 @@ class HipOps:
         R, Cc = inp.shape
         assert out.shape[0] == Cc and out.is_contiguous()
         self._ok(self.lib.cs_transpose_bf16(_p(inp), inp.stride(0), _p(out), out.shape[1], R, Cc, self._stream()), "cs_transpose_bf16")
+
+    def transpose_bf16_batched(self, pairs):
+        """[(inp [R, C], out [C, ld_out >= R]), ...] -> every out = inp^T (zero padded) in ONE launch.  The device descriptor table is
+        cached per list of buffers (the weight shadows and their transposes keep their addresses for the life of the engine)."""
+        import numpy as np
+        key = tuple((a.data_ptr(), b.data_ptr(), a.shape, b.shape, a.stride(0)) for a, b in pairs)
+        cache = getattr(self, "_tr_desc", None)
+        if cache is None or cache[0] != key:
+            rec = np.zeros((len(pairs), 6), dtype=np.int64)
+            tile0 = 0
+            for i, (a, b) in enumerate(pairs):
+                self._chk(a, b)
+                R, Cc = a.shape
+                assert b.shape[0] == Cc and b.is_contiguous() and b.shape[1] >= R and a.stride(1) == 1
+                tiles_x, tiles_y = (Cc + 63) // 64, (b.shape[1] + 63) // 64
+                rec[i] = (a.data_ptr(), b.data_ptr(), a.stride(0), b.shape[1], R | (Cc << 32), tile0 | (tiles_x << 32))
+                tile0 += tiles_x * tiles_y
+            cache = self._tr_desc = (key, torch.from_numpy(rec).cuda(), tile0)
+        _, desc, total = cache
+        self._ok(self.lib.cs_transpose_bf16_batched(_p(desc), len(pairs), total, self._stream()), "cs_transpose_bf16_batched")
 
     def colsum_workspace(self, M, N) -> int:
         return int(self.lib.cs_colsum_workspace(M, N))

@@ -161,6 +161,11 @@ int cs_gelu_bwd(const void* dy, long lddy, const void* x, long ldx, void* dx, lo
 /* --- data movement helpers of the step */
 int cs_cast_f32_bf16(const float* x, void* y, long n, cs_stream_t stream);
 int cs_transpose_bf16(const void* in, long ld_in, void* out, long ld_out, int R, int Cc, cs_stream_t stream); /* out[c,r]; zero pad r in [R, ld_out) */
+/* `count` such transposes in one launch (the W^T shadows the dgrad GEMMs read are rebuilt after every AdamW step: eva_vit_model.py:99-103,
+ * 177-179,218-219 are the linears; 49 matrices per step for B/16).  desc = DEVICE array of 48-byte records
+ *   { const void* in; void* out; long ld_in; long ld_out; int R; int Cc; int tile0; int tiles_x; }
+ * with tiles_x = ceil(Cc / 64), tile0 = sum over the preceding records of tiles_x * ceil(ld_out / 64); total_tiles = that sum over all. */
+int cs_transpose_bf16_batched(const void* desc, int count, int total_tiles, cs_stream_t stream);
 size_t cs_colsum_workspace(int M, int N);
 int cs_colsum_bf16(const void* x, long ldx, float* out, void* workspace, int M, int N, cs_stream_t stream);   /* out[n] += sum_m x[m,n] (bias grads); fixed summation order, no atomics */
 int cs_im2row(const void* img, int img_dtype, void* out, int B, int S, int p, int ldo, cs_stream_t stream);    /* PatchEmbed unfold, eva_vit_model.py:355 */

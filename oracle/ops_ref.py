@@ -383,6 +383,10 @@ class RefOps:
         out.zero_()
         out[:, :R] = inp.T
 
+    def transpose_bf16_batched(self, pairs):
+        for inp, out in pairs:
+            self.transpose_bf16(inp, out)
+
     def colsum_workspace(self, M, N):
         return 4
 

@@ -504,6 +504,17 @@ def test_swiglu_cast_transpose_colsum_im2row(hip, ref):
         outd = torch.full((Cc, ld), float("nan"), dtype=BF, device="cuda")
         hip.transpose_bf16(big.cuda()[:, :Cc], outd)
         assert torch.equal(outd.cpu(), outr), f"transpose[{R},{Cc}]"
+    # the same shapes (strided input views, padded outputs) as ONE batched launch, twice (the second call reuses the cached descriptors)
+    ins = [rnd((R, Cc + 8), BF, seed=50 + i).cuda()[:, :Cc] for i, (R, Cc) in enumerate(((197, 768), (64, 64), (3152, 2304), (130, 70), (2304, 768)))]
+    outs = [torch.full((a.shape[1], (a.shape[0] + 63) // 64 * 64), float("nan"), dtype=BF, device="cuda") for a in ins]
+    for rep in range(2):
+        for o in outs:
+            o.fill_(float("nan"))
+        hip.transpose_bf16_batched(list(zip(ins, outs)))
+        for a, o in zip(ins, outs):
+            want = torch.empty(o.shape, dtype=BF)
+            ref.transpose_bf16(a.cpu(), want)
+            assert torch.equal(o.cpu(), want), f"batched transpose {tuple(a.shape)} rep {rep}"
 
     xs = rnd((1234, 770), BF, seed=44)
     base = rnd((770,), F32, seed=45)
