@@ -93,23 +93,23 @@ struct EpiOps {
 
 // ---------------------------------------------------------------------------------------------------------------- SwiGLU
 // acc[i][0] = x1, acc[i][1] = x2 of hidden units hbase + col(e, lane>>5); out[row][hidden] = silu(x1) * x2 in bf16.
-template <bool LN, bool AUX, int CP>
-__device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int tn, int wn, const EpiOps& eo) {
+template <bool LN, bool AUX, int CP, int FM = 4>
+__device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc)[FM][2], int lane, int row0, int tn, int wn, const EpiOps& eo) {
     const int l31 = lane & 31, hf = lane >> 5;
     const int hbase = tn * 128 + wn * 32;
     const bool colok = hbase < p.group;                                 // wave-uniform: group % 32 == 0 (checked by the launcher)
-    float nm[4], rs[4];
+    float nm[FM], rs[FM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FM; ++i) {
         rs[i] = LN ? eo.rstd[i] : 1.f;
         nm[i] = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
     }
-    unsigned pk[4][4][2];
+    unsigned pk[FM][4][2];
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
     const int sl0 = hf << 4;                                            // byte address of source lane 4*hf
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float hv[4][4];
+        float hv[FM][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = q * 4 + r;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc
             float c1 = 0.f, c2 = 0.f;
             if (LN) { c1 = lane_bcast(sl, eo.cc); c2 = lane_bcast(sl + 128, eo.cc); }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < FM; ++i) {
                 float u = acc[i][0][e], v = acc[i][1][e];
                 if (LN) {                                               // value = rstd * acc - rstd * mean * colsum + bias: two FMAs
                     u = fmaf(rs[i], u, fmaf(nm[i], c1, b1));
@@ -131,7 +131,7 @@ __device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < FM; ++i) {
             pk[i][q][0] = pack2(hv[i][0], hv[i][1]);
             pk[i][q][1] = pack2(hv[i][2], hv[i][3]);
             if (AUX) {                                                  // statistics of the ROUNDED outputs (what the next GEMM reads):
@@ -145,7 +145,7 @@ __device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc
     }
     const __amdgpu_buffer_rsrc_t rc = make_rsrc((const __bf16*)p.C + (size_t)row0 * p.ldc + hbase);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FM; ++i) {
         const bool ok = colok && row0 + i * 32 + l31 < p.M && !CS_ABL(p, 8);      // dbg 8: timing ablation, every store masked
         const unsigned rowoff = (unsigned)((i * 32 + l31) * p.ldc + 8 * hf) * 2u;
 #pragma unroll
@@ -161,7 +161,7 @@ __device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc
         const size_t slice = (size_t)tn * 4 + wn;
         const __amdgpu_buffer_rsrc_t rst = make_rsrc(p.stats_part + (slice * p.M + row0) * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < FM; ++i) {
             const float s = both_halves(ssum[i]), q2 = both_halves(ssq[i]);
             const bool ok = colok && hf == 0 && row0 + i * 32 + l31 < p.M;
             store8<CP>(u32x2{__float_as_uint(s), __float_as_uint(q2)}, rst, ok ? (unsigned)(i * 32 + l31) * 8u : OOB);
@@ -170,36 +170,36 @@ __device__ __forceinline__ void epi_swiglu(const GemmArgs& p, const f32x16 (&acc
 }
 
 // ---------------------------------------------------------------------------------------------------------------- bf16 (+activation)
-template <int ACT, bool LN, int CP, bool F8 = false>
-__device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, const EpiOps& eo) {
+template <int ACT, bool LN, int CP, bool F8 = false, int FM = 4>
+__device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[FM][2], int lane, int row0, int colw, const EpiOps& eo) {
     const int l31 = lane & 31, hf = lane >> 5;
-    float nm[4], rs[4];
+    float nm[FM], rs[FM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FM; ++i) {
         rs[i] = (LN || F8) ? eo.rstd[i] : 1.f;            // F8: the row scale of the quantised A operand
         nm[i] = LN ? -eo.rstd[i] * eo.mean[i] : 0.f;
     }
     const __amdgpu_buffer_rsrc_t rc = make_rsrc((const __bf16*)p.C + (size_t)row0 * p.ldc + colw);
     const int sl0 = hf << 4;
-    unsigned pk[2][4][4][2];
+    unsigned pk[2][FM][4][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float ov[4][4];
+            float ov[FM][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int sl = sl0 + ((j * 32 + 8 * q + r) << 2);
                 const float b = lane_bcast(sl, eo.cb);
                 const float c = (LN || F8) ? lane_bcast(sl, eo.cc) : 0.f;       // LN: folded column sum; F8: column scale of the B operand
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < FM; ++i) {
                     const float a = acc[i][j][q * 4 + r];
                     ov[i][r] = activate_s<ACT>(F8 ? fmaf(rs[i] * c, a, b) : LN ? fmaf(rs[i], a, fmaf(nm[i], c, b)) : a + b);
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < FM; ++i) {
                 pk[j][i][q][0] = pack2(ov[i][0], ov[i][1]);
                 pk[j][i][q][1] = pack2(ov[i][2], ov[i][3]);
             }
@@ -207,7 +207,7 @@ __device__ __forceinline__ void epi_bf16(const GemmArgs& p, const f32x16 (&acc)[
     }
     // stores in row-block order: the four 32-byte pieces of a row's 128-byte line (two column tiles x two group pairs) leave back to back
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FM; ++i) {
         const bool rowok = row0 + i * 32 + l31 < p.M && !CS_ABL(p, 8);        // dbg 8: timing ablation, every store masked
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -358,8 +358,8 @@ __device__ __forceinline__ void epi_swiglu_slab(const GemmArgs& p, const f32x16 
 // accesses -- twice the memory instructions for the same bytes, and 8-byte requests run at 0.54-0.70x the rate of 16-byte ones
 // (MI355X_MICROARCH.md): the epilogue is bound by the CU's vector-memory path.
 // SPLIT bit 0 / bit 1: the stream arrives / leaves as the two 16-bit planes (p.xb_out, p.lo) of y = bits(x) + 0x8000 (GemmArgs::split).
-template <bool LN, bool AUX, int CP, bool F8 = false, int SPLIT = 0>
-__device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (&acc)[4][2], int lane, int row0, int colw, int tn, int wn,
+template <bool LN, bool AUX, int CP, bool F8 = false, int SPLIT = 0, int FM = 4>
+__device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (&acc)[FM][2], int lane, int row0, int colw, int tn, int wn,
                                                const EpiOps& eo, char* slab) {
     static_assert(!(SPLIT & 2) || AUX, "a split stream leaves together with the row statistics");
     const int l31 = lane & 31, hf = lane >> 5;
@@ -383,7 +383,7 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
         if (LN || F8) cc4[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.ln_colsum), off, 0, 0));
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FM; ++i) {
         // the residual rows of the block are requested before the accumulators go through the slab
         f32x4 xin[4][2];
 #pragma unroll
@@ -478,21 +478,30 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
 }
 
 // store instructions one epilogue issues per wave (exact: masked lanes keep their instruction, see OOB)
-template <int EPI, bool AUX, bool SLAB, int SPLIT = 0>
+// (a count BELOW the real one would be safe -- a wait then retires more than it needs to --, one above it is not)
+template <int EPI, bool AUX, bool SLAB, int SPLIT = 0, int FM = 4>
 constexpr int epi_stores() {
-    if (EPI == EPI_SWIGLU_BF16) return 8 + (AUX ? 4 : 0);
-    if (EPI == EPI_RESID_F32) return 32 + (AUX ? ((SPLIT & 2) ? 0 : 16) + 4 : 0);      // per row group: two fp32 or two plane stores (+ the bf16 copy)
-    return 16;
+    if (EPI == EPI_SWIGLU_BF16) return FM * (2 + (AUX ? 1 : 0));
+    if (EPI == EPI_RESID_F32) return FM * (8 + (AUX ? ((SPLIT & 2) ? 0 : 4) + 1 : 0));      // per row block: four row groups x two fp32 or two plane stores (+ the bf16 copy), + statistics
+    return FM * 4;
 }
 
 #define CS_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+inline bool getenv_flag(const char* name) {       // A/B switches read once per process
+    const char* v = getenv(name);
+    return v && v[0] && v[0] != '0';
+}
 
 // EPI: EPI_BF16 / EPI_GELU_BF16 / EPI_QGELU_BF16 / EPI_SWIGLU_BF16 / EPI_RESID_F32 (the latter with LN = folded LayerNorm, i.e. epilogue 6)
 // F8: A and B hold e4m3 bytes (K = bytes per row, a multiple of 128: one K tile = 128 contraction steps in the same 128-byte LDS rows),
 // contracted with the block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 at unit block scales (2x the bf16 MFMA rate at half the operand
 // bytes); the per-row scale of A (p.ln_rstd) and per-row scale of B (p.ln_colsum) are applied in the epilogue.
-template <int EPI, bool LN, bool AUX, bool SLAB, bool F8 = false, int SPLIT = 0>
+// BMT: rows per output tile, 256 or 192 (round 4).  192 = six 32-row blocks, three per wave: launches whose 256-row tiles fill only part
+// of the chip (the student's N = 768 GEMMs at M = 12 608: 150 tiles on 256 CUs) run 198 tiles of 3/4 the work instead.
+template <int EPI, bool LN, bool AUX, bool SLAB, bool F8 = false, int SPLIT = 0, int BMT = 256>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
+    static_assert(BMT == 256 || (BMT == 192 && !F8 && SPLIT == 0 && !LN && !AUX), "192-row tiles: the training schedule's plain epilogues");
     static_assert(SPLIT == 0 || (EPI == EPI_RESID_F32 && LN && !F8), "the split stream belongs to the folded-LayerNorm residual epilogue");
     static_assert(SLAB || EPI != EPI_RESID_F32, "the fp32 residual epilogue exists in the slab form only (whole-line traffic)");
     static_assert(!F8 || (!LN && !AUX && (EPI == EPI_BF16 || EPI == EPI_RESID_F32)), "fp8 operands: bf16 and fp32-residual outputs");
@@ -500,9 +509,11 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     constexpr int CP = 0;                      // default cache policy: the L2 must merge partial-line stores (nt / sc1 measured slower)
     constexpr bool SWI = EPI == EPI_SWIGLU_BF16, RES = EPI == EPI_RESID_F32;
     static_assert(SWI || RES || epi_is_bf16(EPI), "register epilogues");
-    constexpr int BM = 256, BN = 256, WN = 4, TM = 128, TN = 64, FM = 4, FN = 2;
+    constexpr int BM = BMT, BN = 256, WN = 4, TM = BM / 2, TN = 64, FM = TM / 32, FN = 2;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-    constexpr int S = epi_stores<EPI, AUX, SLAB, SPLIT>() < 56 ? epi_stores<EPI, AUX, SLAB, SPLIT>() : 56;     // vmcnt is a 6-bit counter; fewer = safe
+    constexpr int NPA = BM / 32;                 // DMA pieces of the A tile per A-loader wave (ROLES)
+    constexpr int NM = FM * FN, NR = FM + FN;    // MFMAs / fragment reads per k-step and wave (8 / 6; 192-row tiles: 6 / 5)
+    constexpr int S = epi_stores<EPI, AUX, SLAB, SPLIT, FM>() < 55 ? epi_stores<EPI, AUX, SLAB, SPLIT, FM>() : 55;     // vmcnt is a 6-bit counter; fewer = safe
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -546,9 +557,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         tile_of_id(p, tile, ntiles, tm, tn);
         a_src = (const char*)p.A + (size_t)tm * BM * p.lda * ES;
 #pragma unroll
-        for (int i = 0; i < (ROLES ? 8 : 4); ++i) {
+        for (int i = 0; i < (ROLES ? NPA : 4); ++i) {
             int tr, chk;
-            lane_source(ROLES ? (wave & 3) * 8 + i : wave * 4 + i, lane, tr, chk);
+            lane_source(ROLES ? (wave & 3) * NPA + i : wave * 4 + i, lane, tr, chk);
             avoff[i] = (unsigned)(min(tr, p.M - 1 - tm * BM) * p.lda * ES + chk * 16);
         }
     };
@@ -602,10 +613,10 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + (size_t)b_kt * (BK * 2) + bvoff[X]), \
                                      (__attribute__((address_space(3))) void*)(b_ring + (SLOT) * B_BYTES + (wave * 4 + (X)) * 1024), 16, 0, 0)
 
-    // ROLES: piece X (0..7) of the wave's own operand tile -- LDS rows ((wave & 3) * 8 + X) * 4 .. + 3 of the slot
+    // ROLES: piece X of the wave's own operand tile (B: 8 pieces per wave, A: NPA) -- LDS rows (first piece + X) * 4 .. + 3 of the slot
 #define ISSUE_RA(X, SLOT)                                                                                                     \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + (size_t)a_kt * (BK * 2) + avoff[X]), \
-                                     (__attribute__((address_space(3))) void*)(smem + (SLOT) * A_BYTES + ((wave & 3) * 8 + (X)) * 1024), 16, 0, 0)
+                                     (__attribute__((address_space(3))) void*)(smem + (SLOT) * A_BYTES + ((wave & 3) * NPA + (X)) * 1024), 16, 0, 0)
 #define ISSUE_RB(X, SLOT)                                                                                                     \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + (size_t)b_kt * (BK * 2) + avoff[X]), \
                                      (__attribute__((address_space(3))) void*)(b_ring + (SLOT) * B_BYTES + ((wave & 3) * 8 + (X)) * 1024), 16, 0, 0)
@@ -614,10 +625,10 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
         if (role_a) {
             set_a(a_tile);
 #pragma unroll
-            for (int x = 0; x < 8; ++x) ISSUE_RA(x, 0);
+            for (int x = 0; x < NPA; ++x) ISSUE_RA(x, 0);
             adv_a();
 #pragma unroll
-            for (int x = 0; x < 8; ++x) ISSUE_RA(x, 1);
+            for (int x = 0; x < NPA; ++x) ISSUE_RA(x, 1);
             adv_a();
         } else {
             set_b(b_tile);
@@ -630,8 +641,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                 adv_b();
             }
         }
-        if constexpr (MID) {               // K tile 0 landed everywhere before the first fragment read (both roles: one tile of 8 pieces stays in flight)
-            CS_VMCNT(8);
+        if constexpr (MID) {               // K tile 0 landed everywhere before the first fragment read (both roles: one tile stays in flight)
+            if (role_a) CS_VMCNT(NPA);
+            else CS_VMCNT(8);
             __builtin_amdgcn_s_barrier();
         }
     } else {
@@ -664,7 +676,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             eo.cb = eo.cc = 0.f;
             if (LN || F8) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < FM; ++i) {
                     const int r = min(row0 + i * 32 + l31, p.M - 1);
                     if (LN) eo.mean[i] = p.ln_mean[r];
                     eo.rstd[i] = p.ln_rstd[r];
@@ -686,7 +698,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             // In issue order this wave's pending ops are ... A(g), B(g), A(g+1) [, the previous epilogue's S stores]: everything older
             // than A(g+1) must have landed; vmcnt retires in order, so the stores (newest) may stay in flight as well.
             // ROLES: a B loader's pending ops are B(g) [, stores]; an A loader's A(g), A(g+1) [, stores] -- 8 pieces each.
-            constexpr int KEEP = ROLE == 0 ? 4 : ROLE == 1 ? 0 : 8;
+            constexpr int KEEP = ROLE == 0 ? 4 : ROLE == 1 ? 0 : NPA;
             constexpr int SS = S + KEEP > 63 ? 63 - KEEP : S;
             if (after_epi) CS_VMCNT(KEEP + SS);
             else CS_VMCNT(KEEP);
@@ -754,9 +766,15 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                     if constexpr (ROLE == 1) {     // B(g+1): all 8 pieces in k-steps 0 and 1
                         if (ks == 0) { ISSUE_RB(0, slot_b1); ISSUE_RB(1, slot_b1); ISSUE_RB(2, slot_b1); ISSUE_RB(3, slot_b1); }
                         if (ks == 1) { ISSUE_RB(4, slot_b1); ISSUE_RB(5, slot_b1); ISSUE_RB(6, slot_b1); ISSUE_RB(7, slot_b1); }
-                    } else if constexpr (ROLE == 2) {     // A(g+2): all 8 pieces in k-steps 2 and 3
-                        if (ks == 2) { ISSUE_RA(0, slot_a2); ISSUE_RA(1, slot_a2); ISSUE_RA(2, slot_a2); ISSUE_RA(3, slot_a2); }
-                        if (ks == 3) { ISSUE_RA(4, slot_a2); ISSUE_RA(5, slot_a2); ISSUE_RA(6, slot_a2); ISSUE_RA(7, slot_a2); }
+                    } else if constexpr (ROLE == 2) {     // A(g+2): all NPA pieces in k-steps 2 and 3
+                        if (ks == 2) {
+#pragma unroll
+                            for (int x = 0; x < NPA / 2; ++x) ISSUE_RA(x, slot_a2);
+                        }
+                        if (ks == 3) {
+#pragma unroll
+                            for (int x = NPA / 2; x < NPA; ++x) ISSUE_RA(x, slot_a2);
+                        }
                     } else if (ks < 2) {           // two DMA pieces per k-step: B(g+1) first, then A(g+2)
                         if ((ks & 1) == 0) { ISSUE_B(0, slot_b1); ISSUE_B(1, slot_b1); } else { ISSUE_B(2, slot_b1); ISSUE_B(3, slot_b1); }
                     } else {
@@ -775,20 +793,22 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                         }
                     // issue order of this k-step: one LDS read (of the next k-step's fragments) or one DMA piece behind every MFMA
 #ifndef CS_NO_SGB
-                    const bool DMA4 = (ROLE == 1 && ks < 2) || (ROLE == 2 && ks >= 2);      // this k-step carries four pieces of this wave
+                    const bool DMA4 = (ROLE == 1 && ks < 2) || (ROLE == 2 && ks >= 2);      // this k-step carries DN = 4 (A at 192 rows: 3) pieces of this wave
+                    constexpr int DN = ROLE == 2 ? NPA / 2 : 4;
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) {
+                    for (int m = 0; m < NM; ++m) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         if (ROLE == 0) {
-                            if (m < 6) {
+                            if (m < NR) {
                                 if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                             } else {
                                 __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
                             }
                         } else {
-                            if (m < 6 && ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                            if (DMA4 && ks < 3 && m >= 6) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);     // behind the reads: 2 + 2
-                            if (DMA4 && ks == 3 && m >= 2 && m < 6) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // no reads in the last k-step
+                            if (m < NR && ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            if (DMA4 && ks < 3 && m == NM - 2) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);     // behind the last two MFMAs: 2 + 2 (2 + 1)
+                            if (DMA4 && ks < 3 && m == NM - 1) __builtin_amdgcn_sched_group_barrier(0x010, DN - 2, 0);
+                            if (DMA4 && ks == 3 && m >= 2 && m < 2 + DN) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // no reads in the last k-step
                         }
                     }
 #endif
@@ -838,22 +858,29 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             for (int ks = 0; ks < 3; ++ks) {
                 const int cb = ks & 1;
                 frags(la, lb, ks + 1, cb ^ 1);
-                if constexpr (ROLE == 2) {                 // A(g+2): 4 + 4 pieces in k-steps 0 and 1
-                    if (ks == 0) { ISSUE_RA(0, slot_a2); ISSUE_RA(1, slot_a2); ISSUE_RA(2, slot_a2); ISSUE_RA(3, slot_a2); }
-                    if (ks == 1) { ISSUE_RA(4, slot_a2); ISSUE_RA(5, slot_a2); ISSUE_RA(6, slot_a2); ISSUE_RA(7, slot_a2); }
+                if constexpr (ROLE == 2) {                 // A(g+2): its NPA pieces in k-steps 0 and 1
+                    if (ks == 0) {
+#pragma unroll
+                        for (int x = 0; x < NPA / 2; ++x) ISSUE_RA(x, slot_a2);
+                    }
+                    if (ks == 1) {
+#pragma unroll
+                        for (int x = NPA / 2; x < NPA; ++x) ISSUE_RA(x, slot_a2);
+                    }
                 }
                 mfmas(cb, ZERO && ks == 0);
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
+                for (int m = 0; m < NM; ++m) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if (ROLE == 2 && ks < 2 && m >= 6) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+                    if (m < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (ROLE == 2 && ks < 2 && m == NM - 2) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+                    if (ROLE == 2 && ks < 2 && m == NM - 1) __builtin_amdgcn_sched_group_barrier(0x010, NPA / 2 - 2, 0);
                 }
             }
             // K tile g+1 landed everywhere, every wave is done reading the LDS images of K tile g.  Pending ops of a B loader: B(g+1)
             // [, the stores of an epilogue that ran since]; of an A loader: A(g+1) [, those stores], A(g+2).
             {
-                constexpr int KEEP = ROLE == 1 ? 0 : 8;
+                constexpr int KEEP = ROLE == 1 ? 0 : NPA;
                 constexpr int SS = S + KEEP > 63 ? 63 - KEEP : S;
                 if (after_epi) CS_VMCNT(KEEP + SS);
                 else CS_VMCNT(KEEP);
@@ -865,25 +892,20 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             // order they are to issue: the compiler keeps LDS reads and LDS-DMA writes in program order (it cannot tell their slots apart)
             {
                 const int off = ((par8 | hf) ^ sw) << 4;
-#define CS_MID_STEP(X, LOAD)                         \
-                LOAD;                                \
-                if constexpr (ROLE == 1) ISSUE_RB(X, slot_b2);
-                CS_MID_STEP(0, fa[0][0] = *(const bf16x8*)(la_n + 0 * (16 * 256) + off))
-                CS_MID_STEP(1, fa[0][1] = *(const bf16x8*)(la_n + 1 * (16 * 256) + off))
-                CS_MID_STEP(2, fa[0][2] = *(const bf16x8*)(la_n + 2 * (16 * 256) + off))
-                CS_MID_STEP(3, fa[0][3] = *(const bf16x8*)(la_n + 3 * (16 * 256) + off))
-                CS_MID_STEP(4, fb[0][0] = *(const bf16x8*)(lb_n + 0 * (16 * 256) + off))
-                CS_MID_STEP(5, fb[0][1] = *(const bf16x8*)(lb_n + 1 * (16 * 256) + off))
-                CS_MID_STEP(6, (void)0)
-                CS_MID_STEP(7, (void)0)
-#undef CS_MID_STEP
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    if (x < FM) fa[0][x] = *(const bf16x8*)(la_n + x * (16 * 256) + off);
+                    else if (x < NR) fb[0][x - FM] = *(const bf16x8*)(lb_n + (x - FM) * (16 * 256) + off);
+                    if constexpr (ROLE == 1) ISSUE_RB(x, slot_b2);
+                }
             }
             mfmas(1, false);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
+            for (int m = 0; m < NM; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (m < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (ROLE == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                if (m < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (ROLE == 1 && m < NM - 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);          // 8 pieces over NM MFMAs:
+                if (ROLE == 1 && m == NM - 1) __builtin_amdgcn_sched_group_barrier(0x010, 1 + 8 - NM, 0);   // the rest behind the last one
             }
             if (ROLE == 1) adv_b();
             else adv_a();
@@ -922,18 +944,22 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             // of the next K iteration then keeps that iteration's DMA (which refills exactly these slots) behind all slab traffic.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            char* const slab = wave < 4 ? smem + (curA == 0 ? 2 : curA - 1) * A_BYTES + wave * 8192 : b_ring + (gpar ^ 1) * B_BYTES + (wave - 4) * 8192;
+            // 8 KB per wave: four in the B slot; four (192-row tiles: three, the fourth behind the rings -- 3 x 24 + 2 x 32 = 136 of 160 KB) in the A slot
+            char* const slab = wave >= 4 ? b_ring + (gpar ^ 1) * B_BYTES + (wave - 4) * 8192
+                               : (BM == 192 && wave == 3) ? b_ring + 2 * B_BYTES
+                                                          : smem + (curA == 0 ? 2 : curA - 1) * A_BYTES + wave * 8192;
             load_epi_ops(lane_e);
             if constexpr (RES) {
-                epi_resid_slab<LN, AUX, CP, F8, SPLIT>(p, acc, lane_e, row0, colw, tn, wn, eo, slab);
+                epi_resid_slab<LN, AUX, CP, F8, SPLIT, FM>(p, acc, lane_e, row0, colw, tn, wn, eo, slab);
             } else {
+                static_assert(FM == 4, "the slab forms of the bf16 / SwiGLU epilogues exist for 256-row tiles");
                 if constexpr (SWI) epi_swiglu_slab<LN, AUX, CP>(p, acc, lane_e, row0, tn, wn, eo, slab);
                 else epi_bf16_slab<epi_act(EPI), LN, CP>(p, acc, lane_e, row0, colw, eo, slab);
             }
         } else {
             load_epi_ops(lane_e);
-            if constexpr (SWI) epi_swiglu<LN, AUX, CP>(p, acc, lane_e, row0, tn, wn, eo);
-            else epi_bf16<epi_act(EPI), LN, CP, F8>(p, acc, lane_e, row0, colw, eo);
+            if constexpr (SWI) epi_swiglu<LN, AUX, CP, FM>(p, acc, lane_e, row0, tn, wn, eo);
+            else epi_bf16<epi_act(EPI), LN, CP, F8, FM>(p, acc, lane_e, row0, colw, eo);
         }
     }
     CS_VMCNT(0);      // the last two iterations' operand DMA (dead data, see adv_a) must not outlive the workgroup's LDS allocation
@@ -943,12 +969,12 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
 #undef ISSUE_RB
 }
 
-template <int EPI, bool LN, bool AUX, bool SLAB>
+template <int EPI, bool LN, bool AUX, bool SLAB, int BMT = 256>
 int launch_stream_v(const GemmArgs& a, unsigned grid, hipStream_t stream) {
     constexpr size_t lds = 160 * 1024;
-    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, LN, AUX, SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    static bool once = ((void)hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, LN, AUX, SLAB, false, 0, BMT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
-    hipLaunchKernelGGL((gemm_stream_kernel<EPI, LN, AUX, SLAB>), dim3(grid), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((gemm_stream_kernel<EPI, LN, AUX, SLAB, false, 0, BMT>), dim3(grid), dim3(512), lds, stream, a);
     CS_LAUNCH_CHECK();
     return 0;
 }
@@ -1020,9 +1046,23 @@ int cs_gemm_stream_launch(GemmArgs a, int epi, int reserve, hipStream_t stream) 
     } else if (a.stats_part || a.xb_out) return 1;
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = swi ? (a.group + 127) / 128 : (a.N + 255) / 256;
-    const long ntiles = (long)a.tiles_m * a.tiles_n;
+    long ntiles = (long)a.tiles_m * a.tiles_n;
     const long cap = cs_persistent_cap(reserve);
-    const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
+    unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
+    // 192-row tiles (plain epilogues of the training schedule): when the 256-row tiling leaves a large part of the last round of
+    // workgroups empty -- cost = rounds of the persistent grid x rows per tile; taken when it saves more than 10 %
+    if (!ln && !aux && !(a.dbg & 1) && a.M >= 192 && (swi || res || epi == EPI_BF16) && !getenv_flag("CS_NO_BM192")) {
+        const long t192 = (long)((a.M + 191) / 192) * a.tiles_n;
+        const long c256 = ((ntiles + cap - 1) / cap) * 256, c192 = ((t192 + cap - 1) / cap) * 192;
+        if (c192 * 10 < c256 * 9) {
+            a.tiles_m = (a.M + 191) / 192;
+            ntiles = t192;
+            grid = (unsigned)(ntiles < cap ? ntiles : cap);
+            if (swi) return launch_stream_v<EPI_SWIGLU_BF16, false, false, false, 192>(a, grid, stream);
+            if (res) return launch_stream_v<EPI_RESID_F32, false, false, true, 192>(a, grid, stream);
+            return launch_stream_v<EPI_BF16, false, false, false, 192>(a, grid, stream);
+        }
+    }
     if (swi) {
         if (ln) return aux ? launch_stream_t<EPI_SWIGLU_BF16, true, true>(a, grid, stream) : launch_stream_t<EPI_SWIGLU_BF16, true, false>(a, grid, stream);
         return aux ? launch_stream_t<EPI_SWIGLU_BF16, false, true>(a, grid, stream) : launch_stream_t<EPI_SWIGLU_BF16, false, false>(a, grid, stream);

@@ -529,6 +529,8 @@ class EvaEngine:
         x12 = None
         if keep or self.fp8_forward:
             x12 = ops.empty((M, 2 * Hd), BF16)
+            # (a W1|W2 epilogue that stores x1 | x2 AND silu(x1) * x2 was built and measured in round 4: 129.8 us against 112.3 us for GEMM +
+            # cs_swiglu_fwd at 12 608 rows -- the un-overlapped epilogue costs more than the HBM-rate elementwise pass it replaces)
             self._linear(i, "w12", ln2, w12, x12, b12, xq=q3)
             ops.swiglu_fwd(x12, hid)
         else:

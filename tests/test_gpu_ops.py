@@ -82,6 +82,45 @@ def test_gemm_f32_resid_strided(hip, ref, flags):
     check(f"gemm_f32_nobias flags={flags}", Cd2, Cr2, TOL_F32)
 
 
+@pytest.mark.parametrize("M,N,K", [(12608, 768, 768), (12608, 768, 2048), (12608, 768, 4096), (1000, 768, 256), (200, 256, 64), (12608, 4096, 768)])
+def test_gemm_192_row_tiles_equal_256_row_tiles_bit_for_bit(hip, M, N, K):
+    """Round 4: the streaming kernel's 192-row tile form (taken when the 256-row tiling fills the chip badly: the student's N = 768 GEMMs at
+    12 608 rows run 198 tiles instead of 150) accumulates every element in the same order: bf16, fp32-residual and
+    SwiGLU outputs equal the 256-row form (CS_NO_BM192=1) bit for bit."""
+    import os
+    A = rnd((M, K), BF, seed=60).cuda()
+    W = rnd((N, K), BF, 0.1, seed=61).cuda()
+    bias = rnd((N,), F32, 0.5, seed=62).cuda()
+    x0 = rnd((M, N), F32, seed=63).cuda()
+
+    def run():
+        out = {}
+        c = torch.full((M, N), float("nan"), dtype=BF, device="cuda")
+        hip.gemm_nt(A, W, c, bias, epi=0)
+        out["bf16"] = c
+        r = x0.clone()
+        hip.gemm_nt(A, W, r, bias, extra=r, epi=2)
+        out["resid"] = r
+        h = torch.full((M, N // 2), float("nan"), dtype=BF, device="cuda")
+        hip.gemm_nt(A, W, h, bias, epi=3, group=N // 2)
+        out["swiglu"] = h
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        os.environ["CS_NO_BM192"] = "1"
+        want = run()
+    finally:
+        os.environ.pop("CS_NO_BM192", None)
+    got = run()
+    assert set(got) == set(want)
+    for k in want:
+        a, b = got[k], want[k]
+        v = torch.int16 if a.element_size() == 2 else torch.int32
+        assert torch.equal(a.view(v), b.view(v)), f"{k} [{M},{N},{K}]"
+    check(f"gemm192.bf16[{M},{N},{K}]", got["bf16"], (A.float() @ W.float().T + bias).cpu(), TOL_BF)
+
+
 @pytest.mark.parametrize("flags", [0, 0x10, 0x20, 0x30, 0x70, 0x71, 0x8070, 0x90, 0xB0, 0x10B0])
 @pytest.mark.parametrize("Hd,M", [(2048, 394), (256, 34), (96, 130)])
 def test_gemm_swiglu(hip, ref, Hd, M, flags):
