@@ -541,6 +541,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     // behind them -- no wave ever sits behind a barrier with nothing but LDS latency in front of its next MFMA.  Operand lead: B(g+2)
     // goes out in k-step 3 of iteration g (its slot, B(g)'s, is free once every wave has passed the barrier of iteration g), A(g+2) in
     // k-steps 0-1.  Bit-identical outputs; q|k|v 1500 -> 1473 us, W1|W2 2308 -> 2288 us, step +0.4 % (profiles/r04_f_mid_barrier.txt).
+    // (Slab epilogues keep the top-of-tile barrier.  Their form of this schedule -- B(g+2) of an output tile's last K tile issued behind a
+    // barrier that follows the epilogue, because it lands in the B slab -- was built in round 4: with the fragment sets live across the K
+    // tiles the fp32-residual kernels, already at 241-252 VGPRs for their epilogue, spill 24-29 registers into the K loop.)
     constexpr bool MID = ROLES && !SLAB;
 #else
     constexpr bool MID = false;
