@@ -226,12 +226,60 @@ def pmc_traffic_per_launch(chunk_crops):
         return None, None
 
 
+def measure_traffic_live(chunk_crops, timeout_s=150):
+    """Fabric bytes of one dominant-kernel launch MEASURED in this run: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE: counters
+    only, no trace domain, one counter set per pass as MI355X_MICROARCH.md prescribes) over tools/raster_one.py, which launches exactly the
+    kernel the step's dominant launch is (same shape, same flags) a few times.  FETCH_SIZE x 2 (gfx950 correction for wide streaming
+    reads), both in KB.  Returns (bytes per launch, record) or (None, reason) -- any failure (no rocprofv3, timeout, unreadable result)
+    leaves the tracked constant in place."""
+    import shutil
+    import signal
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="cs_pmc_")
+        cmd = [exe, "--pmc", counter, "-d", tmp, "-o", "t", "--", sys.executable, str(ROOT / "tools" / "raster_one.py"), "0", str(chunk_crops), "3"]
+        try:
+            proc = subprocess.Popen(cmd, cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True,
+                                    env=dict(os.environ, TMPDIR=tmp))
+            try:
+                proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                return None, f"rocprofv3 --pmc {counter} timed out"
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(tmp) for f in fs if f.endswith(".db")]
+            if proc.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter}: rc {proc.returncode}, no result database"
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = [v for k, c, v in cur.execute("select kernel_name, counter_name, value from counters_collection")
+                    if c == counter and "gemm_stream_kernel<3" in k]
+            if not rows:
+                return None, f"rocprofv3 --pmc {counter}: the dominant kernel is not in the result"
+            vals[counter] = sum(rows) / len(rows)
+        except (OSError, sqlite3.Error) as e:
+            return None, f"rocprofv3 --pmc {counter}: {e}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    rec = {"fetch_kb": vals["FETCH_SIZE"], "write_kb": vals["WRITE_SIZE"], "chunk_crops": chunk_crops,
+           "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/raster_one.py, "
+                     "per-launch averages; FETCH_SIZE x 2 on gfx950"}
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="report roofline.traffic from the tracked PMC summary (profiles/pmc_traffic.json) instead of two rocprofv3 counter passes "
+                         "after the timed region (also: CLIPSELF_BENCH_NO_PMC=1)")
     ap.add_argument("--teacher-chunk", type=int, default=2048,
                     help="crops per teacher launch; 2048 = the whole batch of configs[1] in one pass (~7 GB of live activations)")
     ap.add_argument("--full-last-block", action="store_true",
@@ -369,6 +417,14 @@ def main():
         F = flops_per_image(cfg, CROPS, cls_only=not a.full_last_block)
         kt = timer.result()
         traffic, pmc = pmc_traffic_per_launch(min(a.teacher_chunk, BATCH * CROPS))
+        if world == 1 and not a.no_live_traffic and not a.no_cpu_baseline and os.environ.get("CLIPSELF_BENCH_NO_PMC") != "1":
+            # the default bench run re-measures the figure (after the timed region; ~40 s); the tracked constant stays as the fallback
+            torch.cuda.synchronize()
+            live, rec = measure_traffic_live(min(a.teacher_chunk, BATCH * CROPS))
+            if live is not None:
+                traffic, pmc = live, rec
+            elif pmc is not None:
+                pmc = dict(pmc, source=f"tracked constant profiles/pmc_traffic.json ({rec}); " + pmc.get("source", ""))
         out = {
             "metric": "images/sec (student+teacher distill step), ViT-B/16 32 crops/img",
             "value": ips, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -384,7 +440,7 @@ def main():
         if kt:
             out["roofline"] = {"bound": "mfma", "achieved": kt["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": kt["tflops"] / PEAK_BF16_TFLOPS,
-                               # HBM/fabric bytes per launch from the tracked PMC summary (not re-measured in this run)
+                               # fabric bytes per launch: two rocprofv3 counter passes after the timed region, or the tracked PMC summary (traffic_source says which)
                                "traffic": traffic, "traffic_source": (pmc or {}).get("source"),
                                "kernel": DOMINANT_KERNEL,
                                "launches": kt["launches"], "mean_us": kt["mean_us"], "flops_per_launch": kt["flops_per_launch"]}
