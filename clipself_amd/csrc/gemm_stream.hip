@@ -488,7 +488,7 @@ constexpr int epi_stores() {
 
 #define CS_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-inline bool getenv_flag(const char* name) {       // A/B switches read once per process
+inline bool getenv_flag(const char* name) {       // A/B switch, read at every launch (~0.1 us) so that a test can flip it inside one process
     const char* v = getenv(name);
     return v && v[0] && v[0] != '0';
 }
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     // a DMA piece stalls its wave for ~100 cycles beside LDS reads; with every wave issuing two pieces in every k-step (round 3) the two
     // waves of a SIMD stall together and the matrix pipe idles, now the stalled wave's partner has a k-step of MFMAs and LDS reads only.
     // Same tiles, same accumulation order: bit-identical outputs; step 704.7 -> 717.5 images/s on one box (profiles/r04_c_dma_roles.md).
-    constexpr bool ROLES = !F8;
+    constexpr bool ROLES = true;
 #else
     constexpr bool ROLES = false;
 #endif
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     // (Slab epilogues keep the top-of-tile barrier.  Their form of this schedule -- B(g+2) of an output tile's last K tile issued behind a
     // barrier that follows the epilogue, because it lands in the B slab -- was built in round 4: with the fragment sets live across the K
     // tiles the fp32-residual kernels, already at 241-252 VGPRs for their epilogue, spill 24-29 registers into the K loop.)
-    constexpr bool MID = ROLES && !SLAB;
+    constexpr bool MID = ROLES && !SLAB && !F8;
 #else
     constexpr bool MID = false;
 #endif
@@ -730,7 +730,17 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                         const i32x4 lo = *(const i32x4*)(lb + j * (16 * 256) + off0), hi = *(const i32x4*)(lb + j * (16 * 256) + off1);
                         b8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     }
-                    if (s2 == 0) {
+                    if constexpr (ROLE == 1) {              // B loaders: the whole B tile behind the first half's fragment reads
+                        if (s2 == 0) {
+#pragma unroll
+                            for (int x = 0; x < 8; ++x) ISSUE_RB(x, slot_b1);
+                        }
+                    } else if constexpr (ROLE == 2) {       // A loaders: the whole A tile behind the second half's
+                        if (s2 == 1) {
+#pragma unroll
+                            for (int x = 0; x < NPA; ++x) ISSUE_RA(x, slot_a2);
+                        }
+                    } else if (s2 == 0) {
                         ISSUE_B(0, slot_b1); ISSUE_B(1, slot_b1); ISSUE_B(2, slot_b1); ISSUE_B(3, slot_b1);
                     } else {
                         ISSUE_A(0, slot_a2); ISSUE_A(1, slot_a2); ISSUE_A(2, slot_a2); ISSUE_A(3, slot_a2);

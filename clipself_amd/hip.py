@@ -423,8 +423,11 @@ class HipOps:
         cached per list of buffers (the weight shadows and their transposes keep their addresses for the life of the engine)."""
         import numpy as np
         key = tuple((a.data_ptr(), b.data_ptr(), a.shape, b.shape, a.stride(0)) for a, b in pairs)
-        cache = getattr(self, "_tr_desc", None)
-        if cache is None or cache[0] != key:
+        tables = self.__dict__.setdefault("_tr_desc_tables", {})      # a few lists at most: every trainable block / a subset after a re-lock
+        cache = tables.get(key)
+        if cache is None:
+            if len(tables) >= 8:
+                tables.clear()
             rec = np.zeros((len(pairs), 6), dtype=np.int64)
             tile0 = 0
             for i, (a, b) in enumerate(pairs):
@@ -434,7 +437,7 @@ class HipOps:
                 tiles_x, tiles_y = (Cc + 63) // 64, (b.shape[1] + 63) // 64
                 rec[i] = (a.data_ptr(), b.data_ptr(), a.stride(0), b.shape[1], R | (Cc << 32), tile0 | (tiles_x << 32))
                 tile0 += tiles_x * tiles_y
-            cache = self._tr_desc = (key, torch.from_numpy(rec).cuda(), tile0)
+            cache = tables[key] = (key, torch.from_numpy(rec).cuda(), tile0)
         _, desc, total = cache
         self._ok(self.lib.cs_transpose_bf16_batched(_p(desc), len(pairs), total, self._stream()), "cs_transpose_bf16_batched")
 
