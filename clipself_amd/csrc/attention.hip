@@ -689,7 +689,7 @@ template <int HG>
 __global__ __launch_bounds__(256) void attn_cls_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ kv,
                                                        const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                        __bf16* __restrict__ out, int Ntok, int H, int ldq, int ldkv, int ldo, float scale) {
-    extern __shared__ float sm[];                 // [HG][Npad] scores -> probabilities | [HG] row sums | [32][HG*64] partial outputs
+    extern __shared__ float sm[];                 // [HG][Npad] scores -> probabilities | [HG] row sums | [4 waves][HG*64] partial outputs
     const int Npad = (Ntok + 3) & ~3;
     float* rsum = sm + HG * Npad;
     float* part = rsum + 8;
@@ -760,15 +760,21 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const __bf16* __restrict_
             for (int j = 0; j < 8; ++j) acc[h][j] += pk * bf2f(vv[h].e[j]);
         }
     }
+    // the 8 key slots of a wave (lanes 8 apart) are combined in registers; only one partial row per wave crosses the LDS (round 4: 6 KB
+    // instead of 48 KB of partials -- the kernel is a pure K / V stream and ran two workgroups per CU, 3.1 TB/s)
 #pragma unroll
     for (int h = 0; h < HG; ++h)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) part[kg * (HG * HD) + h * HD + c * 8 + j] = acc[h][j];
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[h][j];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 8) part[wave * (HG * HD) + h * HD + c * 8 + j] = v;
+        }
     __syncthreads();
     for (int o = tid; o < HG * HD; o += 256) {
-        float v = 0.f;
-#pragma unroll 8
-        for (int g = 0; g < 32; ++g) v += part[g * (HG * HD) + o];
+        const float v = (part[o] + part[HG * HD + o]) + (part[2 * HG * HD + o] + part[3 * HG * HD + o]);
         out[(size_t)b * ldo + h0 * HD + o] = f2bf(v / rsum[o / HD]);
     }
 }
@@ -870,7 +876,7 @@ extern "C" int cs_attn_cls_fwd(const void* q, const void* kv, const float* cos_t
                  "cs_attn_cls_fwd: row strides must be multiples of 8 and cover the heads (ldq=%d ldkv=%d ldo=%d)", ldq, ldkv, ldo);
     CS_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0, "cs_attn_cls_fwd: q/kv must be 16-byte aligned");
     const int HG = H % 6 == 0 ? 6 : (H % 4 == 0 ? 4 : (H % 3 == 0 ? 3 : (H % 2 == 0 ? 2 : 1)));
-    const size_t lds = ((size_t)HG * ((Ntok + 3) & ~3) + 8 + (size_t)32 * HG * HD) * sizeof(float);
+    const size_t lds = ((size_t)HG * ((Ntok + 3) & ~3) + 8 + (size_t)4 * HG * HD) * sizeof(float);
     CS_CHECK_ARG(lds <= 160 * 1024, "cs_attn_cls_fwd: Ntok=%d too large", Ntok);
     const dim3 grid(B, H / HG), block(256);
 #define CS_CLS_LAUNCH(G)                                                                                                      \
