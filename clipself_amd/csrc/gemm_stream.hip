@@ -540,7 +540,7 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     // k-step 3 are in its registers, so the eight MFMAs of that k-step start at once and the first fragments of the NEXT K tile are read
     // behind them -- no wave ever sits behind a barrier with nothing but LDS latency in front of its next MFMA.  Operand lead: B(g+2)
     // goes out in k-step 3 of iteration g (its slot, B(g)'s, is free once every wave has passed the barrier of iteration g), A(g+2) in
-    // k-steps 0-1.  Bit-identical outputs; q|k|v 1500 -> 1473 us, W1|W2 2308 -> 2288 us, step +0.4 % (profiles/r04_f_mid_barrier.txt).
+    // k-steps 1-2.  Bit-identical outputs; q|k|v 1500 -> 1473 us, W1|W2 2308 -> 2288 us, step +0.4 % (profiles/r04_f_mid_barrier.txt).
     // (Slab epilogues keep the top-of-tile barrier.  Their form of this schedule -- B(g+2) of an output tile's last K tile issued behind a
     // barrier that follows the epilogue, because it lands in the B slab -- was built in round 4: with the fragment sets live across the K
     // tiles the fp32-residual kernels, already at 241-252 VGPRs for their epilogue, spill 24-29 registers into the K loop.)
@@ -871,12 +871,15 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
             for (int ks = 0; ks < 3; ++ks) {
                 const int cb = ks & 1;
                 frags(la, lb, ks + 1, cb ^ 1);
-                if constexpr (ROLE == 2) {                 // A(g+2): its NPA pieces in k-steps 0 and 1
-                    if (ks == 0) {
+                // A(g+2) goes out in k-steps 1 and 2: away from the B loaders' k-step 3 burst, which runs into k-step 0 of their SIMD partners
+                // (k-steps 0 and 1: 720.9 -> 724.2 images/s same box, dominant kernel 2360 -> 2331 us; profiles/r04_o_a_pieces_late.txt)
+                constexpr int KA = 1;
+                if constexpr (ROLE == 2) {                 // A(g+2): its NPA pieces in k-steps KA and KA + 1
+                    if (ks == KA) {
 #pragma unroll
                         for (int x = 0; x < NPA / 2; ++x) ISSUE_RA(x, slot_a2);
                     }
-                    if (ks == 1) {
+                    if (ks == KA + 1) {
 #pragma unroll
                         for (int x = NPA / 2; x < NPA; ++x) ISSUE_RA(x, slot_a2);
                     }
@@ -886,8 +889,8 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                 for (int m = 0; m < NM; ++m) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     if (m < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if (ROLE == 2 && ks < 2 && m == NM - 2) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
-                    if (ROLE == 2 && ks < 2 && m == NM - 1) __builtin_amdgcn_sched_group_barrier(0x010, NPA / 2 - 2, 0);
+                    if (ROLE == 2 && (ks == KA || ks == KA + 1) && m == NM - 2) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+                    if (ROLE == 2 && (ks == KA || ks == KA + 1) && m == NM - 1) __builtin_amdgcn_sched_group_barrier(0x010, NPA / 2 - 2, 0);
                 }
             }
             // K tile g+1 landed everywhere, every wave is done reading the LDS images of K tile g.  Pending ops of a B loader: B(g+1)
