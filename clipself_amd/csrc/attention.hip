@@ -15,6 +15,7 @@
 //     (conflict-free ds_read_b128), V as V^T [64][keys+4] (8-byte reads, odd dword stride -> conflict free).
 //   * keys are consumed in chunks of CH*32 with an online softmax, so any sequence length works; for the
 //     14x14(+CLS) grid a single chunk of 224 covers all 197 keys and no rescale is ever taken.
+#include <vector>
 #include "cs_common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -107,7 +108,15 @@ struct AttnArgs {
     float* lse_out;        // fwd (nullable)
     int Ntok, H, ldqkv, ldo;
     float scale;
+#ifdef CS_ABLATION_SWITCHES
+    unsigned long long* trace;   // env CS_ATTN_TRACE=<file>: per workgroup 8 x u64 (HW_ID, XCC_ID, 100 MHz clock at entry / tables / images / attended / end)
+#endif
 };
+#ifdef CS_ABLATION_SWITCHES
+#define ATT_TRACE(slot) do { if (p.trace && threadIdx.x == 0) p.trace[(size_t)blockIdx.y * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ATT_TRACE(slot) do { } while (0)
+#endif
 
 // stage `rows` token rows (tok0..) of one head column block into a swizzled [rows][64] LDS tile (+ optional transposed copy)
 template <int CHK, bool ROPE, bool WITH_T>
@@ -393,6 +402,19 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
     const size_t rowbase = (size_t)b * p.Ntok;
     const float sl2 = p.scale * LOG2E;
     const int last = p.Ntok - 1;
+#ifdef CS_ABLATION_SWITCHES
+    {   // timeline experiments (profiles/r04_t_attention_timeline.md): a subset of the first residents starts (dbg >> 8) x ~4.3 us late
+        // (64: odd ids, 128: every second CU, else ids 256..511); CS_ATTN_TRACE: where and when every workgroup ran
+        const int n = (p.dbg >> 8) & 0xff, id = blockIdx.y;
+        const bool late = (p.dbg & 64) ? (id & 1) && id < 512 : (p.dbg & 128) ? ((id >> 3) & 1) && id < 512 : id >= 256 && id < 512;
+        if (n && late) for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+        if (p.trace && threadIdx.x == 0) {
+            p.trace[(size_t)id * 8 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+            p.trace[(size_t)id * 8 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+        }
+    }
+#endif
+    ATT_TRACE(2);
     // every global load of the workgroup ahead of the first dependent instruction: tables (oldest: vmcnt retires in order), K, V, Q
     float tab[4];
     {
@@ -428,6 +450,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
         rt[(3 * p.grid << 5) + tid] = tab[3];
     }
     __syncthreads();
+    ATT_TRACE(3);
 #pragma unroll
     for (int it = 0; it < KI; ++it) {      // K: rotate + swizzled LDS image
         const int idx = tid + it * NT, r = idx >> 3, c = idx & 7;
@@ -447,6 +470,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
         }
     }
     __syncthreads();
+    ATT_TRACE(4);
     if (q0 >= p.Ntok) return;
     bf16x8 qf[4];
 #pragma unroll
@@ -466,7 +490,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
         if (p.Ntok > 96) attend_chunk<3, false>(Kl, Vt, qf, 96, p.Ntok, sl2, lane, false, m, l, o, 3);
         if (p.Ntok > 192) attend_chunk<1, false>(Kl, Vt, qf, 192, p.Ntok, sl2, lane, false, m, l, o, 6);
     }
+    ATT_TRACE(5);
     if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
+    ATT_TRACE(6);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -796,6 +822,15 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
 #ifdef CS_ABLATION_SWITCHES
     static const int dbg_env = getenv("CS_ATTN_DBG") ? atoi(getenv("CS_ATTN_DBG")) : 0;
     a.dbg = dbg_env;
+    static const char* trace_path = getenv("CS_ATTN_TRACE");
+    static unsigned long long* trace_buf = nullptr;
+    static size_t trace_cap = 0;
+    if (trace_path && trace_cap < (size_t)B * H * 64) {
+        if (trace_buf) (void)hipFree(trace_buf);
+        trace_cap = (size_t)B * H * 64;
+        if (hipMalloc((void**)&trace_buf, trace_cap) != hipSuccess) { trace_buf = nullptr; trace_cap = 0; }
+    }
+    a.trace = trace_buf;
 #else
     a.dbg = 0;
 #endif
@@ -822,6 +857,14 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
         hipLaunchKernelGGL((attn_fwd_kernel<CH>), dim3((Ntok + 255) / 256, B * H), dim3(512), lds, stream, a);
     }
     CS_LAUNCH_CHECK();
+#ifdef CS_ABLATION_SWITCHES
+    if (a.trace && Ntok <= CH * 32) {     // the LAST launch's timeline survives in the file
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> host((size_t)B * H * 8);
+        (void)hipMemcpy(host.data(), a.trace, host.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(trace_path, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+    }
+#endif
     return 0;
 }
 

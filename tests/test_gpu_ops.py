@@ -326,6 +326,35 @@ def test_attention_fwd_bwd(hip, ref, B, Ntok, H, qscale):
     check(tag + ".dv", dq_d[:, 2 * C:], dq_r[:, 2 * C:], 1.5e-2)
 
 
+@pytest.mark.parametrize("B,Ntok,H", [(120, 197, 12), (700, 17, 2), (90, 65, 12)])
+def test_attention_units_are_launch_size_invariant(hip, B, Ntok, H):
+    """A (crop, head) unit's result must not depend on the size of the launch it is part of (more units than resident workgroups: 12
+    rounds of 512): every sampled crop of a large launch equals, bit for bit, the same crop attended in a launch of its own; the statistics
+    partials and the lse too.  (Round 4 built a unit-loop form of attn_fwd8_kernel -- two workgroups per CU walking the units, the next
+    unit's rows requested behind the last P.V -- that this test pinned; measured a tie, not kept: profiles/r04_t_attention_timeline.md.)"""
+    C = H * 64
+    qkv = rnd((B * Ntok, 3 * C), BF, 1.0, seed=33).cuda()
+    cos, sin = (t.cuda() for t in _rope(Ntok, 0))
+    scale = 64 ** -0.5
+    o = torch.full((B * Ntok, C), float("nan"), dtype=BF, device="cuda")
+    lse = torch.full((B * H, Ntok), float("nan"), device="cuda")
+    part = torch.full((H, B * Ntok, 2), float("nan"), device="cuda")
+    hip.attn_fwd_stats(qkv, cos, sin, o, lse, part, B, Ntok, H, scale)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all() and torch.isfinite(part).all()
+    for b in (0, 1, B // 2, B - 2, B - 1):
+        rows = slice(b * Ntok, (b + 1) * Ntok)
+        o1 = torch.empty(Ntok, C, dtype=BF, device="cuda")
+        lse1 = torch.empty(H, Ntok, device="cuda")
+        part1 = torch.empty(H, Ntok, 2, device="cuda")
+        hip.attn_fwd_stats(qkv[rows].contiguous(), cos, sin, o1, lse1, part1, 1, Ntok, H, scale)
+        assert torch.equal(o1, o[rows]), f"crop {b}: output differs from the single-crop launch"
+        assert torch.equal(lse1, lse[b * H:(b + 1) * H])
+        assert torch.equal(part1, part[:, rows])
+    o2 = torch.empty_like(o)                            # repeated launch: same bits
+    hip.attn_fwd(qkv, cos, sin, o2, None, B, Ntok, H, scale)
+    assert torch.equal(o2, o)
+
+
 @pytest.mark.parametrize("B,Ntok,H,qscale", [(5, 197, 12, 1.0), (3, 17, 2, 3.0), (2, 577, 16, 2.0), (2, 785, 3, 4.0)])
 def test_attention_cls_query(hip, ref, B, Ntok, H, qscale):
     """cs_attn_cls_fwd (teacher's last block: CLS query only) against the reference op and against the CLS rows of the
