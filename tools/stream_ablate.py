@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Main loop / epilogue split of the streaming GEMM on the tower shapes: cs_gemm_nt schedule 11 with the timing ablations of a
 -DCS_ABLATION_SWITCHES build (dbg 4 = no epilogue, dbg 8 = every store masked, dbg 2 = no barrier; wrong results by construction).
-usage (GPU box): CLIPSELF_HIP_LIB=<ablation build> python tools/stream_ablate.py [crops=2048] [tag]"""
+env ABLATE_DBG (list of dbg values), ABLATE_RESERVE (compute units left free: grid = 256 - reserve; is the epilogue's cost per CU or per chip?),
+ABLATE_SHAPES (substring filter).   usage (GPU box): CLIPSELF_HIP_LIB=<ablation build> python tools/stream_ablate.py [crops=2048] [tag]"""
 import os
 import sys
 from pathlib import Path
@@ -21,7 +22,11 @@ def main():
     M = crops * 197
     shapes = [("qkv N=2304 K=768 epi0", 2304, 768, 0), ("proj N=768 K=768 epi2", 768, 768, 2),
               ("w12 N=4096 K=768 epi3", 4096, 768, 3), ("w3 N=768 K=2048 epi2", 768, 2048, 2)]
+    reserve = int(os.environ.get("ABLATE_RESERVE", "0"))
+    only = os.environ.get("ABLATE_SHAPES", "")
     for name, N, K, epi in shapes:
+        if only and not any(o in name for o in only.split(",")):
+            continue
         A = torch.randn(M, K, device="cuda").to(BF)
         B = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
         bias = torch.randn(N, device="cuda")
@@ -32,9 +37,9 @@ def main():
             extra, group = C, 0
         else:
             C, extra, group = torch.empty(M, N // 2, dtype=BF, device="cuda"), None, N // 2
-        line = f"[{tag}] {name}:"
+        line = f"[{tag} reserve={reserve}] {name}:"
         for dbg in [int(x) for x in os.environ.get("ABLATE_DBG", "0,4,8,0,4").split(",")]:
-            flags = (11 << 4) | (8 << 8) | (dbg << 12)
+            flags = (11 << 4) | (8 << 8) | (dbg << 12) | (reserve << 20)
             for _ in range(2):
                 ops.gemm_nt(A, B, C, bias, extra, epi=epi, group=group, flags=flags)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
