@@ -388,7 +388,7 @@ class EvaEngine:
         for k, name in enumerate(names):
             o, s = self.offsets[name]
             i = self.block_index(name)
-            if "._" in name or (i is None and not self.train_all) or (i is not None and (i < self.first_trainable or self._never_reached(i, name))):
+            if "._" in name or (i is None and not self._nonblock_trains(name)) or (i is not None and (i < self.first_trainable or self._never_reached(i, name))):
                 continue
             n = math.prod(s)
             nxt = self.offsets[names[k + 1]][0] if k + 1 < len(names) else self.numel
@@ -406,10 +406,18 @@ class EvaEngine:
         if self.fp8_forward and self.fp8_dgrad:
             self.sync_fp8(range(self.first_trainable, self.cfg.layers))
 
+    def _nonblock_trains(self, name):
+        """Does a tensor outside the blocks (stem, final norm, head) train?  EVA02: only without --lock-image (set_trainable_all)."""
+        return self.train_all
+
+    def _pos_trains(self):
+        return self.train_all
+
     def trainable_names(self):
         if self.train_all:
             return self.public_names()
-        return [n for n in self.public_names() if (self.block_index(n) if self.block_index(n) is not None else -1) >= self.first_trainable]
+        return [n for n in self.public_names()
+                if (self.block_index(n) >= self.first_trainable if self.block_index(n) is not None else self._nonblock_trains(n))]
 
     def bucket_range(self, key):
         """Flat [begin, end) of a gradient bucket: a block index, "head" (final norm + head) or "stem" (cls_token, pos_embed, patch embedding)."""
@@ -946,7 +954,7 @@ class EvaEngine:
         self.ops.adamw_step(self.master, self.grad, self.exp_avg, self.exp_avg_sq, self.shadow, self.flags,
                             lr, beta1, beta2, eps, wd, step, grad_scale)
         self.sync_transposed()
-        if self.train_all:
+        if self._pos_trains():
             self._pos_cache.clear()                # pos_embed moved: drop the rescaled copies of non-native grids
         if self.fp8_forward:
             self.sync_fp8(range(self.first_trainable, self.cfg.layers))

@@ -10,6 +10,7 @@ does each stage (paths under /root/reference/src/open_clip/):
   image head      transformer.py:486-494     ln_post(x[:,0]) @ proj
   dense head      transformer.py:576-587     normalize(ln_post(x[:,1:]) @ proj)
   lock            transformer.py:391-422     groups = [stem, positional_embedding, blocks..., last block]; the last n train
+                                             (n > L: positional_embedding, then conv1 / class_embedding / ln_pre: _stem_bwd)
 
 The frozen teacher uses the EVA02 engine's schedule tricks unchanged: CLS-query-only last block, ln_1 / ln_2 folded into the in_proj / c_fc
 GEMMs with the residual GEMMs emitting the bf16 copy and the row statistics of the stream (`_teacher_block_folded`).
@@ -60,6 +61,8 @@ class ClipVitEngine(EvaEngine):
         # CLS query only (forward() consumes x[:, 0] alone, transformer.py:486-494).  Same switches as the EVA02 engine.
         self.fold_block_ln = not trainable
         self.cls_only_last_block = True
+        # lock() with more groups than blocks (transformer.py:391-422): 1 = positional_embedding trains, 2 = conv1 / class_embedding / ln_pre too
+        self.stem_level = 0
 
     def _layout(self):
         return clip_vit_layout(self.cfg, self.prefix)
@@ -103,16 +106,25 @@ class ClipVitEngine(EvaEngine):
                 self.fold[i] = out
 
     def set_trainable_blocks(self, unlocked_groups: int):
-        """VisionTransformer.lock (transformer.py:391-422): of [stem, positional_embedding, block 0 .. L-1] the last n groups train;
-        n = 0 freezes everything.  Unlocking the positional embedding or the stem (n > L) is not part of any CLIPSelf recipe."""
+        """VisionTransformer.lock (transformer.py:391-422): of the groups [[conv1, class_embedding, ln_pre], positional_embedding, block 0 ..
+        L-1] the last n train; n = 0 freezes everything, n = L + 1 adds the positional embedding, n >= L + 2 the stem (a slice longer than
+        the list is the whole list).  ln_post and proj never train in this family (:405-408)."""
         L = self.cfg.layers
-        if unlocked_groups > L:
-            raise NotImplementedError(f"unlocked_groups={unlocked_groups} > {L}: training positional_embedding / conv1 / ln_pre is not supported")
-        super().set_trainable_blocks(unlocked_groups)
+        self.stem_level = min(max(unlocked_groups - L, 0), 2)
+        super().set_trainable_blocks(min(unlocked_groups, L))
         if unlocked_groups <= 0:
             self.first_trainable = L
             if self.trainable:
                 self.flags.zero_()
+
+    def _nonblock_trains(self, name):
+        tail = name[len(self.prefix):]
+        if tail == "positional_embedding":
+            return self.stem_level >= 1
+        return self.stem_level >= 2 and tail in ("conv1.weight", "class_embedding", "ln_pre.weight", "ln_pre.bias")
+
+    def _pos_trains(self):
+        return self.stem_level >= 1
 
     # ------------------------------------------------------------------------------------------ tables
     def rope_tables(self, grid: int):
@@ -136,7 +148,8 @@ class ClipVitEngine(EvaEngine):
         return self._pos_cache[grid]
 
     # ------------------------------------------------------------------------------------------ forward pieces
-    def _stem(self, images):
+    def _stem(self, images, keep=None):
+        """keep (dict, stem_level > 0): the im2row matrix, ln_pre's input and row statistics for _stem_bwd."""
         ops, cfg, P = self.ops, self.cfg, self.prefix
         B, _, S, _ = images.shape
         p, C = cfg.patch_size, cfg.width
@@ -149,7 +162,11 @@ class ClipVitEngine(EvaEngine):
         ops.gemm_nt(A, self.storage_of(self.shadow, P + "conv1.weight"), x.view(B * N, C), extra=pos, epi=EPI_PATCH_F32, group=g * g)
         ops.cls_row(x, self.p[P + "class_embedding"], pos)
         y = ops.empty((B, N, C), F32)                       # ln_pre's output is the residual stream
-        ops.layernorm_fwd_f32(x.view(B * N, C), self.p[P + "ln_pre.weight"], self.p[P + "ln_pre.bias"], y.view(B * N, C), None, None, cfg.ln_eps)
+        mean = rstd = None
+        if keep is not None:
+            mean, rstd = ops.empty((B * N,), F32), ops.empty((B * N,), F32)
+            keep.update(patches=A, x_pre=x.view(B * N, C), st=(mean, rstd))
+        ops.layernorm_fwd_f32(x.view(B * N, C), self.p[P + "ln_pre.weight"], self.p[P + "ln_pre.bias"], y.view(B * N, C), mean, rstd, cfg.ln_eps)
         return y, g
 
     def _block_fwd(self, i, x, B, N, cos, sin, with_attn=True, save=None, inplace=True):
@@ -291,7 +308,8 @@ class ClipVitEngine(EvaEngine):
     def encode_dense(self, images, need_grad: bool = False):
         ops, cfg, P = self.ops, self.cfg, self.prefix
         B = images.shape[0]
-        x, g = self._stem(images)
+        stem_keep = {} if (need_grad and self.stem_level > 0) else None
+        x, g = self._stem(images, stem_keep)
         N, C, E = g * g + 1, cfg.width, cfg.embed_dim
         cos, sin = self.rope_tables(g)
         xf = x.view(B * N, C)
@@ -313,7 +331,7 @@ class ClipVitEngine(EvaEngine):
         inv = ops.empty((M,), F32)
         ops.l2norm_fwd(feats, dense, inv)
         if need_grad:
-            self._ctx = dict(B=B, N=N, g=g, saves=saves, xL=xf, stf=(mean, rstd), dense=dense, inv=inv, cos=cos, sin=sin)
+            self._ctx = dict(B=B, N=N, g=g, saves=saves, xL=xf, stf=(mean, rstd), dense=dense, inv=inv, cos=cos, sin=sin, stem=stem_keep)
         return dense.view(B, N, E), g
 
     # ------------------------------------------------------------------------------------------ backward
@@ -381,3 +399,35 @@ class ClipVitEngine(EvaEngine):
             self._block_bwd(i, c["saves"].pop(i), g, gb, B, N, c["cos"], c["sin"], ws, next_bias=cproj_bias(i - 1) if i > 0 else None)
             if self.grad_ready_hook is not None:
                 self.grad_ready_hook(i)
+        if c["stem"] is not None:
+            self._stem_bwd(g, c["stem"], B, N, c["g"], ws[0])
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook("stem")
+
+    def _stem_bwd(self, g, keep, B, N, grid, ws):
+        """Gradients of the stem from g = d loss / d (ln_pre output) fp32 [B*N, C]  (transformer.py:551-569: x = ln_pre(cat(class_embedding,
+        conv1(img)) + positional_embedding)).  ln_pre backward (its gamma / beta at stem level 2), then: positional_embedding <- sum over images
+        (through the bicubic rescale for a non-native grid, :724-734), class_embedding <- the CLS rows, conv1.weight <- dY^T . im2row(images) (no
+        bias).  Once per step on [B*N, C]; the row bookkeeping is tensor code, the LayerNorm backward and the contraction are the kernels."""
+        ops, cfg, P = self.ops, self.cfg, self.prefix
+        C, M = cfg.width, B * N
+        lvl2 = self.stem_level >= 2
+        d_pre = ops.empty((M, C), F32)
+        ops.layernorm_bwd(g.to(BF16), keep["x_pre"], self.p[P + "ln_pre.weight"], *keep["st"], d_pre, DX_F32_ASSIGN,
+                          self.g[P + "ln_pre.weight"] if lvl2 else None, self.g[P + "ln_pre.bias"] if lvl2 else None, True, ws)
+        d3 = d_pre.view(B, N, C)
+        d_pos = d3.sum(dim=0)                                                    # [N, C]
+        gpos = self.g[P + "positional_embedding"]                                # [native N, C]
+        if grid == cfg.grid:
+            gpos.add_(d_pos)
+        else:
+            gpos[0].add_(d_pos[0])
+            with torch.enable_grad():
+                pe = self.p[P + "positional_embedding"].detach()[1:].T.reshape(1, C, cfg.grid, cfg.grid).clone().requires_grad_(True)
+                out = F.interpolate(pe, (grid, grid), mode="bicubic", align_corners=False)
+                (d_pe,) = torch.autograd.grad(out, pe, d_pos[1:].T.reshape(1, C, grid, grid))
+            gpos[1:].add_(d_pe.reshape(C, cfg.grid * cfg.grid).T)
+        if lvl2:
+            self.g[P + "class_embedding"].view(C).add_(d_pos[0])
+            gp = d3[:, 1:, :].to(BF16).reshape(B * (N - 1), C)                   # patch rows, in the im2row matrix's row order
+            self._wgrad(gp, keep["patches"], self.storage_of(self.grad, P + "conv1.weight"))

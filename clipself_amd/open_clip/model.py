@@ -124,7 +124,7 @@ class EVAVisionTower(_Node):
         first = self.engine.first_trainable
         for full, p in self._flat.items():
             blk = self.engine.block_index(full)
-            p.requires_grad = blk is not None and blk >= first
+            p.requires_grad = blk >= first if blk is not None else self.engine._nonblock_trains(full)
 
     def unlock(self):
         """Undo lock(): the whole tower trains again (the state a freshly built model is in, like the reference's)."""
@@ -322,7 +322,8 @@ class CustomCLIP(nn.Module):
 class ClipVisionTower(EVAVisionTower):
     """`model.visual` of the OpenAI-CLIP family: class/positional embeddings, ln_pre, fused-QKV blocks with a GELU MLP, ln_post, proj."""
     ENGINE = ClipVitEngine
-    UNLOCKED_TRAINS_ALL = False                # conv1 / class + positional embeddings / ln_pre / ln_post / proj stay frozen in this family
+    UNLOCKED_TRAINS_ALL = False                # lock() unlocks at most stem + positional embedding + blocks (transformer.py:391-422); training
+                                               # ln_post / proj too (no --lock-image at all) is not built for this family
 
     def __init__(self, cfg: TowerCfg, ops=None, trainable: bool = True, teacher_chunk: int = 2048):
         super().__init__(cfg, ops=ops, trainable=trainable, teacher_chunk=teacher_chunk)
@@ -341,7 +342,8 @@ class ClipVisionTower(EVAVisionTower):
         pass                                                # no rotary tables in this family
 
     def lock(self, unlocked_groups=0, freeze_bn_stats=False):
-        """transformer.py:391-422: of [stem, positional_embedding, block 0 .. L-1] the last `unlocked_groups` train (0 = all frozen)."""
+        """transformer.py:391-422: of [[conv1, class_embedding, ln_pre], positional_embedding, block 0 .. L-1] the last `unlocked_groups`
+        train (0 = all frozen; L + 1 adds the positional embedding, >= L + 2 the stem: ClipVitEngine._stem_bwd)."""
         super().lock(unlocked_groups=unlocked_groups, freeze_bn_stats=freeze_bn_stats)
 
 

@@ -298,6 +298,37 @@ def gen_tiny_openai(oc):
     np.savez_compressed(GOLD / "tiny_openai_step.npz", **blob)
 
 
+def gen_tiny_openai_stem(oc):
+    """VisionTransformer.lock with more groups than blocks (transformer.py:391-422: groups = [[conv1, class_embedding, ln_pre],
+    positional_embedding, block 0 .. L-1]): L + 1 unlocks the positional embedding, L + 2 the stem as well; ln_post / proj stay frozen.
+    One step at L + 1, three at L + 2 (native grid), one at L + 2 on a 64-px image (gradient through the bicubic rescale of the
+    positional embedding, transformer.py:724-734)."""
+    cfg = tiny_openai_cfg()
+    L = cfg.layers
+    blob = {}
+    for tag, unlocked, steps, size in (("pos/", L + 1, 1, cfg.image_size), ("stem/", L + 2, 3, cfg.image_size), ("stem64/", L + 2, 1, 64)):
+        rec = dict(TINY, seed_w=3, seed_b=41, steps=steps, unlocked=unlocked)
+        student, teacher, out, first, groups = _run_steps(oc, cfg, rec, size, cfg.image_size, build=_build_openai)
+        blob[tag + "losses"] = np.array(out["losses"], np.float64)
+        blob[tag + "lrs"] = np.array(out["lrs"], np.float64)
+        blob[tag + "groups"] = np.array(json.dumps({n: k for n, k in groups.items() if n.startswith("visual.")}))
+        blob[tag + "recipe"] = np.array(json.dumps(dict(rec, image_size=size)))
+        none = []
+        for n, g in first["grads"].items():
+            if g is None:
+                none.append(n)
+            elif n.startswith("visual.") and (".resblocks." not in n or n.endswith(("resblocks.0.ln_1.weight", "resblocks.0.attn.in_proj_weight",
+                                                                                   "resblocks.1.mlp.c_fc.weight"))):
+                blob[tag + "grad/" + n] = g.numpy()
+        blob[tag + "grad_none"] = np.array(none)
+        if steps > 1:
+            for n, p in student.named_parameters():
+                if n.startswith("visual.") and p.requires_grad and ".resblocks." not in n:
+                    blob[tag + "final/" + n] = p.detach().numpy()
+        print("tiny openai", tag, "losses", out["losses"], "trainable", sorted(n for n, k in groups.items() if k != "frozen" and ".resblocks." not in n))
+    np.savez_compressed(GOLD / "tiny_openai_stem.npz", **blob)
+
+
 def gen_vitb16(oc):
     """OpenAI-CLIP ViT-B/16 at BASELINE cfg-1 size (2 images x 8 boxes, 224^2), nn.GELU variant (`--pretrained ''` path of the factory):
     loss trajectory, feature slices, every gradient norm."""
@@ -547,8 +578,12 @@ def main():
     if "--curve-only" in sys.argv:
         gen_curve(oc)
         return
+    if "--openai-stem-only" in sys.argv:
+        gen_tiny_openai_stem(oc)
+        return
     if "--openai-only" in sys.argv:
         gen_tiny_openai(oc)
+        gen_tiny_openai_stem(oc)
         if "--tiny-only" not in sys.argv:
             gen_vitb16(oc)
         return
@@ -568,6 +603,7 @@ def main():
     gen_regionclip(oc)
     gen_curve(oc)
     gen_tiny_openai(oc)
+    gen_tiny_openai_stem(oc)
     gen_zeroshot(oc)
     gen_params(oc)
     gen_schedules(oc)

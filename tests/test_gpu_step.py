@@ -547,6 +547,60 @@ def test_tiny_openai_vit_step_matches_reference_goldens(golden_dir, quick):
         assert rel(w["visual.transformer.resblocks.0.mlp.c_fc.weight"], g["final/visual.transformer.resblocks.0.mlp.c_fc.weight"]) < 2e-2
 
 
+@pytest.mark.parametrize("tag", ["pos/", "stem/", "stem64/"])
+def test_tiny_openai_vit_stem_groups_match_reference_goldens(golden_dir, tag):
+    """`lock_image_tower(unlocked_groups > layers)` of the OpenAI-CLIP family (transformer.py:391-422): the positional embedding (L + 1
+    groups) and conv1 / class_embedding / ln_pre (L + 2) train.  HIP path through the public API -- optimizer groups, first-step gradients,
+    three-step trajectory and updated stem parameters against the real reference, native grid and the rescaled 8x8 grid."""
+    from clipself_amd.config import tiny_openai_cfg
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.scheduler import cosine_lr
+    from clipself_amd.training.train import train_step
+    g = np.load(golden_dir / "tiny_openai_stem.npz")
+    rec = json.loads(str(g[tag + "recipe"]))
+    cfg = tiny_openai_cfg()
+    student, teacher = _pair_openai(cfg, rec["seed_w"])
+    student.lock_image_tower(unlocked_groups=rec["unlocked"])
+    assert type(student.visual.engine.ops).__name__ == "HipOps" and student.visual.engine.stem_level == (1 if tag == "pos/" else 2)
+    groups = json.loads(str(g[tag + "groups"]))
+    named = dict(student.named_parameters())
+    for n, kind in groups.items():
+        assert named[n].requires_grad == (kind != "frozen"), n
+    opt = FlatAdamW(student, lr=rec["lr"], betas=(0.9, 0.999), eps=1e-8, weight_decay=rec["wd"])
+    decay = {id(p) for p in opt.param_groups[1]["params"]}
+    for n, kind in groups.items():
+        if kind != "frozen":
+            assert (id(named[n]) in decay) == (kind == "decay"), n
+    sched = cosine_lr(opt, rec["lr"], rec["warmup"], rec["total"])
+    sd0 = {n: p.detach().clone() for n, p in named.items() if n.startswith("visual.") and ".resblocks." not in n}
+    losses, worst = [], 0.0
+    for step in range(rec["steps"]):
+        batch = synthetic_batch(rec["batch"], rec["boxes"], rec["image_size"], cfg.image_size, seed=rec["seed_b"] + step)
+        out, _, _ = train_step(student, CLIPSelf(), batch, opt, sched, step, teacher, _args())
+        losses.append(float(out["loss"].detach()))
+        if step == 0:
+            checked = 0
+            for k in g.files:
+                if k.startswith(tag + "grad/"):
+                    n = k[len(tag) + 5:]
+                    r = rel(named[n].grad, g[k])
+                    worst, checked = max(worst, r), checked + 1
+                    assert r < 3e-2, f"{n}: {r:.3e}"
+            assert checked == (4 if tag == "pos/" else 8)
+            for n in ("visual.ln_post.weight", "visual.proj") + (("visual.conv1.weight", "visual.class_embedding") if tag == "pos/" else ()):
+                assert named[n].grad is None, n
+    _log(f"tiny-openai stem {tag} worst grad rel={worst:.3e} losses {losses} vs {g[tag + 'losses'].tolist()}")
+    assert np.allclose(losses, g[tag + "losses"], atol=1e-3)
+    for k in g.files:
+        if k.startswith(tag + "final/"):
+            n = k[len(tag) + 6:]
+            upd = rel(named[n].detach() - sd0[n], torch.as_tensor(g[k]).cuda() - sd0[n])
+            assert upd < 8e-2, f"{n}: update rel {upd:.3e}"
+    for n in ("visual.ln_post.weight", "visual.ln_post.bias", "visual.proj"):
+        assert torch.equal(named[n].detach(), sd0[n]), n
+
+
 def test_vitb16_openai_cfg1_matches_reference_goldens(golden_dir):
     """OpenAI-CLIP ViT-B/16, 2 images x 8 boxes, 224^2 through `create_model('ViT-B-16')`: loss within the north-star tolerance,
     feature directions, every gradient norm of the real reference."""
