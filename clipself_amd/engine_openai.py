@@ -111,13 +111,21 @@ class ClipVitEngine(EvaEngine):
         the list is the whole list).  ln_post and proj never train in this family (:405-408)."""
         L = self.cfg.layers
         self.stem_level = min(max(unlocked_groups - L, 0), 2)
-        super().set_trainable_blocks(min(unlocked_groups, L))
+        super().set_trainable_blocks(min(unlocked_groups, L))               # (clears train_all)
         if unlocked_groups <= 0:
             self.first_trainable = L
             if self.trainable:
                 self.flags.zero_()
 
+    def set_trainable_all(self):
+        """No lock at all (training.main without --lock-image, src/training/main.py:161-166): besides the stem and the blocks, ln_post and proj
+        train (transformer.py:576-584 on the dense path)."""
+        self.stem_level = 2
+        super().set_trainable_all()
+
     def _nonblock_trains(self, name):
+        if self.train_all:
+            return True
         tail = name[len(self.prefix):]
         if tail == "positional_embedding":
             return self.stem_level >= 1
@@ -331,7 +339,8 @@ class ClipVitEngine(EvaEngine):
         inv = ops.empty((M,), F32)
         ops.l2norm_fwd(feats, dense, inv)
         if need_grad:
-            self._ctx = dict(B=B, N=N, g=g, saves=saves, xL=xf, stf=(mean, rstd), dense=dense, inv=inv, cos=cos, sin=sin, stem=stem_keep)
+            self._ctx = dict(B=B, N=N, g=g, saves=saves, xL=xf, stf=(mean, rstd), dense=dense, inv=inv, cos=cos, sin=sin, stem=stem_keep,
+                             lnf=lnf if self.train_all else None)
         return dense.view(B, N, E), g
 
     # ------------------------------------------------------------------------------------------ backward
@@ -393,8 +402,17 @@ class ClipVitEngine(EvaEngine):
         ws = (ops.empty((ws_bytes,), torch.uint8), ops.empty((max(ops.colsum_workspace(M, max(cfg.hidden, 3 * C)), 4),), torch.uint8))
         L, first = cfg.layers, self.first_trainable
         cproj_bias = lambda i: self.g[f"{P}{self.BLOCK_TAG}{i}.mlp.c_proj.bias"] if i >= first else None
-        ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "ln_post.weight"], *c["stf"], g, DX_F32_ASSIGN, None, None, True, ws[0],   # ln_post frozen
-                          dx_copy=gb if first < L else None, copy_colsum=cproj_bias(L - 1))                                    # (transformer.py:405)
+        if self.train_all:
+            # proj [C,E] (transformer.py:583-584: tokens @ proj) and ln_post train: dproj = LN(x)^T . dfeats; the CLS rows of d_feats are exact
+            # zeros (the dense map drops them), so they add nothing
+            self._wgrad(c["lnf"], d_feats, self.g[P + "proj"])
+            ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "ln_post.weight"], *c["stf"], g, DX_F32_ASSIGN, self.g[P + "ln_post.weight"],
+                              self.g[P + "ln_post.bias"], True, ws[0], dx_copy=gb, copy_colsum=cproj_bias(L - 1))
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook("head")
+        else:
+            ops.layernorm_bwd(d_lnf, c["xL"], self.p[P + "ln_post.weight"], *c["stf"], g, DX_F32_ASSIGN, None, None, True, ws[0],   # ln_post frozen
+                              dx_copy=gb if first < L else None, copy_colsum=cproj_bias(L - 1))                                    # (transformer.py:405)
         for i in range(L - 1, first - 1, -1):
             self._block_bwd(i, c["saves"].pop(i), g, gb, B, N, c["cos"], c["sin"], ws, next_bias=cproj_bias(i - 1) if i > 0 else None)
             if self.grad_ready_hook is not None:

@@ -78,7 +78,7 @@ class _Node(nn.Module):
 class EVAVisionTower(_Node):
     """`model.visual`: EVA02 ViT (RoPE + SwiGLU + sub-LN) executing on the HIP engine."""
     ENGINE = EvaEngine
-    UNLOCKED_TRAINS_ALL = True                 # False: the tower only differentiates transformer blocks (OpenAI-CLIP ViT family)
+    UNLOCKED_TRAINS_ALL = True                 # a fresh model trains its whole visual tower, like the reference's before lock() (both families)
 
     def __init__(self, cfg: TowerCfg, ops=None, trainable: bool = True, teacher_chunk: int = 2048):
         super().__init__()
@@ -322,8 +322,6 @@ class CustomCLIP(nn.Module):
 class ClipVisionTower(EVAVisionTower):
     """`model.visual` of the OpenAI-CLIP family: class/positional embeddings, ln_pre, fused-QKV blocks with a GELU MLP, ln_post, proj."""
     ENGINE = ClipVitEngine
-    UNLOCKED_TRAINS_ALL = False                # lock() unlocks at most stem + positional embedding + blocks (transformer.py:391-422); training
-                                               # ln_post / proj too (no --lock-image at all) is not built for this family
 
     def __init__(self, cfg: TowerCfg, ops=None, trainable: bool = True, teacher_chunk: int = 2048):
         super().__init__(cfg, ops=ops, trainable=trainable, teacher_chunk=teacher_chunk)

@@ -111,5 +111,8 @@ def trainable_names(sd, cfg, unlocked_groups: int, prefix="visual."):
     for i in range(cfg.layers):
         tag = f"{prefix}transformer.resblocks.{i}."
         groups.append([n for n in sd if n.startswith(tag)])
+    if unlocked_groups < 0:         # no lock_image_tower() call at all (training.main without --lock-image): the whole visual tower trains
+        groups.append([prefix + "ln_post.weight", prefix + "ln_post.bias", prefix + "proj"])
+        unlocked_groups = len(groups)
     keep = [n for grp in (groups[-unlocked_groups:] if unlocked_groups else []) for n in grp]
     return keep + (["logit_scale"] if "logit_scale" in sd else [])

@@ -302,12 +302,14 @@ def gen_tiny_openai_stem(oc):
     """VisionTransformer.lock with more groups than blocks (transformer.py:391-422: groups = [[conv1, class_embedding, ln_pre],
     positional_embedding, block 0 .. L-1]): L + 1 unlocks the positional embedding, L + 2 the stem as well; ln_post / proj stay frozen.
     One step at L + 1, three at L + 2 (native grid), one at L + 2 on a 64-px image (gradient through the bicubic rescale of the
-    positional embedding, transformer.py:724-734)."""
+    positional embedding, transformer.py:724-734), three with no lock at all (the whole visual tower trains)."""
     cfg = tiny_openai_cfg()
     L = cfg.layers
     blob = {}
-    for tag, unlocked, steps, size in (("pos/", L + 1, 1, cfg.image_size), ("stem/", L + 2, 3, cfg.image_size), ("stem64/", L + 2, 1, 64)):
-        rec = dict(TINY, seed_w=3, seed_b=41, steps=steps, unlocked=unlocked)
+    for tag, unlocked, steps, size in (("pos/", L + 1, 1, cfg.image_size), ("stem/", L + 2, 3, cfg.image_size), ("stem64/", L + 2, 1, 64),
+                                       ("all/", None, 3, cfg.image_size)):
+        # "all/": no lock_image_tower() call at all (training.main without --lock-image, main.py:161-166): ln_post and proj train as well
+        rec = dict(TINY, seed_w=3, seed_b=41, steps=steps, unlocked=unlocked, lock=unlocked is not None)
         student, teacher, out, first, groups = _run_steps(oc, cfg, rec, size, cfg.image_size, build=_build_openai)
         blob[tag + "losses"] = np.array(out["losses"], np.float64)
         blob[tag + "lrs"] = np.array(out["lrs"], np.float64)

@@ -547,7 +547,7 @@ def test_tiny_openai_vit_step_matches_reference_goldens(golden_dir, quick):
         assert rel(w["visual.transformer.resblocks.0.mlp.c_fc.weight"], g["final/visual.transformer.resblocks.0.mlp.c_fc.weight"]) < 2e-2
 
 
-@pytest.mark.parametrize("tag", ["pos/", "stem/", "stem64/"])
+@pytest.mark.parametrize("tag", ["pos/", "stem/", "stem64/", "all/"])
 def test_tiny_openai_vit_stem_groups_match_reference_goldens(golden_dir, tag):
     """`lock_image_tower(unlocked_groups > layers)` of the OpenAI-CLIP family (transformer.py:391-422): the positional embedding (L + 1
     groups) and conv1 / class_embedding / ln_pre (L + 2) train.  HIP path through the public API -- optimizer groups, first-step gradients,
@@ -561,7 +561,10 @@ def test_tiny_openai_vit_stem_groups_match_reference_goldens(golden_dir, tag):
     rec = json.loads(str(g[tag + "recipe"]))
     cfg = tiny_openai_cfg()
     student, teacher = _pair_openai(cfg, rec["seed_w"])
-    student.lock_image_tower(unlocked_groups=rec["unlocked"])
+    if rec["lock"]:
+        student.lock_image_tower(unlocked_groups=rec["unlocked"])
+    else:                                                  # "all/": training.main without --lock-image -- ln_post and proj train as well
+        student.visual.unlock()
     assert type(student.visual.engine.ops).__name__ == "HipOps" and student.visual.engine.stem_level == (1 if tag == "pos/" else 2)
     groups = json.loads(str(g[tag + "groups"]))
     named = dict(student.named_parameters())
@@ -587,8 +590,8 @@ def test_tiny_openai_vit_stem_groups_match_reference_goldens(golden_dir, tag):
                     r = rel(named[n].grad, g[k])
                     worst, checked = max(worst, r), checked + 1
                     assert r < 3e-2, f"{n}: {r:.3e}"
-            assert checked == (4 if tag == "pos/" else 8)
-            for n in ("visual.ln_post.weight", "visual.proj") + (("visual.conv1.weight", "visual.class_embedding") if tag == "pos/" else ()):
+            assert checked == {"pos/": 4, "stem/": 8, "stem64/": 8, "all/": 11}[tag]
+            for n in (("visual.ln_post.weight", "visual.proj") if tag != "all/" else ()) + (("visual.conv1.weight", "visual.class_embedding") if tag == "pos/" else ()):
                 assert named[n].grad is None, n
     _log(f"tiny-openai stem {tag} worst grad rel={worst:.3e} losses {losses} vs {g[tag + 'losses'].tolist()}")
     assert np.allclose(losses, g[tag + "losses"], atol=1e-3)
@@ -598,7 +601,7 @@ def test_tiny_openai_vit_stem_groups_match_reference_goldens(golden_dir, tag):
             upd = rel(named[n].detach() - sd0[n], torch.as_tensor(g[k]).cuda() - sd0[n])
             assert upd < 8e-2, f"{n}: update rel {upd:.3e}"
     for n in ("visual.ln_post.weight", "visual.ln_post.bias", "visual.proj"):
-        assert torch.equal(named[n].detach(), sd0[n]), n
+        assert torch.equal(named[n].detach(), sd0[n]) == (tag != "all/"), n
 
 
 def test_vitb16_openai_cfg1_matches_reference_goldens(golden_dir):

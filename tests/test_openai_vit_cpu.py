@@ -235,6 +235,8 @@ def test_api_state_dict_lock_and_method_step(gold):
     res = CLIP(cfg, ops=RefOps(), trainable=False).load_state_dict(student.state_dict())
     assert not res.missing_keys and not res.unexpected_keys
 
+    # a fresh model is unlocked, like the reference's before lock_image_tower(): the whole visual tower trains (text tower frozen, model.py:214)
+    assert all(p.requires_grad for n, p in student.named_parameters() if n.startswith("visual.")) and student.visual.engine.train_all
     student.lock_image_tower(unlocked_groups=0)            # transformer.py:395: 0 groups = everything frozen (EVA02 differs)
     assert not any(p.requires_grad for n, p in student.named_parameters() if n.startswith("visual."))
     student.lock_image_tower(unlocked_groups=1)
@@ -247,8 +249,11 @@ def test_api_state_dict_lock_and_method_step(gold):
     for n_groups in (cfg.layers + 2, cfg.layers + 7):              # groups[-n:] with n past the list = every group; ln_post / proj stay frozen
         student.lock_image_tower(unlocked_groups=n_groups)
         assert {n for n, p in student.named_parameters() if p.requires_grad and n.startswith("visual.")} == blocks | stem | {"visual.positional_embedding"}
+    student.visual.unlock()
+    assert all(p.requires_grad for n, p in student.named_parameters() if n.startswith("visual.")) and student.visual.engine.train_all
     student.lock_image_tower(unlocked_groups=cfg.layers)
     assert {n for n, p in student.named_parameters() if p.requires_grad and n.startswith("visual.")} == blocks
+    assert not student.visual.engine.train_all and student.visual.engine.stem_level == 0
     student.train()
 
     batch = _batches(cfg, rec, 1)[0]
@@ -266,6 +271,7 @@ def test_api_state_dict_lock_and_method_step(gold):
 
 # ------------------------------------------------------------------------------------------------ (4) lock() with more groups than blocks
 STEM = ("visual.conv1.weight", "visual.class_embedding", "visual.ln_pre.weight", "visual.ln_pre.bias")
+N_GRADS = {"pos/": 4, "stem/": 8, "stem64/": 8, "all/": 11}           # gradients the golden holds per recipe (stem / head tensors + three block tensors)
 
 
 @pytest.fixture(scope="module")
@@ -273,7 +279,7 @@ def gold_stem(golden_dir):
     return np.load(golden_dir / "tiny_openai_stem.npz")
 
 
-@pytest.mark.parametrize("tag", ["pos/", "stem/", "stem64/"])
+@pytest.mark.parametrize("tag", ["pos/", "stem/", "stem64/", "all/"])
 def test_oracle_stem_groups_match_reference(gold_stem, tag):
     """positional_embedding (L + 1 groups) and conv1 / class_embedding / ln_pre (L + 2) train: the restatement's autograd gradients, losses
     and AdamW results against the real reference (oracle/gen_golden.py::gen_tiny_openai_stem), native grid and the rescaled 8x8 grid."""
@@ -282,18 +288,19 @@ def test_oracle_stem_groups_match_reference(gold_stem, tag):
     cfg = tiny_openai_cfg()
     student, teacher = seeded_visual_state(cfg, rec["seed_w"]), seeded_visual_state(cfg, rec["seed_w"])
     batches = [synthetic_batch(rec["batch"], rec["boxes"], rec["image_size"], cfg.image_size, seed=rec["seed_b"] + s) for s in range(rec["steps"])]
-    kw = dict(lr=rec["lr"], wd=rec["wd"], warmup=rec["warmup"], total_steps=rec["total"], unlocked_groups=rec["unlocked"])
+    kw = dict(lr=rec["lr"], wd=rec["wd"], warmup=rec["warmup"], total_steps=rec["total"], unlocked_groups=rec["unlocked"] if rec["lock"] else -1)
     _, grads = eva_ref.train_steps({k: v.clone() for k, v in student.items()}, teacher, cfg, batches[:1], **kw)
     groups = json.loads(str(g[tag + "groups"]))
     assert {n for n in grads if n.startswith("visual.")} == {n for n, k in groups.items() if k != "frozen"}
-    assert groups["visual.positional_embedding"] == "decay" and groups["visual.ln_post.weight"] == "frozen" and groups["visual.proj"] == "frozen"
+    head = ("frozen", "frozen") if tag != "all/" else ("no_decay", "decay")     # "all/" = no lock at all: ln_post and proj train too
+    assert groups["visual.positional_embedding"] == "decay" and (groups["visual.ln_post.weight"], groups["visual.proj"]) == head
     assert all(groups[n] == ("frozen" if tag == "pos/" else "decay" if n.endswith("conv1.weight") else "no_decay") for n in STEM)
     checked = 0
     for k in g.files:
         if k.startswith(tag + "grad/"):
             assert rel(grads[k[len(tag) + 5:]], g[k]) < 1e-4, k
             checked += 1
-    assert checked == (4 if tag == "pos/" else 8)
+    assert checked == N_GRADS[tag]
     log, _ = eva_ref.train_steps(student, teacher, cfg, batches, **kw)
     assert np.allclose([l["loss"] for l in log], g[tag + "losses"], atol=5e-6)
     for k in g.files:
@@ -316,7 +323,7 @@ def _engine_step(eng, teacher_eng, batch, step, rec):
     return float(loss)
 
 
-@pytest.mark.parametrize("tag", ["pos/", "stem/", "stem64/"])
+@pytest.mark.parametrize("tag", ["pos/", "stem/", "stem64/", "all/"])
 def test_engine_stem_backward_is_the_gradient(gold_stem, tag):
     """ClipVitEngine._stem_bwd through the per-kernel references: ln_pre backward, positional / class embedding sums, conv1 wgrad."""
     g = gold_stem
@@ -324,15 +331,19 @@ def test_engine_stem_backward_is_the_gradient(gold_stem, tag):
     cfg = tiny_openai_cfg()
     eng, teacher_eng = ClipVitEngine(cfg, RefOps(), trainable=True), _engine(cfg, rec["seed_w"], False)
     eng.load_state(seeded_visual_state(cfg, rec["seed_w"]))
-    eng.set_trainable_blocks(rec["unlocked"])
-    assert eng.stem_level == (1 if tag == "pos/" else 2) and eng.first_trainable == 0
+    if rec["lock"]:
+        eng.set_trainable_blocks(rec["unlocked"])
+    else:
+        eng.set_trainable_all()
+    assert eng.stem_level == (1 if tag == "pos/" else 2) and eng.first_trainable == 0 and eng.train_all == (tag == "all/")
     names = set(eng.trainable_names())
-    assert ("visual.positional_embedding" in names) and (("visual.conv1.weight" in names) == (tag != "pos/")) and "visual.ln_post.weight" not in names
+    assert ("visual.positional_embedding" in names) and (("visual.conv1.weight" in names) == (tag != "pos/"))
+    assert ("visual.ln_post.weight" in names) == ("visual.proj" in names) == (tag == "all/")
     fired = []
     eng.grad_ready_hook = fired.append
     batch = synthetic_batch(rec["batch"], rec["boxes"], rec["image_size"], cfg.image_size, seed=rec["seed_b"])
     loss = _engine_step(eng, teacher_eng, batch, 0, rec)
-    assert fired == list(range(cfg.layers - 1, -1, -1)) + ["stem"]
+    assert fired == (["head"] if tag == "all/" else []) + list(range(cfg.layers - 1, -1, -1)) + ["stem"]
     assert abs(loss - g[tag + "losses"][0]) < 5e-3
     checked = 0
     for k in g.files:
@@ -342,19 +353,23 @@ def test_engine_stem_backward_is_the_gradient(gold_stem, tag):
             r = rel(got.reshape(g[k].shape), g[k])
             assert r < 2e-2, f"{name}: rel {r:.3e}"                       # measured <= 5.4e-3 through the reference ops
             checked += 1
-    assert checked == (4 if tag == "pos/" else 8)
+    assert checked == N_GRADS[tag]
     if tag == "pos/":                                   # frozen stem tensors: no flag, no gradient written
         for n in STEM:
             assert float(eng.g[n].abs().max()) == 0.0, n
 
 
-def test_engine_stem_three_steps_track_reference(gold_stem):
-    g, tag = gold_stem, "stem/"
+@pytest.mark.parametrize("tag", ["stem/", "all/"])
+def test_engine_stem_three_steps_track_reference(gold_stem, tag):
+    g = gold_stem
     rec = json.loads(str(g[tag + "recipe"]))
     cfg = tiny_openai_cfg()
     eng, teacher_eng = ClipVitEngine(cfg, RefOps(), trainable=True), _engine(cfg, rec["seed_w"], False)
     eng.load_state(seeded_visual_state(cfg, rec["seed_w"]))
-    eng.set_trainable_blocks(rec["unlocked"])
+    if rec["lock"]:
+        eng.set_trainable_blocks(rec["unlocked"])
+    else:
+        eng.set_trainable_all()
     losses = []
     for step in range(rec["steps"]):
         batch = synthetic_batch(rec["batch"], rec["boxes"], rec["image_size"], cfg.image_size, seed=rec["seed_b"] + step)
@@ -363,7 +378,7 @@ def test_engine_stem_three_steps_track_reference(gold_stem):
     assert np.allclose(losses, g[tag + "losses"], atol=1e-2), (losses, g[tag + "losses"])
     sd0 = seeded_visual_state(cfg, rec["seed_w"])
     for n in ("visual.proj", "visual.ln_post.weight", "visual.ln_post.bias"):
-        assert torch.equal(eng.p[n], sd0[n].reshape(eng.p[n].shape)), n
+        assert torch.equal(eng.p[n], sd0[n].reshape(eng.p[n].shape)) == (tag != "all/"), n
     for k in g.files:
         if k.startswith(tag + "final/"):
             name = k[len(tag) + 6:]
