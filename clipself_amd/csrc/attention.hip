@@ -711,10 +711,13 @@ int check_common(const char* who, int B, int Ntok, int H, int ldqkv, int ldo) {
 //     reused across the HG heads;
 //   * arithmetic mirrors attn_fwd_kernel: keys 1.. rotated and rounded to bf16, fp32 scores, exp2(s - max) rounded to
 //     bf16 for the P.V product, fp32 row sum of the unrounded exponentials.
+// Round 4: the same kernel serves the OpenAI-CLIP family's extra query tokens (cs_attn_query_fwd: open_clip/transformer.py:736-834) -- qpb
+// query rows share one image's keys / values, `allow` [queries][Ntok] says which keys a query may attend (no rotary tables there).
 template <int HG>
 __global__ __launch_bounds__(256) void attn_cls_kernel(const __bf16* __restrict__ q, const __bf16* __restrict__ kv,
                                                        const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                       __bf16* __restrict__ out, int Ntok, int H, int ldq, int ldkv, int ldo, float scale) {
+                                                       __bf16* __restrict__ out, int Ntok, int H, int ldq, int ldkv, int ldo, float scale,
+                                                       int qpb, const unsigned char* __restrict__ allow) {
     extern __shared__ float sm[];                 // [HG][Npad] scores -> probabilities | [HG] row sums | [4 waves][HG*64] partial outputs
     const int Npad = (Ntok + 3) & ~3;
     float* rsum = sm + HG * Npad;
@@ -722,7 +725,8 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const __bf16* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x, h0 = blockIdx.y * HG;
     const int c = tid & 7, kg = tid >> 3;         // 16-byte chunk of the head dim; key slot (32 per pass)
-    const __bf16* kbase = kv + (size_t)b * Ntok * ldkv + h0 * HD + c * 8;
+    const __bf16* kbase = kv + (size_t)(b / qpb) * Ntok * ldkv + h0 * HD + c * 8;
+    const unsigned char* arow = allow ? allow + (size_t)b * Ntok : nullptr;
     const __bf16* vbase = kbase + H * HD;
     float qf[HG][8];
 #pragma unroll
@@ -737,7 +741,7 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const __bf16* __restrict_
         U128 kk[HG];
 #pragma unroll
         for (int h = 0; h < HG; ++h) kk[h].u = *(const uint4*)(kbase + (size_t)key * ldkv + h * HD);
-        if (key > 0) {
+        if (key > 0 && cos_t) {
             const float* cs = cos_t + (size_t)(key - 1) * HD + c * 8;
             const float* sn = sin_t + (size_t)(key - 1) * HD + c * 8;
 #pragma unroll
@@ -751,7 +755,7 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const __bf16* __restrict_
             dot += __shfl_xor(dot, 1);
             dot += __shfl_xor(dot, 2);
             dot += __shfl_xor(dot, 4);
-            if (c == 0) sm[h * Npad + key] = dot * sl2;
+            if (c == 0) sm[h * Npad + key] = (arow && !arow[key]) ? -INFINITY : dot * sl2;      // masked key: p = exp2(-inf) = 0 exactly
         }
     }
     __syncthreads();
@@ -909,25 +913,18 @@ extern "C" int cs_attn_bwd(const void* qkv, const void* o, const void* dout, con
     return 0;
 }
 
-// q [B, ldq] bf16: the CLS-token queries (H*64 wide, bias added; token 0 is never rotated); kv [B*N, ldkv] bf16 = k|v
-// (un-rotated, bias added); out [B, ldo] bf16 = the CLS row of softmax(q k^T * scale) v.
-extern "C" int cs_attn_cls_fwd(const void* q, const void* kv, const float* cos_t, const float* sin_t, void* out, int B, int Ntok, int H,
-                               int ldq, int ldkv, int ldo, float scale, hipStream_t stream) {
-    CS_CHECK_ARG(q && kv && cos_t && sin_t && out, "cs_attn_cls_fwd: null pointer");
-    CS_CHECK_ARG(B > 0 && Ntok > 1 && H > 0, "cs_attn_cls_fwd: bad sizes B=%d Ntok=%d H=%d", B, Ntok, H);
-    CS_CHECK_ARG(ldq % 8 == 0 && ldkv % 8 == 0 && ldq >= H * HD && ldkv >= 2 * H * HD && ldo >= H * HD,
-                 "cs_attn_cls_fwd: row strides must be multiples of 8 and cover the heads (ldq=%d ldkv=%d ldo=%d)", ldq, ldkv, ldo);
-    CS_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0, "cs_attn_cls_fwd: q/kv must be 16-byte aligned");
+static int attn_cls_launch(const void* q, const void* kv, const float* cos_t, const float* sin_t, void* out, int rows, int Ntok, int H,
+                           int ldq, int ldkv, int ldo, float scale, int qpb, const unsigned char* allow, hipStream_t stream) {
     const int HG = H % 6 == 0 ? 6 : (H % 4 == 0 ? 4 : (H % 3 == 0 ? 3 : (H % 2 == 0 ? 2 : 1)));
     const size_t lds = ((size_t)HG * ((Ntok + 3) & ~3) + 8 + (size_t)4 * HG * HD) * sizeof(float);
     CS_CHECK_ARG(lds <= 160 * 1024, "cs_attn_cls_fwd: Ntok=%d too large", Ntok);
-    const dim3 grid(B, H / HG), block(256);
+    const dim3 grid(rows, H / HG), block(256);
 #define CS_CLS_LAUNCH(G)                                                                                                      \
     {                                                                                                                         \
         static bool once = (set_lds(attn_cls_kernel<G>, 160 * 1024), true);                                                   \
         (void)once;                                                                                                           \
         hipLaunchKernelGGL(attn_cls_kernel<G>, grid, block, lds, stream, (const __bf16*)q, (const __bf16*)kv, cos_t, sin_t,   \
-                           (__bf16*)out, Ntok, H, ldq, ldkv, ldo, scale);                                                     \
+                           (__bf16*)out, Ntok, H, ldq, ldkv, ldo, scale, qpb, allow);                                         \
     }
     switch (HG) {
         case 6: CS_CLS_LAUNCH(6) break;
@@ -939,4 +936,30 @@ extern "C" int cs_attn_cls_fwd(const void* q, const void* kv, const float* cos_t
 #undef CS_CLS_LAUNCH
     CS_LAUNCH_CHECK();
     return 0;
+}
+
+// q [B, ldq] bf16: the CLS-token queries (H*64 wide, bias added; token 0 is never rotated); kv [B*N, ldkv] bf16 = k|v
+// (un-rotated, bias added); out [B, ldo] bf16 = the CLS row of softmax(q k^T * scale) v.
+extern "C" int cs_attn_cls_fwd(const void* q, const void* kv, const float* cos_t, const float* sin_t, void* out, int B, int Ntok, int H,
+                               int ldq, int ldkv, int ldo, float scale, hipStream_t stream) {
+    CS_CHECK_ARG(q && kv && cos_t && sin_t && out, "cs_attn_cls_fwd: null pointer");
+    CS_CHECK_ARG(B > 0 && Ntok > 1 && H > 0, "cs_attn_cls_fwd: bad sizes B=%d Ntok=%d H=%d", B, Ntok, H);
+    CS_CHECK_ARG(ldq % 8 == 0 && ldkv % 8 == 0 && ldq >= H * HD && ldkv >= 2 * H * HD && ldo >= H * HD,
+                 "cs_attn_cls_fwd: row strides must be multiples of 8 and cover the heads (ldq=%d ldkv=%d ldo=%d)", ldq, ldkv, ldo);
+    CS_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0, "cs_attn_cls_fwd: q/kv must be 16-byte aligned");
+    return attn_cls_launch(q, kv, cos_t, sin_t, out, B, Ntok, H, ldq, ldkv, ldo, scale, 1, nullptr, stream);
+}
+
+// Extra query tokens of the OpenAI-CLIP family's mask-attention pooling (open_clip/transformer.py:736-834, reached through
+// extract_type='v1' :660-671 and encode_masks(mask_attn=True), model.py:245-247): Q query rows per image against the image's own keys /
+// values of the same depth, key j of query row r allowed iff allow[r * Ntok + j] != 0 (key 0 = the CLS token, always allowed there).
+// q [B*Q, ldq] bf16; kv [B*Ntok, ldkv] bf16 = k|v; out [B*Q, ldo] bf16.  No rotary embedding in this family.  Inference only.
+extern "C" int cs_attn_query_fwd(const void* q, const void* kv, const unsigned char* allow, void* out, int B, int Q, int Ntok, int H,
+                                 int ldq, int ldkv, int ldo, float scale, hipStream_t stream) {
+    CS_CHECK_ARG(q && kv && allow && out, "cs_attn_query_fwd: null pointer");
+    CS_CHECK_ARG(B > 0 && Q > 0 && Ntok > 1 && H > 0, "cs_attn_query_fwd: bad sizes B=%d Q=%d Ntok=%d H=%d", B, Q, Ntok, H);
+    CS_CHECK_ARG(ldq % 8 == 0 && ldkv % 8 == 0 && ldq >= H * HD && ldkv >= 2 * H * HD && ldo >= H * HD,
+                 "cs_attn_query_fwd: row strides must be multiples of 8 and cover the heads (ldq=%d ldkv=%d ldo=%d)", ldq, ldkv, ldo);
+    CS_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0, "cs_attn_query_fwd: q/kv must be 16-byte aligned");
+    return attn_cls_launch(q, kv, nullptr, nullptr, out, B * Q, Ntok, H, ldq, ldkv, ldo, scale, Q, allow, stream);
 }

@@ -9,6 +9,7 @@ does each stage (paths under /root/reference/src/open_clip/):
   MLP             transformer.py:209-213,31-34   GELU (erf) or QuickGELU
   image head      transformer.py:486-494     ln_post(x[:,0]) @ proj
   dense head      transformer.py:576-587     normalize(ln_post(x[:,1:]) @ proj)
+  mask attention  transformer.py:660-671,736-834   extract_type='v1' / encode_masks(mask_attn=True): extra query tokens (mask_attn_pool, inference)
   lock            transformer.py:391-422     groups = [stem, positional_embedding, blocks..., last block]; the last n train
                                              (n > L: positional_embedding, then conv1 / class_embedding / ln_pre: _stem_bwd)
 
@@ -311,6 +312,72 @@ class ClipVitEngine(EvaEngine):
             ops.layernorm_fwd(xc, self.p[P + "ln_post.weight"], self.p[P + "ln_post.bias"], cls, None, None, cfg.ln_eps)
             self._head(cls, out[k0:k0 + B])
         return out
+
+    # ------------------------------------------------------------------------------------------ mask-attention pooling (inference)
+    def mask_attn_pool(self, images, masks, chunk: int = 64):
+        """VisionTransformer.mask_attn_pool / _mask_attn_pool (transformer.py:736-834), the pooling behind extract_type='v1' (:660-671) and
+        encode_masks(mask_attn=True).  masks: list over images of bool [n_i, g, g] on the token grid.  Every mask is an extra token -- a copy
+        of the image's CLS embedding after ln_pre -- that runs through ALL blocks; the reference's attention mask hides the extra tokens from
+        everybody and lets token q see the CLS token plus the image tokens inside its mask, so the image tokens are exactly forward()'s and
+        an extra token is a query-only passenger.  Per block: the image tokens' usual q|k|v GEMM, whose k|v columns also serve the Q extra
+        queries of the image (cs_attn_query_fwd), then out_proj / MLP on the [B*Q, C] passenger stream with the same GEMM epilogues as the
+        blocks.  Images with fewer masks are padded with see-everything tokens whose rows are dropped (:793-795,823-824).  -> fp32 [sum n_i, E]"""
+        ops, cfg, P = self.ops, self.cfg, self.prefix
+        C, Hd, H, eps, E = cfg.width, cfg.hidden, cfg.heads, cfg.ln_eps, cfg.embed_dim
+        counts = [int(m.shape[0]) for m in masks]
+        assert len(masks) == images.shape[0] and min(counts) > 0, "one non-empty mask list per image"
+        Q = max(counts)
+        outs = []
+        act = EPI_QGELU_BF16 if cfg.quick_gelu else EPI_GELU_BF16
+        for k0 in range(0, images.shape[0], chunk):
+            img = images[k0:k0 + chunk]
+            B = img.shape[0]
+            x, g = self._stem(img)
+            N = g * g + 1
+            cos, sin = self.rope_tables(g)
+            allow = torch.ones((B, Q, N), dtype=torch.uint8, device=self.device)
+            for b, m in enumerate(masks[k0:k0 + B]):
+                assert tuple(m.shape[1:]) == (g, g), f"masks live on the {g}x{g} token grid, got {tuple(m.shape[1:])}"
+                allow[b, :m.shape[0], 1:] = m.reshape(m.shape[0], -1).to(device=self.device, dtype=torch.uint8)
+            allow = allow.view(B * Q, N)
+            xf = x.view(B * N, C)
+            xm = x[:, :1, :].expand(B, Q, C).reshape(B * Q, C).contiguous()          # fp32 passenger stream
+            MQ = B * Q
+            for i in range(cfg.layers):
+                b_ = f"{P}{self.BLOCK_TAG}{i}."
+                wqkv, bqkv = self.w[b_ + "attn.in_proj_weight"], self.p[b_ + "attn.in_proj_bias"]
+                ln1 = ops.empty((B * N, C), BF16)
+                ops.layernorm_fwd(xf, self.p[b_ + "ln_1.weight"], self.p[b_ + "ln_1.bias"], ln1, None, None, eps)
+                qkv = ops.empty((B * N, 3 * C), BF16)
+                ops.gemm_nt(ln1, wqkv, qkv, bias=bqkv, epi=EPI_BF16)
+                lnm = ops.empty((MQ, C), BF16)
+                ops.layernorm_fwd(xm, self.p[b_ + "ln_1.weight"], self.p[b_ + "ln_1.bias"], lnm, None, None, eps)
+                qm = ops.empty((MQ, C), BF16)
+                ops.gemm_nt(lnm, wqkv[:C], qm, bias=bqkv[:C], epi=EPI_BF16)
+                attm = ops.empty((MQ, C), BF16)
+                ops.attn_query_fwd(qm, qkv[:, C:], allow, attm, B, Q, N, H, cfg.head_width ** -0.5)
+                ops.gemm_nt(attm, self.w[b_ + "attn.out_proj.weight"], xm, bias=self.p[b_ + "attn.out_proj.bias"], extra=xm, epi=EPI_RESID_F32)
+                ln2 = ops.empty((MQ, C), BF16)
+                ops.layernorm_fwd(xm, self.p[b_ + "ln_2.weight"], self.p[b_ + "ln_2.bias"], ln2, None, None, eps)
+                hid = ops.empty((MQ, Hd), BF16)
+                ops.gemm_nt(ln2, self.w[b_ + "mlp.c_fc.weight"], hid, bias=self.p[b_ + "mlp.c_fc.bias"], epi=act)
+                ops.gemm_nt(hid, self.w[b_ + "mlp.c_proj.weight"], xm, bias=self.p[b_ + "mlp.c_proj.bias"], extra=xm, epi=EPI_RESID_F32)
+                if i + 1 < cfg.layers:                      # the image tokens move on (they never see the passengers); not needed after the last block
+                    att = ops.empty((B * N, C), BF16)
+                    ops.attn_fwd(qkv, cos, sin, att, None, B, N, H, cfg.head_width ** -0.5)
+                    ops.gemm_nt(att, self.w[b_ + "attn.out_proj.weight"], xf, bias=self.p[b_ + "attn.out_proj.bias"], extra=xf, epi=EPI_RESID_F32)
+                    ln2i = ops.empty((B * N, C), BF16)
+                    ops.layernorm_fwd(xf, self.p[b_ + "ln_2.weight"], self.p[b_ + "ln_2.bias"], ln2i, None, None, eps)
+                    hidi = ops.empty((B * N, Hd), BF16)
+                    ops.gemm_nt(ln2i, self.w[b_ + "mlp.c_fc.weight"], hidi, bias=self.p[b_ + "mlp.c_fc.bias"], epi=act)
+                    ops.gemm_nt(hidi, self.w[b_ + "mlp.c_proj.weight"], xf, bias=self.p[b_ + "mlp.c_proj.bias"], extra=xf, epi=EPI_RESID_F32)
+            lnp = ops.empty((MQ, C), BF16)
+            ops.layernorm_fwd(xm, self.p[P + "ln_post.weight"], self.p[P + "ln_post.bias"], lnp, None, None, eps)
+            pooled = ops.empty((MQ, E), F32)
+            self._head(lnp, pooled)
+            pooled = pooled.view(B, Q, E)
+            outs += [pooled[b, :n] for b, n in enumerate(counts[k0:k0 + B])]
+        return torch.cat(outs)
 
     # ------------------------------------------------------------------------------------------ student
     def encode_dense(self, images, need_grad: bool = False):

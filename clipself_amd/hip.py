@@ -49,6 +49,7 @@ SIGNATURES = {
     "cs_l2norm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "cs_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_attn_cls_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "cs_attn_query_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_attn_bwd_workspace": (_sz, [_i, _i, _i]),
     "cs_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_swiglu_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
@@ -364,6 +365,13 @@ class HipOps:
         self._chk(q, kv, cos, sin, out)
         self._ok(self.lib.cs_attn_cls_fwd(_p(q), _p(kv), _p(cos), _p(sin), _p(out), B, Ntok, H, q.stride(0), kv.stride(0),
                                           out.stride(0), scale, self._stream()), "cs_attn_cls_fwd")
+
+    def attn_query_fwd(self, q, kv, allow, out, B, Q, Ntok, H, scale):
+        """Q extra query rows per image against the image's keys / values; allow [B*Q, Ntok] uint8 (1 = may attend).  Inference only."""
+        self._chk(q, kv, allow, out)
+        assert allow.dtype == torch.uint8 and allow.is_contiguous() and tuple(allow.shape) == (B * Q, Ntok)
+        self._ok(self.lib.cs_attn_query_fwd(_p(q), _p(kv), _p(allow), _p(out), B, Q, Ntok, H, q.stride(0), kv.stride(0), out.stride(0),
+                                            scale, self._stream()), "cs_attn_query_fwd")
 
     def attn_bwd_workspace(self, B, Ntok, H) -> int:
         return int(self.lib.cs_attn_bwd_workspace(B, Ntok, H))

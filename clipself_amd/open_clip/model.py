@@ -200,6 +200,16 @@ class EVAVisionTower(_Node):
         return (fm * m.unsqueeze(-1)).sum(1) / (m.sum(1, keepdim=True) + 1e-12)
 
 
+def boxes_to_grid_masks(normed_boxes, grid_h: int, grid_w: int):
+    """VisionTransformer._generate_masks_per_image (open_clip/transformer.py:636-646): box * (w, h, w, h), truncated towards zero, rows
+    y0:y1 and columns x0:x1 of a [k, grid_h, grid_w] bool mask set (an empty slice leaves the mask empty)."""
+    scaled = (normed_boxes.detach().to("cpu", F32)[:, :4] * torch.tensor([[grid_w, grid_h, grid_w, grid_h]], dtype=F32)).long().tolist()
+    masks = torch.zeros(len(scaled), grid_h, grid_w, dtype=torch.bool)
+    for i, (x0, y0, x1, y1) in enumerate(scaled):
+        masks[i, y0:y1, x0:x1] = True
+    return masks
+
+
 def boxes_to_rois(normed_boxes, device):
     """list[Tensor[k_i, 4]] (x0,y0,x1,y1 in [0,1]) -> [K,5] with the image index in column 0 (the layout
     torchvision.roi_align builds from a box list)."""
@@ -306,10 +316,12 @@ class CustomCLIP(nn.Module):
         return features
 
     def encode_masks(self, image, masks, normalize=True, mask_attn=False):
-        if mask_attn:
-            raise NotImplementedError("mask_attn=True (attention-masked pooling, transformer.py:560-590) is not built; only mask pooling "
-                                      "of the dense map")
-        mask_pooled = self.visual.mask_pool(image, masks)
+        if mask_attn:                                       # model.py:245-247 of the reference; the OpenAI-CLIP family only (EVA02 has no such method)
+            if not hasattr(self.visual, "mask_attn_pool"):
+                raise NotImplementedError("mask_attn=True exists for the OpenAI-CLIP ViT family only (open_clip/transformer.py:785-834)")
+            mask_pooled = self.visual.mask_attn_pool(image, masks)
+        else:
+            mask_pooled = self.visual.mask_pool(image, masks)
         if normalize:
             mask_pooled = F.normalize(mask_pooled, dim=-1)
         return mask_pooled
@@ -330,11 +342,22 @@ class ClipVisionTower(EVAVisionTower):
         self.patch_size = (cfg.patch_size, cfg.patch_size)
 
     def extract_roi_features(self, x, normed_boxes, extract_type="v2", **kwargs):
-        """The reference dispatches `extract_type` for this family (open_clip/transformer.py:515-521): 'v2' = the dense map +
-        RoIAlign built here; 'v1' (attention-masked CLS queries per box) is not on the CLIPSelf path and not built."""
+        """The reference dispatches `extract_type` for this family (open_clip/transformer.py:515-521): 'v2' = the dense map + RoIAlign
+        (differentiable), 'v1' = every box rasterised on the token grid and pooled by an extra query token (:660-671; inference)."""
+        if extract_type == "v1":
+            g = x.shape[-1] // self.cfg.patch_size
+            return self.mask_attn_pool(x, [boxes_to_grid_masks(b, g, g) for b in normed_boxes])
         if extract_type != "v2":
-            raise NotImplementedError(f"extract_type={extract_type!r}: only the dense 'v2' path exists for the OpenAI-CLIP ViT family")
+            raise NotImplementedError(f"extract_type={extract_type!r}: the reference builds 'v1' and 'v2' (transformer.py:515-521)")
         return super().extract_roi_features(x, normed_boxes)
+
+    def mask_attn_pool(self, image, masks):
+        """VisionTransformer.mask_attn_pool (transformer.py:785-834): one extra query token per mask through every block.  Forward only: the
+        hand-written backward does not cover the extra tokens, so a call that would need their gradient raises instead of silently detaching."""
+        if torch.is_grad_enabled() and self._trainable():
+            raise NotImplementedError("mask-attention pooling (extract_type='v1' / mask_attn=True) is built for inference: call it under "
+                                      "torch.no_grad() or on a frozen tower; the training step differentiates extract_type='v2' only")
+        return self.engine.mask_attn_pool(image.to(self.engine.device), list(masks))
 
     def _register_tables(self):
         pass                                                # no rotary tables in this family

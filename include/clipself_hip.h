@@ -138,6 +138,13 @@ int cs_attn_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* o
  * kv [B*Ntok, ldkv] bf16 = k|v; out [B, ldo] bf16. */
 int cs_attn_cls_fwd(const void* q, const void* kv, const float* cos_t, const float* sin_t, void* out, int B, int Ntok, int H,
                     int ldq, int ldkv, int ldo, float scale, cs_stream_t stream);
+/* Extra query tokens of the OpenAI-CLIP family's mask-attention pooling: VisionTransformer.mask_attn_pool / _mask_attn_pool
+ * (src/open_clip/transformer.py:736-834), reached through extract_type='v1' (:660-671) and CLIP.encode_masks(mask_attn=True)
+ * (src/open_clip/model.py:245-247).  Q query rows per image attend the image's own keys / values of the same depth: key j of query row r
+ * is allowed iff allow[r * Ntok + j] != 0 (the reference's bool attn_mask, inverted; key 0 = the CLS token).  q [B*Q, ldq] bf16;
+ * kv [B*Ntok, ldkv] bf16 = k|v; out [B*Q, ldo] bf16.  No rotary embedding in this family.  Inference only (no backward). */
+int cs_attn_query_fwd(const void* q, const void* kv, const unsigned char* allow, void* out, int B, int Q, int Ntok, int H,
+                      int ldq, int ldkv, int ldo, float scale, cs_stream_t stream);
 /* cs_attn_fwd that also emits stats_part [H][B*Ntok][2] f32 = per head (sum, sum of squares) of each output row's 64 values. */
 int cs_attn_fwd_stats(const void* qkv, const float* cos_t, const float* sin_t, void* out, float* lse, float* stats_part, int B, int Ntok,
                       int H, int ldqkv, int ldo, float scale, cs_stream_t stream);

@@ -11,6 +11,7 @@ fp32 CPU restatement (plain torch) of the OpenAI-CLIP vision transformer on the 
   nn.MultiheadAttention (fused in_proj, bias on q, k and v; 1/sqrt(head_dim) on q)   as called at transformer.py:203,217-230
   QuickGELU                                                   transformer.py:31-34
   VisionTransformer.lock                                      transformer.py:391-422
+  _extract_roi_features_v1 / mask_attn_pool / _mask_attn_pool  transformer.py:636-646,660-671,736-834 (inference)
 
 Functional (a dict of tensors keyed by the reference's state-dict names), like oracle/eva_ref.py whose helpers it reuses.
 Pinned against the reference itself: oracle/gen_golden.py (--openai) imports the real reference in the build container and
@@ -101,6 +102,59 @@ def encode_dense(sd, cfg, images, emulate_bf16=False, prefix="visual."):
 def encode_pseudo_boxes(sd, cfg, images, normed_boxes_list, emulate_bf16=False, prefix="visual."):
     dense, g = encode_dense(sd, cfg, images, emulate_bf16, prefix)
     return roi_align_1x1(dense.reshape(images.shape[0], g, g, -1), rois_from_list(normed_boxes_list, g))
+
+
+def boxes_to_masks(normed_boxes, grid_h: int, grid_w: int):
+    """_generate_masks_per_image (transformer.py:636-646): box * (w, h, w, h), truncated to integers, rows y0:y1 / columns x0:x1 set."""
+    boxes = normed_boxes * torch.tensor([[grid_w, grid_h, grid_w, grid_h]], dtype=normed_boxes.dtype)
+    masks = torch.zeros(len(normed_boxes), grid_h, grid_w, dtype=torch.bool)
+    for i, box in enumerate(boxes):
+        x0, y0, x1, y1 = box.long().tolist()
+        masks[i, y0:y1, x0:x1] = True
+    return masks
+
+
+def mask_attn_pool(sd, cfg, images, masks, emulate_bf16=False, prefix="visual."):
+    """mask_attn_pool / _mask_attn_pool (transformer.py:736-834).  masks: list over images of bool [n_i, g, g].  Every mask is an extra token --
+    a copy of the image's CLS embedding after ln_pre -- that runs through all blocks; the attention mask (:806-818) hides the extra tokens from
+    everybody (column block [:, :Q] masked) and lets token q see the CLS token plus the image tokens inside its mask, so the image tokens evolve
+    exactly as in forward() and each extra token is a query-only passenger: x_q += out_proj(softmax(q_q K^T / 8 | allowed) V), then the MLP.
+    Images with fewer masks are padded with see-everything tokens whose rows are dropped (:793-795,823-824).  Returns [sum n_i, E]."""
+    rq = _Round(emulate_bf16)
+    x, g = stem(sd, cfg, images, rq, prefix)                      # [B, N, C]
+    B, N, C = x.shape
+    H, d = cfg.heads, cfg.head_width
+    counts = [int(m.shape[0]) for m in masks]
+    Q = max(counts)
+    allow = torch.ones(B, Q, N, dtype=torch.bool)                 # key allowed?  column 0 = CLS: always
+    for b, m in enumerate(masks):
+        allow[b, :m.shape[0], 1:] = m.reshape(m.shape[0], -1)
+    xm = x[:, :1].expand(B, Q, C).clone()
+    for i in range(cfg.layers):
+        blk = f"{prefix}transformer.resblocks.{i}."
+        Wqkv, bqkv = sd[blk + "attn.in_proj_weight"], sd[blk + "attn.in_proj_bias"]
+        n1 = rq(layer_norm(x, sd[blk + "ln_1.weight"], sd[blk + "ln_1.bias"], cfg.ln_eps))
+        kv = rq(rq(n1) @ rq(Wqkv[C:]).T + bqkv[C:])               # keys / values of the image's own tokens at this depth
+        k, v = (t.reshape(B, N, H, d).permute(0, 2, 1, 3) for t in kv.split(C, dim=-1))
+        nm = rq(layer_norm(xm, sd[blk + "ln_1.weight"], sd[blk + "ln_1.bias"], cfg.ln_eps))
+        q = rq(rq(nm) @ rq(Wqkv[:C]).T + bqkv[:C]).reshape(B, Q, H, d).permute(0, 2, 1, 3)
+        sc = (q * d ** -0.5) @ k.transpose(-2, -1)                # [B, H, Q, N]
+        att = sc.masked_fill(~allow[:, None], float("-inf")).softmax(dim=-1)
+        om = rq((rq(att) @ v).transpose(1, 2).reshape(B, Q, C))
+        xm = xm + om @ rq(sd[blk + "attn.out_proj.weight"]).T + sd[blk + "attn.out_proj.bias"]
+        n2 = rq(layer_norm(xm, sd[blk + "ln_2.weight"], sd[blk + "ln_2.bias"], cfg.ln_eps))
+        fc = rq(n2 @ rq(sd[blk + "mlp.c_fc.weight"]).T + sd[blk + "mlp.c_fc.bias"])
+        xm = xm + rq(activation(fc, cfg.quick_gelu)) @ rq(sd[blk + "mlp.c_proj.weight"]).T + sd[blk + "mlp.c_proj.bias"]
+        if i + 1 < cfg.layers:
+            x = block(sd, cfg, x, i, rq, True, prefix)            # the image tokens never see the extra ones
+    pooled = rq(layer_norm(xm, sd[prefix + "ln_post.weight"], sd[prefix + "ln_post.bias"], cfg.ln_eps)) @ rq(sd[prefix + "proj"])
+    return torch.cat([pooled[b, :n] for b, n in enumerate(counts)])
+
+
+def extract_roi_features_v1(sd, cfg, images, normed_boxes_list, emulate_bf16=False, prefix="visual."):
+    """_extract_roi_features_v1 (transformer.py:660-671): the boxes rasterised on the token grid, then mask_attn_pool."""
+    g = images.shape[-1] // cfg.patch_size
+    return mask_attn_pool(sd, cfg, images, [boxes_to_masks(b, g, g) for b in normed_boxes_list], emulate_bf16, prefix)
 
 
 def trainable_names(sd, cfg, unlocked_groups: int, prefix="visual."):

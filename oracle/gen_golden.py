@@ -331,6 +331,40 @@ def gen_tiny_openai_stem(oc):
     np.savez_compressed(GOLD / "tiny_openai_stem.npz", **blob)
 
 
+def gen_tiny_openai_maskattn(oc):
+    """OpenAI-CLIP family only: extract_type='v1' and encode_masks(mask_attn=True) (transformer.py:515-521,660-671,736-834) -- every mask /
+    box becomes an extra query token (a copy of the CLS embedding after ln_pre) that runs through all blocks attending the CLS token and
+    the image tokens inside its mask; nobody attends the extra tokens.  Inference vectors: 2 images, 3 + 2 masks (one of them empty), boxes
+    on the native 4x4 grid and on a 64-px image (8x8 grid, rescaled positional embedding)."""
+    blob = {}
+    for tag, quick in (("", False), ("q/", True)):
+        cfg = tiny_openai_cfg(quick)
+        model = _build_openai(oc, cfg, 3)
+        model.eval()
+        gen = torch.Generator().manual_seed(97)
+        images = torch.randn(2, 3, cfg.image_size, cfg.image_size, generator=gen)
+        g = cfg.image_size // cfg.patch_size
+        masks = [torch.rand(3, g, g, generator=gen) > 0.5, torch.rand(2, g, g, generator=gen) > 0.4]
+        masks[0][1] = False                                  # an empty mask: its token attends the CLS token only
+        boxes = [torch.tensor([[0.05, 0.10, 0.60, 0.70], [0.30, 0.26, 0.95, 0.99], [0.55, 0.55, 0.70, 0.60]]),
+                 torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.26, 0.51, 0.74, 0.76]])]
+        with torch.no_grad():
+            blob[tag + "mask_attn"] = model.encode_masks(images, masks, normalize=False, mask_attn=True).numpy()
+            blob[tag + "mask_attn_normalized"] = model.encode_masks(images, masks, normalize=True, mask_attn=True).numpy()
+            blob[tag + "v1"] = model.encode_pseudo_boxes(images, boxes, normalize=False, extract_type="v1").numpy()
+            if not quick:
+                images64 = torch.randn(2, 3, 64, 64, generator=gen)
+                blob["v1_64"] = model.encode_pseudo_boxes(images64, boxes, normalize=False, extract_type="v1").numpy()
+                blob["images64"] = images64.numpy()
+        if not quick:
+            blob["images"] = images.numpy()
+            for i, (m, b) in enumerate(zip(masks, boxes)):
+                blob[f"masks{i}"] = m.numpy()
+                blob[f"boxes{i}"] = b.numpy()
+        print("tiny openai mask_attn", "quick" if quick else "gelu", blob[tag + "mask_attn"].shape, float(np.abs(blob[tag + "mask_attn"]).mean()))
+    np.savez_compressed(GOLD / "tiny_openai_maskattn.npz", **blob)
+
+
 def gen_vitb16(oc):
     """OpenAI-CLIP ViT-B/16 at BASELINE cfg-1 size (2 images x 8 boxes, 224^2), nn.GELU variant (`--pretrained ''` path of the factory):
     loss trajectory, feature slices, every gradient norm."""
@@ -583,9 +617,13 @@ def main():
     if "--openai-stem-only" in sys.argv:
         gen_tiny_openai_stem(oc)
         return
+    if "--openai-maskattn-only" in sys.argv:
+        gen_tiny_openai_maskattn(oc)
+        return
     if "--openai-only" in sys.argv:
         gen_tiny_openai(oc)
         gen_tiny_openai_stem(oc)
+        gen_tiny_openai_maskattn(oc)
         if "--tiny-only" not in sys.argv:
             gen_vitb16(oc)
         return
@@ -606,6 +644,7 @@ def main():
     gen_curve(oc)
     gen_tiny_openai(oc)
     gen_tiny_openai_stem(oc)
+    gen_tiny_openai_maskattn(oc)
     gen_zeroshot(oc)
     gen_params(oc)
     gen_schedules(oc)

@@ -341,6 +341,19 @@ class RefOps:
         o = (self._r(e) @ v) / e.sum(-1, keepdim=True)
         out.copy_(o.permute(0, 2, 1, 3).reshape(B, C).to(torch.bfloat16))
 
+    def attn_query_fwd(self, q, kv, allow, out, B, Q, Ntok, H, scale):
+        """cs_attn_query_fwd: Q query rows per image against the image's keys / values, allow [B*Q, Ntok] uint8; same rounding points as
+        attn_cls_fwd (fp32 scores, exp(s - max) rounded to bf16 for P.V, fp32 row sum of the unrounded ones), no rotary embedding."""
+        C = H * 64
+        qh = q[:, :C].float().reshape(B, Q, H, 64).permute(0, 2, 1, 3)
+        k = kv[:, :C].float().reshape(B, Ntok, H, 64).permute(0, 2, 1, 3)
+        v = kv[:, C:2 * C].float().reshape(B, Ntok, H, 64).permute(0, 2, 1, 3)
+        s = (qh @ k.transpose(-1, -2)) * scale
+        s = s.masked_fill(~allow.view(B, 1, Q, Ntok).bool(), float("-inf"))
+        e = torch.exp(s - s.max(-1, keepdim=True).values)
+        o = (self._r(e) @ v) / e.sum(-1, keepdim=True)
+        out.copy_(o.permute(0, 2, 1, 3).reshape(B * Q, C).to(torch.bfloat16))
+
     def attn_bwd_workspace(self, B, Ntok, H):
         return 4
 

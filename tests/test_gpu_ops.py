@@ -489,6 +489,45 @@ def test_block_layernorms_folded_into_gemms(hip, ref, M, C, Hd, flags):
     check(tag + ".hid_rstd", rh, torch.rsqrt(hf.var(-1, unbiased=False) + 1e-6), 1e-4)
 
 
+@pytest.mark.parametrize("B,Q,Ntok,H", [(3, 5, 197, 12), (2, 1, 17, 2), (2, 9, 577, 16), (4, 3, 65, 4)])
+def test_attention_extra_query_tokens_with_key_masks(hip, ref, B, Q, Ntok, H):
+    """cs_attn_query_fwd (mask-attention pooling of the OpenAI-CLIP family, open_clip/transformer.py:736-834): Q query rows per image against
+    the image's k|v columns of a q|k|v tensor (strided view), per-query key masks incl. a CLS-only row; against the reference op, against
+    the CLS-query kernel (all keys allowed, identity rotary tables) and bit-reproducible."""
+    C = H * 64
+    qkv = rnd((B * Ntok, 3 * C), F32, 1.0, seed=70)
+    qkv[:, C:2 * C] *= 2.0
+    qkv = qkv.to(BF)
+    q = (rnd((B * Q, C), F32, 1.0, seed=71) * 2.0).to(BF)
+    gen = torch.Generator().manual_seed(72)
+    allow = (torch.rand(B * Q, Ntok, generator=gen) > 0.5).to(torch.uint8)
+    allow[:, 0] = 1                                          # the CLS key is always visible in the reference's mask
+    allow[0, 1:] = 0                                         # an empty mask
+    allow[-1] = 1                                            # a see-everything (padding) token
+    o_r = torch.empty(B * Q, C, dtype=BF)
+    ref.attn_query_fwd(q, qkv[:, C:], allow, o_r, B, Q, Ntok, H, 0.125)
+    qd, kvd, ad = q.cuda(), qkv.cuda()[:, C:], allow.cuda()
+    o_d = torch.full((B * Q, C), float("nan"), dtype=BF, device="cuda")
+    hip.attn_query_fwd(qd, kvd, ad, o_d, B, Q, Ntok, H, 0.125)
+    tag = f"attn_query[{B},{Q},{Ntok},{H}]"
+    check(tag + ".o", o_d, o_r, 6e-3)
+    o_d2 = torch.empty_like(o_d)
+    hip.attn_query_fwd(qd, kvd, ad, o_d2, B, Q, Ntok, H, 0.125)
+    assert torch.equal(o_d2, o_d)
+    # CLS-only row: softmax over one key = that key's value row, exactly (bf16 of a bf16)
+    v0 = qkv[:Ntok][0, 2 * C:].cuda()
+    assert torch.equal(o_d[0], v0)
+    # everything allowed == the CLS-query kernel with identity rotary tables (same arithmetic, one query per image)
+    ones = torch.ones(B, Ntok, dtype=torch.uint8, device="cuda")
+    g = int(round((Ntok - 1) ** 0.5))
+    cos, sin = torch.ones(g * g, 64, device="cuda"), torch.zeros(g * g, 64, device="cuda")
+    q1 = q[::Q].contiguous().cuda()
+    a, b = torch.empty(B, C, dtype=BF, device="cuda"), torch.empty(B, C, dtype=BF, device="cuda")
+    hip.attn_query_fwd(q1, kvd, ones, a, B, 1, Ntok, H, 0.125)
+    hip.attn_cls_fwd(q1, kvd, cos, sin, b, B, Ntok, H, 0.125)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,Ntok,H", [(3, 197, 12), (2, 577, 16), (4, 17, 2)])
 def test_attention_fwd_stats_and_layernorm_stats_only(hip, ref, B, Ntok, H):
     C = H * 64

@@ -604,6 +604,37 @@ def test_tiny_openai_vit_stem_groups_match_reference_goldens(golden_dir, tag):
         assert torch.equal(named[n].detach(), sd0[n]) == (tag != "all/"), n
 
 
+@pytest.mark.parametrize("quick", [False, True])
+def test_tiny_openai_vit_mask_attention_pooling_matches_reference_goldens(golden_dir, quick):
+    """extract_type='v1' and encode_masks(mask_attn=True) of the OpenAI-CLIP family (open_clip/transformer.py:660-671,736-834) on the HIP
+    path against vectors of the real reference: 2 images, 3 + 2 masks (one empty), boxes on the native and on the rescaled 8x8 grid."""
+    from clipself_amd.config import tiny_openai_cfg
+    from clipself_amd.open_clip.model import CLIP
+    g = np.load(golden_dir / "tiny_openai_maskattn.npz")
+    cfg, tag = tiny_openai_cfg(quick), "q/" if quick else ""
+    model = CLIP(cfg, trainable=False)
+    model.visual.engine.load_state(seeded_visual_state(cfg, 3))
+    model.eval()
+    assert type(model.visual.engine.ops).__name__ == "HipOps"
+    images = torch.from_numpy(g["images"]).cuda()
+    masks = [torch.from_numpy(g["masks0"]).cuda(), torch.from_numpy(g["masks1"]).cuda()]
+    boxes = [torch.from_numpy(g["boxes0"]).cuda(), torch.from_numpy(g["boxes1"]).cuda()]
+    with torch.no_grad():
+        pooled = model.encode_masks(images, masks, normalize=False, mask_attn=True)
+        normed = model.encode_masks(images, masks, normalize=True, mask_attn=True)
+        v1 = model.encode_pseudo_boxes(images, boxes, normalize=False, extract_type="v1")
+        whole = model.encode_image(images)
+    _log(f"tiny-openai mask_attn quick={quick} rel={rel(pooled, g[tag + 'mask_attn']):.3e} 1-cos={one_minus_cos(pooled, g[tag + 'mask_attn']):.2e} "
+         f"v1 rel={rel(v1, g[tag + 'v1']):.3e}; whole-image box vs image feature rel={rel(v1[3], whole[1]):.3e}")
+    assert rel(pooled, g[tag + "mask_attn"]) < 7e-3 and one_minus_cos(pooled, g[tag + "mask_attn"]) < 2e-5
+    assert rel(normed, g[tag + "mask_attn_normalized"]) < 7e-3 and rel(v1, g[tag + "v1"]) < 7e-3
+    assert rel(v1[3], whole[1]) < 7e-3                     # a box over the whole grid: the passenger token is the CLS token
+    if not quick:
+        with torch.no_grad():
+            v64 = model.encode_pseudo_boxes(torch.from_numpy(g["images64"]).cuda(), boxes, normalize=False, extract_type="v1")
+        assert rel(v64, g["v1_64"]) < 7e-3
+
+
 def test_vitb16_openai_cfg1_matches_reference_goldens(golden_dir):
     """OpenAI-CLIP ViT-B/16, 2 images x 8 boxes, 224^2 through `create_model('ViT-B-16')`: loss within the north-star tolerance,
     feature directions, every gradient norm of the real reference."""
