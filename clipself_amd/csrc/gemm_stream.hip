@@ -530,7 +530,9 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     // a DMA piece stalls its wave for ~100 cycles beside LDS reads; with every wave issuing two pieces in every k-step (round 3) the two
     // waves of a SIMD stall together and the matrix pipe idles, now the stalled wave's partner has a k-step of MFMAs and LDS reads only.
     // Same tiles, same accumulation order: bit-identical outputs; step 704.7 -> 717.5 images/s on one box (profiles/r04_c_dma_roles.md).
-    constexpr bool ROLES = true;
+    // (bf16 kernels.  The e4m3 kernels keep round 3's issue: with the roles' offset registers beside a 48-register fragment set they spilled 36
+    // VGPRs into the K loop -- RegionCLIP L/14-336 fp8 forward + dgrad 451.0 / 452.7 -> 456.4 / 456.8 images/s without, profiles/r04_v_f8_roles.txt)
+    constexpr bool ROLES = !F8;
 #else
     constexpr bool ROLES = false;
 #endif
