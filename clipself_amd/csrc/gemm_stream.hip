@@ -29,6 +29,8 @@
 // Epilogues: bf16 (+bias, optional GELU / QuickGELU, optional folded LayerNorm), fused SwiGLU (+folded LayerNorm, +row statistics of the
 // hidden matrix), fp32 residual (+folded LayerNorm, + bf16 copy and row statistics of the new stream).  Reference call sites:
 // eva_vit_model.py:99-103 (SwiGLU), :177-179 (q|k|v), :218-219 (proj), :306-307 (residual adds); open_clip/transformer.py:195-211.
+#include <vector>
+#include <cstdio>
 #include "gemm_common.h"
 
 namespace {
@@ -351,6 +353,21 @@ __device__ __forceinline__ void epi_swiglu_slab(const GemmArgs& p, const f32x16 
     }
 }
 
+#ifdef CS_ABLATION_SWITCHES
+// Epilogue timeline (env CS_GEMM_TRACE=<file>, tools/epi_trace.py): per workgroup and wave 16 x u64 of the LAST tile's residual epilogue -- the
+// 100 MHz clock at entry and, per 32-row block, after (loads issued + slab written), after every outstanding memory access has landed
+// (an extra s_waitcnt vmcnt(0): the trace build waits for a block's rows at once) and at the block's end.
+__device__ unsigned long long* g_epi_trace = nullptr;
+#define EPI_TRACE(slot)                                                                                                            \
+    do {                                                                                                                           \
+        if (g_epi_trace && (threadIdx.x & 63) == 0)                                                                                \
+            g_epi_trace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();           \
+    } while (0)
+#define EPI_TRACE_WAIT() do { if (g_epi_trace) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#else
+#define EPI_TRACE(slot) do { } while (0)
+#define EPI_TRACE_WAIT() do { } while (0)
+#endif
 // fp32 residual through the slab: the accumulators of one 32-row block go [32 rows][256 bytes] (16-byte slot s of row r at
 // r*256 + (s ^ (r & 15)) * 16, written with 16-byte DS stores while a lane still owns a row) and come back EIGHT lanes per row, eight
 // consecutive columns per lane: every global access of the epilogue is a 16-byte-per-lane request over whole 128- / 256-byte row segments
@@ -382,6 +399,7 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
         if (p.bias) cb4[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.bias), off, 0, 0));
         if (LN || F8) cc4[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.ln_colsum), off, 0, 0));
     }
+    EPI_TRACE(0);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         // the residual rows of the block are requested before the accumulators go through the slab
@@ -416,6 +434,9 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
                 const int s16 = (j * 8 + 2 * q + hf) ^ (l31 & 15);
                 *(f32x4*)(slab + l31 * 256 + s16 * 16) = t;
             }
+        EPI_TRACE(1 + 3 * i);
+        EPI_TRACE_WAIT();
+        EPI_TRACE(2 + 3 * i);
         const int sel = lane & 7;
         float st_s = 0.f, st_q = 0.f;
 #pragma unroll
@@ -473,6 +494,7 @@ __device__ __forceinline__ void epi_resid_slab(const GemmArgs& p, const f32x16 (
             const bool ok = sel < 4 && row0 + rrel < p.M && colw < p.N;
             store8<CP>(u32x2{__float_as_uint(st_s), __float_as_uint(st_q)}, rst, ok ? (unsigned)rrel * 8u : OOB);
         }
+        EPI_TRACE(3 + 3 * i);
         __builtin_amdgcn_sched_barrier(0);       // keep the next block's residual loads (32 registers) out of this block
     }
 }
@@ -1047,7 +1069,29 @@ int cs_gemm_stream_launch_f8(GemmArgs a, int epi, int reserve, hipStream_t strea
 
 // Returns 1 when the problem is outside what the register epilogues cover (the caller falls back to gemm_persist_kernel), 0 on launch,
 // < 0 on error.  `a` arrives with M/N/K, leading dimensions, operands and epilogue operands set (gemm_nt_impl); reserve = CUs to leave free.
+#ifdef CS_ABLATION_SWITCHES
+static int stream_launch_impl(GemmArgs a, int epi, int reserve, hipStream_t stream);
 int cs_gemm_stream_launch(GemmArgs a, int epi, int reserve, hipStream_t stream) {
+    static const char* path = getenv("CS_GEMM_TRACE");
+    static unsigned long long* buf = nullptr;
+    constexpr size_t WORDS = 256 * 8 * 16;
+    if (path && !buf && hipMalloc((void**)&buf, WORDS * 8) == hipSuccess) {
+        (void)hipMemset(buf, 0, WORDS * 8);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_epi_trace), &buf, sizeof(buf));
+    }
+    const int rc = stream_launch_impl(a, epi, reserve, stream);
+    if (path && buf && rc == 0 && (epi == EPI_RESID_F32 || epi == EPI_RESID_LN_F32)) {      // the last launch's timeline survives in the file
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> host(WORDS);
+        (void)hipMemcpy(host.data(), buf, WORDS * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(path, "wb")) { fwrite(host.data(), 8, WORDS, f); fclose(f); }
+    }
+    return rc;
+}
+static int stream_launch_impl(GemmArgs a, int epi, int reserve, hipStream_t stream) {
+#else
+int cs_gemm_stream_launch(GemmArgs a, int epi, int reserve, hipStream_t stream) {
+#endif
     const bool swi = epi == EPI_SWIGLU_BF16, res = epi == EPI_RESID_F32 || epi == EPI_RESID_LN_F32;
     if (!(swi || res || epi == EPI_BF16 || epi == EPI_QGELU_BF16)) return 1;      // exact GELU (erf) keeps the slab epilogue: register pressure
     if (a.M < 1 || a.K % BK != 0) return 1;
