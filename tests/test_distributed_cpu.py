@@ -158,6 +158,12 @@ def test_two_rank_unlocked_tower(tmp_path):
     run_two_rank_equivalence("cpu", tmp_path, 1e-3, lock=False)
 
 
+def test_two_rank_unlocked_openai_tower(tmp_path):
+    """The OpenAI-CLIP family without --lock-image (round 4: ln_post / proj and the stem train): "head" and "stem" buckets, same step as one
+    process on the union batch."""
+    run_two_rank_equivalence("cpu", tmp_path, 1e-3, family="openai", lock=False)
+
+
 def test_stats_are_not_collected_unless_asked(tmp_path):
     """A training run (training/main.py) never drains the wrapper's statistics, so without collect_stats(True) no timing event or
     per-bucket record may be kept from one step to the next (two live device events per step, forever)."""
