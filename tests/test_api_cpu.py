@@ -53,7 +53,7 @@ def test_three_training_steps_through_the_reference_call_contract(golden_dir):
         assert bs == rec["batch"] and set(out) == {"loss_cosine", "loss"}
         assert float(logit_scale) == pytest.approx(1 / 0.07, rel=1e-5)
         assert opt.param_groups[0]["lr"] == pytest.approx(g["lrs"][step])
-        losses.append(float(out["loss"]))
+        losses.append(float(out["loss"].detach()))
         if step == 0:
             none = {str(n) for n in g["grad_none"]}
             for n, p in student.named_parameters():

@@ -80,7 +80,7 @@ def test_tiny_step_matches_reference_goldens(golden_dir):
     for step in range(rec["steps"]):
         batch = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"] + step)
         out, bs, _ = train_step(student, CLIPSelf(), batch, opt, sched, step, teacher, _args())
-        losses.append(float(out["loss"]))
+        losses.append(float(out["loss"].detach()))
         if step == 0:
             none = {str(n) for n in g["grad_none"]}
             worst = 0.0
@@ -128,7 +128,7 @@ def test_b16_cfg1_matches_reference_goldens(golden_dir):
             assert rel(t.norm(dim=-1), g["teacher_rownorm"]) < 1e-3 and rel(s.norm(dim=-1), g["student_rownorm"]) < 4e-4     # 4.7e-4 / 1.8e-4
             assert float((cos - torch.from_numpy(g["cos"])).abs().max()) < 3.4e-3                                       # 1.7e-3
         out, bs, _ = train_step(student, CLIPSelf(), batch, opt, sched, step, teacher, _args())
-        losses.append(float(out["loss"]))
+        losses.append(float(out["loss"].detach()))
         if step == 0:
             none = {str(n) for n in g["grad_none"]}
             norms = dict(zip((str(x) for x in g["grad_names"]), g["grad_norms"]))
@@ -527,7 +527,7 @@ def test_tiny_openai_vit_step_matches_reference_goldens(golden_dir, quick):
     for step in range(steps):
         batch = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"] + step)
         out, bs, _ = train_step(student, CLIPSelf(), batch, opt, sched, step, teacher, _args())
-        losses.append(float(out["loss"]))
+        losses.append(float(out["loss"].detach()))
         if step == 0:
             worst, checked = 0.0, 0
             for n, p in student.named_parameters():
@@ -669,7 +669,7 @@ def test_vitb16_openai_cfg1_matches_reference_goldens(golden_dir):
             assert rel(t.norm(dim=-1), g["teacher_rownorm"]) < 1e-3 and rel(s.norm(dim=-1), g["student_rownorm"]) < 4e-4     # 4.7e-4 / 1.8e-4
             assert float((cos - torch.from_numpy(g["cos"])).abs().max()) < 3.4e-3                                       # 1.7e-3
         out, bs, _ = train_step(student, CLIPSelf(), batch, opt, sched, step, teacher, _args())
-        losses.append(float(out["loss"]))
+        losses.append(float(out["loss"].detach()))
         if step == 0:
             norms = dict(zip((str(x) for x in g["grad_names"]), g["grad_norms"]))
             worst = ("", 0.0)

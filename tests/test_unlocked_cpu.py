@@ -64,7 +64,7 @@ def check_unlocked_step(golden_dir, ops_cls, device, tol_grad, tol_final):
     for step in range(rec["steps"]):
         batch = synthetic_batch(rec["batch"], rec["boxes"], cfg.image_size, cfg.image_size, seed=rec["seed_b"] + step)
         out, _, _ = train_step(student, CLIPSelf(), tuple(t.to(device) for t in batch), opt, sched, step, teacher, args)
-        losses.append(float(out["loss"]))
+        losses.append(float(out["loss"].detach()))
         if step == 0:
             none = {str(n) for n in g["grad_none"]}
             for n, p in student.named_parameters():
