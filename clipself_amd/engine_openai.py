@@ -221,17 +221,21 @@ class ClipVitEngine(EvaEngine):
                         fc=fc, hid=hid)
         return x2
 
-    def _teacher_block_folded(self, i, x, xb, st, B, N, cos, sin, emit_next):
+    def _teacher_block_folded(self, i, x, xb, st, B, N, cos, sin, emit_next, lo=None):
         """One frozen-tower block with both LayerNorms folded into the GEMMs (in place on x).  xb / st = bf16 copy and (mean, rstd) of x as
         left by the previous block's c_proj GEMM, or None (first block: plain ln_1 kernel).  Returns (xb, st) for the next block when
-        emit_next."""
+        emit_next.  With lo (int16 [M, C]; round 4) the stream lives in the two 16-bit planes (xb, lo) between the first residual GEMM of
+        the tower, which reads fp32 x, and the last one (emit_next False), which writes fp32 x again -- cs_gemm_nt_ln_split as in the EVA02
+        engine: 8 instead of 10 bytes per stream element and residual GEMM, same fp32 values.  This family has no LayerNorm in front of
+        out_proj / c_proj, so the split kernel gets the identity statistics (mean 0, rstd 1, column sums 0: x + 1 * (acc - 0 * 0) + b)."""
         ops, cfg = self.ops, self.cfg
         C, Hd, H, eps = cfg.width, cfg.hidden, cfg.heads, cfg.ln_eps
         b = f"{self.prefix}{self.BLOCK_TAG}{i}."
         M = B * N
         f = self.fold[i]
         qkv = ops.empty((M, 3 * C), BF16)
-        if xb is None:
+        first = xb is None
+        if first:
             ln1 = ops.empty((M, C), BF16)
             ops.layernorm_fwd(x, self.p[b + "ln_1.weight"], self.p[b + "ln_1.bias"], ln1, None, None, eps)
             ops.gemm_nt(ln1, self.w[b + "attn.in_proj_weight"], qkv, bias=self.p[b + "attn.in_proj_bias"], epi=EPI_BF16)
@@ -241,21 +245,39 @@ class ClipVitEngine(EvaEngine):
         att = ops.empty((M, C), BF16)
         ops.attn_fwd(qkv, cos, sin, att, None, B, N, H, cfg.head_width ** -0.5)
         part = ops.empty(((C + 63) // 64, M, 2), F32)
-        xb2 = ops.empty((M, C), BF16)
-        ops.gemm_nt_ln(att, self.w[b + "attn.out_proj.weight"], x, bias=self.p[b + "attn.out_proj.bias"], extra=x, stats_part=part, xb_out=xb2,
-                       epi=EPI_RESID_F32)
+        xb2 = xb if (lo is not None and not first) else ops.empty((M, C), BF16)
+        ident = self._identity_stats(M, C) if lo is not None else None
+        wo, bo = self.w[b + "attn.out_proj.weight"], self.p[b + "attn.out_proj.bias"]
+        if lo is not None:
+            ops.gemm_nt_ln_split(att, wo, xb2, lo, bo, *ident, x_in=x if first else None, stats_part=part)
+        else:
+            ops.gemm_nt_ln(att, wo, x, bias=bo, extra=x, stats_part=part, xb_out=xb2, epi=EPI_RESID_F32)
         mean, rstd = ops.empty((M,), F32), ops.empty((M,), F32)
         ops.ln_stats_finalize(part, 64, C, mean, rstd, eps)
         Wf, cf, df = f["fc"]
         hid = ops.empty((M, Hd), BF16)
         ops.gemm_nt_ln(xb2, Wf, hid, bias=df, ln_mean=mean, ln_rstd=rstd, ln_colsum=cf, epi=EPI_QGELU_BF16 if cfg.quick_gelu else EPI_GELU_BF16)
         wp, bp = self.w[b + "mlp.c_proj.weight"], self.p[b + "mlp.c_proj.bias"]
-        if not emit_next:
-            ops.gemm_nt(hid, wp, x, bias=bp, extra=x, epi=EPI_RESID_F32)
-            return None, None
-        ops.gemm_nt_ln(hid, wp, x, bias=bp, extra=x, stats_part=part, xb_out=xb2, epi=EPI_RESID_F32)
+        if lo is not None:
+            if not emit_next:
+                ops.gemm_nt_ln_split(hid, wp, xb2, lo, bp, *ident, x_out=x)
+                return None, None
+            ops.gemm_nt_ln_split(hid, wp, xb2, lo, bp, *ident, stats_part=part)
+        else:
+            if not emit_next:
+                ops.gemm_nt(hid, wp, x, bias=bp, extra=x, epi=EPI_RESID_F32)
+                return None, None
+            ops.gemm_nt_ln(hid, wp, x, bias=bp, extra=x, stats_part=part, xb_out=xb2, epi=EPI_RESID_F32)
         ops.ln_stats_finalize(part, 64, C, mean, rstd, eps)
         return xb2, (mean, rstd)
+
+    def _identity_stats(self, M, C):
+        """(mean = 0 [M], rstd = 1 [M], column sums = 0 [C]): statistics under which a folded-LayerNorm epilogue is the plain one, bit for bit."""
+        key = ("ident", M, C)
+        if key not in self._tables:
+            self._tables[key] = (torch.zeros(M, dtype=F32, device=self.device), torch.ones(M, dtype=F32, device=self.device),
+                                 torch.zeros(C, dtype=F32, device=self.device))
+        return self._tables[key]
 
     def _block_fwd_cls(self, i, x, B, N, cos, sin):
         """Last teacher block restricted to what forward() consumes: the CLS row.  x fp32 [B*N, C] -> fp32 [B, C]; keys and values still
@@ -302,9 +324,10 @@ class ClipVitEngine(EvaEngine):
             xf = x.view(B * N, cfg.width)
             last = cfg.layers - 1 if self.cls_only_last_block else cfg.layers
             xb = st = None
+            lo = ops.empty((B * N, cfg.width), torch.int16) if fold_blocks and self.split_stream and last > 1 else None
             for i in range(last):
                 if fold_blocks:
-                    xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last)
+                    xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last, lo=lo)
                 else:
                     self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
             xc = self._block_fwd_cls(last, xf, B, N, cos, sin) if last < cfg.layers else x[:, 0, :]

@@ -134,6 +134,10 @@ def test_engine_teacher_schedule_variants_are_the_same_function(gold, quick):
     eng = _engine(cfg, rec["seed_w"], False)
     assert eng.cls_only_last_block and eng.fold_block_ln and not _engine(cfg, rec["seed_w"], True).fold_block_ln
     fast = eng.encode_image(crops.flatten(0, 1), chunk=4)
+    assert eng.split_stream                                   # round 4: the folded schedule keeps the stream as two 16-bit planes ...
+    eng.split_stream = False
+    assert torch.equal(eng.encode_image(crops.flatten(0, 1), chunk=4), fast)      # ... which hold the same fp32 values, bit for bit
+    eng.split_stream = True
     eng.fold_block_ln = False
     cls_only = eng.encode_image(crops.flatten(0, 1), chunk=4)
     eng.cls_only_last_block = False
