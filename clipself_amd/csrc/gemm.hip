@@ -613,7 +613,7 @@ int launch_persist(GemmArgs a, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (EPI == EPI_SWIGLU_BF16) ? (a.group + BN / 2 - 1) / (BN / 2) : (a.N + BN - 1) / BN;
     const long ntiles = (long)a.tiles_m * a.tiles_n;
-    const long cap = cs_persistent_cap(a.reserve);       // flags bits 20-26: compute units left free
+    const long cap = cs_persistent_cap(a.reserve);       // flags bits 20-27: compute units left free
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
     if constexpr (EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16) {           // the wide-N GEMMs of the towers (q|k|v, W1|W2)
         const bool parts_ok = (long)grid == cs_persistent_cap(0) && a.tiles_n >= a.nsplit && a.tiles_m >= 8 / a.nsplit;
@@ -709,7 +709,7 @@ int launch(GemmArgs a, int splits, int use_glds, int force_cfg, hipStream_t stre
 //       bit 12: streaming kernel: slab form of the bf16 / SwiGLU epilogues (exact A/B switch); bit 15: split-ring schedule issues its DMA in
 //               one burst behind the barrier instead of interleaved with the MFMAs (exact A/B switch).  Builds with -DCS_ABLATION_SWITCHES
 //               additionally read bits 12-14 as timing ablations with wrong results (gemm_common.h: CS_ABL); the shipped library does not.
-//       bits 20-26: compute units the persistent kernels leave free (grid = compute units - n; multi-GPU runs keep room for RCCL's kernels)
+//       bits 20-27: compute units the persistent kernels leave free (grid = compute units - n; multi-GPU runs keep room for RCCL's kernels)
 //       bits 16-17 (persistent kernel, epilogues 0 and 3): 1 = B-stationary raster (each XCD keeps its share of B in L2; bits 8-11 = N parts,
 //                 0 = automatic), 2 = the same with non-temporal A loads, 3 = grouped raster with non-temporal B loads
 static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias, const float* extra, const float* ln_mean,
@@ -758,7 +758,7 @@ static int gemm_nt_impl(const void* A, const void* B, void* C, const float* bias
     const int glds = (flags & 1) ? 0 : 1;
     const int force = (flags >> 4) & 15;
     a.dbg = (flags >> 12) & 15;
-    a.reserve = (flags >> 20) & 127;
+    a.reserve = (flags >> 20) & 255;
     switch (epi) {
         case EPI_BF16: return launch<EPI_BF16>(a, splits, glds, force, stream);
         case EPI_F32: return launch<EPI_F32>(a, splits, glds, force, stream);

@@ -66,7 +66,7 @@ inline int cs_num_cus() {
     }();
     return n;
 }
-// persistent grid: one workgroup per compute unit, minus the ones the caller keeps free (cs_gemm_nt flags bits 20-26)
+// persistent grid: one workgroup per compute unit, minus the ones the caller keeps free (cs_gemm_nt flags bits 20-27)
 inline long cs_persistent_cap(int reserve) {
     const int n = cs_num_cus();
     return n - (reserve > 0 && reserve < n - 32 ? reserve : 0);

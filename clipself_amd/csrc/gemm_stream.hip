@@ -1164,7 +1164,7 @@ extern "C" int cs_gemm_nt_ln_split(const void* A, const void* B, const float* bi
     a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_colsum = ln_colsum; a.stats_part = stats_part; a.xb_out = (__bf16*)hi; a.ldxb = ldxb;
     a.lo = (unsigned short*)lo;
     a.split = (x_in == nullptr ? 1 : 0) | (x_out == nullptr ? 2 : 0);
-    a.reserve = (flags >> 20) & 127;
+    a.reserve = (flags >> 20) & 255;
     a.dbg = (flags >> 12) & 15;
     a.tiles_m = (M + 255) / 256;
     a.tiles_n = (N + 255) / 256;
@@ -1179,7 +1179,7 @@ extern "C" int cs_gemm_nt_ln_split(const void* A, const void* B, const float* bi
 // C ABI: fp8 (OCP e4m3) operands quantised row-wise by cs_quant_rows_fp8 -- BASELINE configs[4] "fp8 MFMA weights".
 //   C[m, n] = row_scale[m] * col_scale[n] * sum_k A8[m, k] * B8[n, k] + bias[n]  (+ extra[m, n] for epi 2)
 //   epi 0: C bf16 [M, ldc];  epi 2: C fp32 [M, ldc] = extra + ..., in place allowed.  K8 = bytes per operand row (contraction length padded
-//   to a multiple of 128 with zero bytes), lda / ldb = row strides in bytes.  flags bits 20-26 as cs_gemm_nt (compute units left free).
+//   to a multiple of 128 with zero bytes), lda / ldb = row strides in bytes.  flags bits 20-27 as cs_gemm_nt (compute units left free).
 extern "C" int cs_gemm_nt_f8(const void* A8, const void* B8, void* C, const float* bias, const float* extra, const float* row_scale,
                              const float* col_scale, int M, int N, int K8, int lda, int ldb, int ldc, int epi, int flags, hipStream_t stream) {
     CS_CHECK_ARG(M > 0 && N > 0 && K8 > 0 && K8 % 128 == 0, "cs_gemm_nt_f8: K8=%d must be a positive multiple of 128 (M=%d N=%d)", K8, M, N);
@@ -1195,7 +1195,7 @@ extern "C" int cs_gemm_nt_f8(const void* A8, const void* B8, void* C, const floa
     a.M = M; a.N = N; a.K = K8; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.group = 0;
     a.tiles_m = a.tiles_n = 0; a.ktiles_per_split = K8 / 128; a.split_stride = 0; a.gm = 8; a.rm = 0; a.nsplit = 1;
     a.ln_mean = nullptr; a.ln_rstd = row_scale; a.ln_colsum = col_scale; a.stats_part = nullptr; a.xb_out = nullptr; a.ldxb = 0;
-    a.reserve = (flags >> 20) & 127;
+    a.reserve = (flags >> 20) & 255;
     a.dbg = (flags >> 12) & 15;
     return cs_gemm_stream_launch_f8(a, epi, a.reserve, stream);
 }

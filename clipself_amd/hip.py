@@ -127,14 +127,14 @@ class HipOps:
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise RuntimeError("HipOps needs a ROCm device (torch.cuda.is_available() is False); no CPU fallback exists")
-        # OR-ed into the flags of every GEMM call: bits 20-26 = compute units the persistent GEMM kernels leave free
+        # OR-ed into the flags of every GEMM call: bits 20-27 = compute units the persistent GEMM kernels leave free
         # (training/distributed.py reserves a few for RCCL's reduction kernels in data-parallel runs)
         self.gemm_flags = 0
 
     def reserve_compute_units(self, n: int):
         """Persistent GEMM grids use 256 - n compute units from now on (0 = all)."""
-        assert 0 <= n < 128
-        self.gemm_flags = (self.gemm_flags & ~(127 << 20)) | (int(n) << 20)
+        assert 0 <= n < 256
+        self.gemm_flags = (self.gemm_flags & ~(255 << 20)) | (int(n) << 20)
 
     # -- helpers ---------------------------------------------------------------------------------
     def _stream(self):

@@ -34,7 +34,7 @@ const char* cs_last_error(void);
  *        (src/open_clip/transformer.py:209-213 `mlp`, :31-34 `QuickGELU`)
  * flags bit0: use register staging instead of the global_load_lds DMA path; bits 4-7: force a tile schedule (0 = heuristic; 11 = the
  * streaming persistent kernel with register-level epilogues, the default for the bf16 / QuickGELU / SwiGLU epilogues of large problems);
- * bits 20-26: compute units the persistent kernels leave free (0 = use all 256; data-parallel runs reserve a few for RCCL's kernels). */
+ * bits 20-27: compute units the persistent kernels leave free (0 = use all 256; data-parallel runs reserve a few for RCCL's kernels). */
 int cs_gemm_nt(const void* A, const void* B, void* C, const float* bias, const float* extra, int M, int N, int K,
                int lda, int ldb, int ldc, int epi, int splits, int group, int flags, cs_stream_t stream);
 
@@ -86,7 +86,7 @@ int cs_gemm_nt_ln(const void* A, const void* B, void* C, const float* bias, cons
  *   stats_part: per 64-column slice (sum, sum of squares) of the fp32 outputs as in cs_gemm_nt_ln; required when the stream leaves
  *               split (x_out == NULL), rejected with x_out != NULL.
  * out = x + rstd[m] * (A.B^T - mean[m] * ln_colsum[n]) + bias[n];  N % 32 == 0, K % 64 == 0; hi / lo 16-byte aligned with ldxb % 8 == 0
- * (the planes move in 16-byte pieces); flags bits 20-26 as cs_gemm_nt. */
+ * (the planes move in 16-byte pieces); flags bits 20-27 as cs_gemm_nt. */
 int cs_gemm_nt_ln_split(const void* A, const void* B, const float* bias, const float* ln_mean, const float* ln_rstd,
                         const float* ln_colsum, const float* x_in, float* x_out, void* hi, void* lo, int ldxb, float* stats_part,
                         int M, int N, int K, int lda, int ldb, int ldc, int flags, cs_stream_t stream);
