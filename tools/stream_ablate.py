@@ -2,7 +2,7 @@
 """Main loop / epilogue split of the streaming GEMM on the tower shapes: cs_gemm_nt schedule 11 with the timing ablations of a
 -DCS_ABLATION_SWITCHES build (dbg 4 = no epilogue, dbg 8 = every store masked, dbg 2 = no barrier; wrong results by construction).
 env ABLATE_DBG (list of dbg values), ABLATE_RESERVE (compute units left free: grid = 256 - reserve; is the epilogue's cost per CU or per chip?),
-ABLATE_SHAPES (substring filter).   usage (GPU box): CLIPSELF_HIP_LIB=<ablation build> python tools/stream_ablate.py [crops=2048] [tag]"""
+ABLATE_SHAPES (substring filter), ABLATE_DATA (randn | zeros | const | sparse operand values).   usage (GPU box): CLIPSELF_HIP_LIB=<ablation build> python tools/stream_ablate.py [crops=2048] [tag]"""
 import os
 import sys
 from pathlib import Path
@@ -29,6 +29,13 @@ def main():
             continue
         A = torch.randn(M, K, device="cuda").to(BF)
         B = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
+        data = os.environ.get("ABLATE_DATA", "randn")           # operand values: the clock under matrix load follows the power they draw
+        if data == "zeros":
+            A.zero_(); B.zero_()
+        elif data == "const":
+            A.fill_(1.0); B.fill_(0.5)
+        elif data == "sparse":                                   # 3 of 4 elements zero
+            A[:, torch.arange(K, device="cuda") % 4 != 0] = 0
         bias = torch.randn(N, device="cuda")
         if epi == 0:
             C, extra, group = torch.empty(M, N, dtype=BF, device="cuda"), None, 0
@@ -37,7 +44,7 @@ def main():
             extra, group = C, 0
         else:
             C, extra, group = torch.empty(M, N // 2, dtype=BF, device="cuda"), None, N // 2
-        line = f"[{tag} reserve={reserve}] {name}:"
+        line = f"[{tag} reserve={reserve} data={os.environ.get('ABLATE_DATA', 'randn')}] {name}:"
         for dbg in [int(x) for x in os.environ.get("ABLATE_DBG", "0,4,8,0,4").split(",")]:
             flags = (11 << 4) | (8 << 8) | (dbg << 12) | (reserve << 20)
             for _ in range(2):
