@@ -316,9 +316,9 @@ class CustomCLIP(nn.Module):
         return features
 
     def encode_masks(self, image, masks, normalize=True, mask_attn=False):
-        if mask_attn:                                       # model.py:245-247 of the reference; the OpenAI-CLIP family only (EVA02 has no such method)
-            if not hasattr(self.visual, "mask_attn_pool"):
-                raise NotImplementedError("mask_attn=True exists for the OpenAI-CLIP ViT family only (open_clip/transformer.py:785-834)")
+        # open_clip/model.py:245-247: the OpenAI-CLIP family pools through extra query tokens when mask_attn is set; the EVA02 model takes the
+        # argument and ignores it (eva_clip/model.py:342-346: always mask_pool) -- and so does this one
+        if mask_attn and hasattr(self.visual, "mask_attn_pool"):
             mask_pooled = self.visual.mask_attn_pool(image, masks)
         else:
             mask_pooled = self.visual.mask_pool(image, masks)

@@ -82,6 +82,12 @@ def test_list_of_boxes_and_no_grad_paths_agree():
     assert b.requires_grad and float((a - b.detach()).norm() / a.norm()) < 1e-2
     assert d.shape == (2, cfg.embed_dim, cfg.grid, cfg.grid)
     assert torch.allclose(d.norm(dim=1), torch.ones(2, cfg.grid, cfg.grid), atol=1e-5)
+    # the EVA02 model takes `extract_type` and `mask_attn` and ignores them (eva_vit_model.py:625-629 `**kwargs`, eva_clip/model.py:342-346):
+    # zero_shot.py:73-76 passes extract_type='v1' / mask_attn=True to whatever model it is given
+    masks = [torch.rand(2, cfg.grid, cfg.grid) > 0.5, torch.rand(3, cfg.grid, cfg.grid) > 0.5]
+    with torch.no_grad():
+        assert torch.equal(student.encode_pseudo_boxes(images, rois_list, normalize=False, extract_type="v1"), a)
+        assert torch.equal(student.encode_masks(images, masks, mask_attn=True), student.encode_masks(images, masks, mask_attn=False))
     # ragged batch through the method (invalid rows dropped like clipself.py:29-36)
     out, bs, _ = CLIPSelf()((images, boxes, crops), student, teacher, None, "cpu", None, False, _args())
     assert bs == 2 and torch.isfinite(out["loss_cosine"])
