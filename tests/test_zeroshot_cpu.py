@@ -59,3 +59,26 @@ def test_macc_is_the_reference_metric(golden_dir):
 
 def test_zero_shot_run_matches_reference(golden_dir):
     run_zeroshot(RefOps, "cpu", golden_dir)
+
+
+def test_zero_shot_run_with_the_openai_family_and_extract_type_v1():
+    """`--extract-type v1` on the OpenAI-CLIP family (zero_shot.py:73-76 of the reference): box features through the extra query tokens,
+    mask features through encode_masks(mask_attn=True); end to end through run() on the synthetic panoptic loader."""
+    from clipself_amd.config import tiny_openai_cfg
+    from clipself_amd.open_clip import CLIP
+    cfg = tiny_openai_cfg()
+    model = CLIP(cfg, ops=RefOps(), trainable=False)
+    model.visual.engine.load_state(seeded_visual_state(cfg, 3))
+    model.eval()
+    g = cfg.image_size // cfg.patch_size
+    out = {}
+    for et in ("v1", "v2"):
+        val = SyntheticPanopticVal(2, 2, 3, cfg.image_size, cfg.image_size, g, cfg.embed_dim, num_classes=7, seed=11)
+        args = SimpleNamespace(device="cpu", precision="fp32", distributed=False, horovod=False, extract_type=et, image_ave_pool=False,
+                               zeroshot_frequency=1, epochs=1, rank=0)
+        out[et] = {k: v.cpu() for k, v in run(model, _ValLoader(val), args).items()}
+    for key in ("rois", "maskpool"):
+        a, b = out["v1"]["sim_" + key], out["v2"]["sim_" + key]
+        assert torch.isfinite(a).all() and a.shape == b.shape
+        assert float((a - b).abs().max()) > 1e-4, key       # a different pooling, not the dense-map one under another name
+    assert torch.equal(out["v1"]["sim_crops"], out["v2"]["sim_crops"])      # crop features do not depend on the extract type
