@@ -508,6 +508,13 @@ constexpr int epi_stores() {
     return FM * 4;
 }
 
+// cache policy of the operand DMA (gfx950 aux bits: 0 default | 1 = sc0 | 2 = nt | 16 = sc1); A/B experiments: -DCS_DMA_AUX_A=.. -DCS_DMA_AUX_B=..
+#ifndef CS_DMA_AUX_A
+#define CS_DMA_AUX_A 0
+#endif
+#ifndef CS_DMA_AUX_B
+#define CS_DMA_AUX_B 0
+#endif
 #define CS_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 inline bool getenv_flag(const char* name) {       // A/B switch, read at every launch (~0.1 us) so that a test can flip it inside one process
@@ -635,18 +642,18 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
     };
 #define ISSUE_A(X, SLOT)                                                                                                      \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + (size_t)a_kt * (BK * 2) + avoff[X]), \
-                                     (__attribute__((address_space(3))) void*)(smem + (SLOT) * A_BYTES + (wave * 4 + (X)) * 1024), 16, 0, 0)
+                                     (__attribute__((address_space(3))) void*)(smem + (SLOT) * A_BYTES + (wave * 4 + (X)) * 1024), 16, 0, CS_DMA_AUX_A)
 #define ISSUE_B(X, SLOT)                                                                                                      \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + (size_t)b_kt * (BK * 2) + bvoff[X]), \
-                                     (__attribute__((address_space(3))) void*)(b_ring + (SLOT) * B_BYTES + (wave * 4 + (X)) * 1024), 16, 0, 0)
+                                     (__attribute__((address_space(3))) void*)(b_ring + (SLOT) * B_BYTES + (wave * 4 + (X)) * 1024), 16, 0, CS_DMA_AUX_B)
 
     // ROLES: piece X of the wave's own operand tile (B: 8 pieces per wave, A: NPA) -- LDS rows (first piece + X) * 4 .. + 3 of the slot
 #define ISSUE_RA(X, SLOT)                                                                                                     \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + (size_t)a_kt * (BK * 2) + avoff[X]), \
-                                     (__attribute__((address_space(3))) void*)(smem + (SLOT) * A_BYTES + ((wave & 3) * NPA + (X)) * 1024), 16, 0, 0)
+                                     (__attribute__((address_space(3))) void*)(smem + (SLOT) * A_BYTES + ((wave & 3) * NPA + (X)) * 1024), 16, 0, CS_DMA_AUX_A)
 #define ISSUE_RB(X, SLOT)                                                                                                     \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src + (size_t)b_kt * (BK * 2) + avoff[X]), \
-                                     (__attribute__((address_space(3))) void*)(b_ring + (SLOT) * B_BYTES + ((wave & 3) * 8 + (X)) * 1024), 16, 0, 0)
+                                     (__attribute__((address_space(3))) void*)(b_ring + (SLOT) * B_BYTES + ((wave & 3) * 8 + (X)) * 1024), 16, 0, CS_DMA_AUX_B)
 
     if constexpr (ROLES) {
         if (role_a) {
