@@ -62,6 +62,7 @@ class ClipVitEngine(EvaEngine):
         # CLS query only (forward() consumes x[:, 0] alone, transformer.py:486-494).  Same switches as the EVA02 engine.
         self.fold_block_ln = not trainable
         self.cls_only_last_block = True
+        self.fold_cls_block = True                              # ln_1 of the CLS-only block folded into its K|V GEMM (A/B switch)
         # lock() with more groups than blocks (transformer.py:391-422): 1 = positional_embedding trains, 2 = conv1 / class_embedding / ln_pre too
         self.stem_level = 0
 
@@ -279,23 +280,34 @@ class ClipVitEngine(EvaEngine):
                                  torch.zeros(C, dtype=F32, device=self.device))
         return self._tables[key]
 
-    def _block_fwd_cls(self, i, x, B, N, cos, sin):
+    def _block_fwd_cls(self, i, x, B, N, cos, sin, xb=None, st=None, lo=None):
         """Last teacher block restricted to what forward() consumes: the CLS row.  x fp32 [B*N, C] -> fp32 [B, C]; keys and values still
-        come from every token.  Row-for-row the same arithmetic as _block_fwd."""
+        come from every token.  Row-for-row the same arithmetic as _block_fwd.  With xb / st (/ lo) -- the bf16 operand view, ln_1 statistics
+        (and low plane) the previous folded block left -- ln_1 is folded into the K|V GEMM like in every other block (no LayerNorm pass over
+        the whole stream, which never returns to fp32) and only the B CLS rows are rebuilt in fp32 (EvaEngine._block_fwd_cls)."""
         ops, cfg = self.ops, self.cfg
         C, Hd, H, eps = cfg.width, cfg.hidden, cfg.heads, cfg.ln_eps
         b = f"{self.prefix}{self.BLOCK_TAG}{i}."
         M = B * N
-        ln1 = ops.empty((M, C), BF16)
-        ops.layernorm_fwd(x, self.p[b + "ln_1.weight"], self.p[b + "ln_1.bias"], ln1, None, None, eps)
         wqkv, bqkv = self.w[b + "attn.in_proj_weight"], self.p[b + "attn.in_proj_bias"]
         kv = ops.empty((M, 2 * C), BF16)
-        ops.gemm_nt(ln1, wqkv[C:], kv, bias=bqkv[C:], epi=EPI_BF16)
         q = ops.empty((B, C), BF16)
-        ops.gemm_nt(ln1.view(B, N, C)[:, 0, :], wqkv[:C], q, bias=bqkv[:C], epi=EPI_BF16)
+        if xb is not None:
+            Wq, cq, dq = self.fold[i]["qkv"]
+            ops.gemm_nt_ln(xb, Wq[C:], kv, bias=dq[C:], ln_mean=st[0], ln_rstd=st[1], ln_colsum=cq[C:], epi=EPI_BF16)
+            xc = (self._join_planes(xb.view(B, N, C)[:, 0, :], lo.view(B, N, C)[:, 0, :]) if lo is not None
+                  else x.view(B, N, C)[:, 0, :].contiguous())
+            ln1c = ops.empty((B, C), BF16)
+            ops.layernorm_fwd(xc, self.p[b + "ln_1.weight"], self.p[b + "ln_1.bias"], ln1c, None, None, eps)
+            ops.gemm_nt(ln1c, wqkv[:C], q, bias=bqkv[:C], epi=EPI_BF16)
+        else:
+            ln1 = ops.empty((M, C), BF16)
+            ops.layernorm_fwd(x, self.p[b + "ln_1.weight"], self.p[b + "ln_1.bias"], ln1, None, None, eps)
+            ops.gemm_nt(ln1, wqkv[C:], kv, bias=bqkv[C:], epi=EPI_BF16)
+            ops.gemm_nt(ln1.view(B, N, C)[:, 0, :], wqkv[:C], q, bias=bqkv[:C], epi=EPI_BF16)
+            xc = x.view(B, N, C)[:, 0, :].contiguous()
         att = ops.empty((B, C), BF16)
         ops.attn_cls_fwd(q, kv, cos, sin, att, B, N, H, cfg.head_width ** -0.5)
-        xc = x.view(B, N, C)[:, 0, :].contiguous()
         ops.gemm_nt(att, self.w[b + "attn.out_proj.weight"], xc, bias=self.p[b + "attn.out_proj.bias"], extra=xc, epi=EPI_RESID_F32)
         ln2 = ops.empty((B, C), BF16)
         ops.layernorm_fwd(xc, self.p[b + "ln_2.weight"], self.p[b + "ln_2.bias"], ln2, None, None, eps)
@@ -324,13 +336,17 @@ class ClipVitEngine(EvaEngine):
             xf = x.view(B * N, cfg.width)
             last = cfg.layers - 1 if self.cls_only_last_block else cfg.layers
             xb = st = None
-            lo = ops.empty((B * N, cfg.width), torch.int16) if fold_blocks and self.split_stream and last > 1 else None
+            cls_folded = fold_blocks and self.fold_cls_block and last < cfg.layers and last > 0      # the CLS-only block takes the planes + statistics as they are
+            lo = ops.empty((B * N, cfg.width), torch.int16) if fold_blocks and self.split_stream and (last > 1 or cls_folded) else None
             for i in range(last):
                 if fold_blocks:
-                    xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last, lo=lo)
+                    xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last or cls_folded, lo=lo)
                 else:
                     self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
-            xc = self._block_fwd_cls(last, xf, B, N, cos, sin) if last < cfg.layers else x[:, 0, :]
+            if last < cfg.layers:
+                xc = self._block_fwd_cls(last, xf, B, N, cos, sin, xb if cls_folded else None, st, lo)
+            else:
+                xc = x[:, 0, :]
             cls = ops.empty((B, cfg.width), BF16)
             ops.layernorm_fwd(xc, self.p[P + "ln_post.weight"], self.p[P + "ln_post.bias"], cls, None, None, cfg.ln_eps)
             self._head(cls, out[k0:k0 + B])

@@ -27,6 +27,8 @@ S = int(argv[3]) if len(argv) > 3 else cfg.image_size
 plain = len(argv) > 4 and argv[4] == "plain"
 if plain:
     teacher.visual.engine.fold_block_ln = teacher.visual.engine.cls_only_last_block = False
+if len(argv) > 4 and argv[4] == "nocls":                     # the CLS-only last block with its own LayerNorm pass over the whole stream (round 3 form)
+    teacher.visual.engine.fold_cls_block = False
 if len(argv) > 4 and argv[4] == "nosplit":                  # the folded schedule with the fp32 stream + bf16 copy instead of the two 16-bit planes
     teacher.visual.engine.split_stream = False
 student.lock_image_tower(unlocked_groups=cfg.layers)
