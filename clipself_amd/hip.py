@@ -133,7 +133,7 @@ class HipOps:
 
     def reserve_compute_units(self, n: int):
         """Persistent GEMM grids use 256 - n compute units from now on (0 = all)."""
-        assert 0 <= n < 256
+        assert 0 <= n < 224, "cs_persistent_cap() keeps at least 32 workgroups: a reserve of 224 or more would be ignored"
         self.gemm_flags = (self.gemm_flags & ~(255 << 20)) | (int(n) << 20)
 
     # -- helpers ---------------------------------------------------------------------------------
