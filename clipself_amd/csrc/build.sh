@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -munsafe-fp-atomics $CS_EXTRA_FLAGS"
 OBJS=""
-for f in gemm gemm_stream attention norm elementwise roialign_loss adamw preprocess; do
+for f in gemm gemm_stream attention norm elementwise roialign_loss adamw preprocess runtime; do
   if [ ! -f "_obj_$f.o" ] || [ "$f.hip" -nt "_obj_$f.o" ] || [ cs_common.h -nt "_obj_$f.o" ] || [ gemm_common.h -nt "_obj_$f.o" ]; then
     $HIPCC $FLAGS -c "$f.hip" -o "_obj_$f.o" &
   fi

@@ -616,7 +616,9 @@ int launch_persist(GemmArgs a, hipStream_t stream) {
     const long cap = cs_persistent_cap(a.reserve);       // flags bits 20-27: compute units left free
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
     if constexpr (EPI == EPI_BF16 || EPI == EPI_SWIGLU_BF16) {           // the wide-N GEMMs of the towers (q|k|v, W1|W2)
-        const bool parts_ok = (long)grid == cs_persistent_cap(0) && a.tiles_n >= a.nsplit && a.tiles_m >= 8 / a.nsplit;
+        // the B-stationary raster gives every XCD gridDim / 8 workgroups: any full persistent grid that is a multiple of 8 will do -- also
+        // the reduced grid of a launch that leaves compute units to RCCL or to the other tower (a.reserve)
+        const bool parts_ok = (long)grid == cap && grid % 8 == 0 && a.tiles_n >= a.nsplit && a.tiles_m >= 8 / a.nsplit;
         if (a.rm == 1 && parts_ok) return launch_persist_rm<EPI, 1>(a, grid, stream);
         if (a.rm == 2 && parts_ok) return launch_persist_rm<EPI, 2>(a, grid, stream);
         if (a.rm == 3) return launch_persist_rm<EPI, 3>(a, grid, stream);

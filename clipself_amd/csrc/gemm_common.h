@@ -66,10 +66,12 @@ inline int cs_num_cus() {
     }();
     return n;
 }
-// persistent grid: one workgroup per compute unit, minus the ones the caller keeps free (cs_gemm_nt flags bits 20-27)
+// persistent grid: one workgroup per compute unit, minus the ones the caller keeps free (cs_gemm_nt flags bits 20-27: for RCCL's kernels in
+// data-parallel runs, and for the OTHER tower's kernels when the frozen teacher's pass and the student's step share the chip -- the student's
+// GEMMs then keep as few as 8 workgroups).  A reserve that would leave fewer than 8 is ignored.
 inline long cs_persistent_cap(int reserve) {
     const int n = cs_num_cus();
-    return n - (reserve > 0 && reserve < n - 32 ? reserve : 0);
+    return n - (reserve > 0 && reserve <= n - 8 ? reserve : 0);
 }
 
 // gemm_stream.hip: streaming persistent kernel with register-level epilogues.  Returns 1 when the problem is outside what it covers

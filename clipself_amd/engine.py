@@ -704,6 +704,18 @@ class EvaEngine:
                                 "LayerNorm kernels (the folded form would lose precision on these weights)", self.block_fold_ratio, self.block_fold_limit)
         return self.block_fold_ratio <= self.block_fold_limit
 
+    def _rccl_window_step(self, i, k0):
+        """rccl_window = (leading blocks, CUs): the persistent GEMMs of the first chunk's leading blocks leave those CUs to RCCL's kernels
+        (a prefetched pass runs them beside the student's gradient buckets); shared by every engine's encode_image()."""
+        win, cus = self.rccl_window
+        if win and k0 == 0 and i in (0, win) and hasattr(self.ops, "reserve_compute_units"):
+            self.ops.reserve_compute_units(cus if i < win else 0)
+
+    def _rccl_window_close(self, k0):
+        """... and whatever happens inside the window (an exception included), the reservation does not outlive the pass."""
+        if self.rccl_window[0] and k0 == 0 and hasattr(self.ops, "reserve_compute_units"):
+            self.ops.reserve_compute_units(0)
+
     def encode_image(self, images, chunk: int = 256):
         """Frozen-teacher path: full ViT, final LN on the CLS row, head.  [K,3,S,S] -> fp32 [K,E].
         Activation-free: crops are streamed in chunks, blocks update the residual stream in place."""
@@ -723,16 +735,15 @@ class EvaEngine:
             folded = self.fold_sub_ln and fold_blocks
             lo = ops.empty((B * N, cfg.width), torch.int16) if folded and self.split_stream and last > 0 else None
             cls_folded = folded and last < cfg.layers and last > 0          # the CLS-only block takes the planes + statistics as they are
-            win, cus = self.rccl_window if hasattr(ops, "reserve_compute_units") else (0, 0)
-            for i in range(last):
-                if win and k0 == 0 and i in (0, win):
-                    ops.reserve_compute_units(cus if i < win else 0)
-                if folded:
-                    xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last or cls_folded, lo=lo)
-                else:
-                    self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
-            if win and k0 == 0:
-                ops.reserve_compute_units(0)
+            try:
+                for i in range(last):
+                    self._rccl_window_step(i, k0)
+                    if folded:
+                        xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last or cls_folded, lo=lo)
+                    else:
+                        self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
+            finally:
+                self._rccl_window_close(k0)
             if last < cfg.layers:
                 xc = self._block_fwd_cls(last, xf, B, N, cos, sin, xb if cls_folded else None, st, lo)
             else:

@@ -338,11 +338,15 @@ class ClipVitEngine(EvaEngine):
             xb = st = None
             cls_folded = fold_blocks and self.fold_cls_block and last < cfg.layers and last > 0      # the CLS-only block takes the planes + statistics as they are
             lo = ops.empty((B * N, cfg.width), torch.int16) if fold_blocks and self.split_stream and (last > 1 or cls_folded) else None
-            for i in range(last):
-                if fold_blocks:
-                    xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last or cls_folded, lo=lo)
-                else:
-                    self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
+            try:
+                for i in range(last):
+                    self._rccl_window_step(i, k0)                # EvaEngine: leading blocks of a prefetched pass leave CUs to RCCL
+                    if fold_blocks:
+                        xb, st = self._teacher_block_folded(i, xf, xb, st, B, N, cos, sin, emit_next=i + 1 < last or cls_folded, lo=lo)
+                    else:
+                        self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
+            finally:
+                self._rccl_window_close(k0)
             if last < cfg.layers:
                 xc = self._block_fwd_cls(last, xf, B, N, cos, sin, xb if cls_folded else None, st, lo)
             else:

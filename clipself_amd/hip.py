@@ -70,6 +70,9 @@ SIGNATURES = {
     "cs_cosine_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp]),
     "cs_fed_bce_fwd": (_i, [_vp, _l, _vp, _vp, _vp, _i, _i, _f, _f, _vp]),
     "cs_fed_bce_bwd": (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _f, _f, _vp, _vp]),
+    "cs_num_compute_units": (_i, []),
+    "cs_stream_create_cu_mask": (_i, [_i, _i, ctypes.POINTER(_vp)]),
+    "cs_stream_destroy": (_i, [_vp]),
     "cs_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp]),
 }
 
@@ -127,14 +130,56 @@ class HipOps:
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise RuntimeError("HipOps needs a ROCm device (torch.cuda.is_available() is False); no CPU fallback exists")
-        # OR-ed into the flags of every GEMM call: bits 20-27 = compute units the persistent GEMM kernels leave free
-        # (training/distributed.py reserves a few for RCCL's reduction kernels in data-parallel runs)
+        # OR-ed into the flags of every GEMM call: bits 20-27 = compute units the persistent GEMM kernels leave free.  Two callers
+        # withhold CUs: training/distributed.py (a few for RCCL's reduction kernels while gradient buckets are in flight) and the
+        # single-GPU tower partition of training/clipself.py (the frozen teacher's prefetched pass leaves `share` CUs to the student,
+        # whose own persistent GEMMs are capped at `cap` workgroups meanwhile).
         self.gemm_flags = 0
+        self._rccl_reserve = 0          # reserve_compute_units()
+        self._share = 0                 # share_compute_units(): CUs given to the other tower, added to the RCCL reserve
+        self._cap = 0                   # cap_compute_units(): upper bound of a persistent grid (0 = none)
+        self.num_cus = int(self.lib.cs_num_compute_units())
+
+    def _update_flags(self):
+        n = self._rccl_reserve + self._share
+        if self._cap:
+            n = max(n, self.num_cus - self._cap)
+        assert 0 <= n <= self.num_cus - 8 and n < 256, f"persistent GEMM grids keep at least 8 workgroups (asked to leave {n} of {self.num_cus} CUs free)"
+        self.gemm_flags = (self.gemm_flags & ~(255 << 20)) | (int(n) << 20)
 
     def reserve_compute_units(self, n: int):
-        """Persistent GEMM grids use 256 - n compute units from now on (0 = all)."""
-        assert 0 <= n < 224, "cs_persistent_cap() keeps at least 32 workgroups: a reserve of 224 or more would be ignored"
-        self.gemm_flags = (self.gemm_flags & ~(255 << 20)) | (int(n) << 20)
+        """Persistent GEMM grids leave n compute units free from now on (0 = none): room for RCCL's kernels in data-parallel runs."""
+        self._rccl_reserve = int(n)
+        self._update_flags()
+
+    def share_compute_units(self, n: int):
+        """... and n more for the other tower of the step (the frozen teacher's side of the single-GPU partition)."""
+        self._share = int(n)
+        self._update_flags()
+
+    def cap_compute_units(self, n: int):
+        """Persistent GEMM grids use at most n workgroups (0 = no cap): the student's side of the partition."""
+        self._cap = int(n)
+        self._update_flags()
+
+    def persistent_grid(self) -> int:
+        """Workgroups a persistent GEMM launches under the current reservation (diagnostics, tests)."""
+        return self.num_cus - ((self.gemm_flags >> 20) & 255)
+
+    def num_compute_units(self) -> int:
+        return self.num_cus
+
+    def stream_create_cu_mask(self, first_cu: int, n_cus: int):
+        """torch stream whose kernels run on compute units [first_cu, first_cu + n_cus) only (cs_stream_create_cu_mask)."""
+        h = ctypes.c_void_p()
+        self._ok(self.lib.cs_stream_create_cu_mask(int(first_cu), int(n_cus), ctypes.byref(h)), "cs_stream_create_cu_mask")
+        s = torch.cuda.ExternalStream(h.value)
+        s._cs_handle = h.value
+        return s
+
+    def stream_destroy(self, stream):
+        torch.cuda.synchronize()
+        self._ok(self.lib.cs_stream_destroy(ctypes.c_void_p(stream._cs_handle)), "cs_stream_destroy")
 
     # -- helpers ---------------------------------------------------------------------------------
     def _stream(self):

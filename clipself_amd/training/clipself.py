@@ -52,6 +52,10 @@ def _known_all_valid(normed_boxes):
     return getattr(normed_boxes, "_cs_all_valid", None)
 
 
+# compute units the prefetched teacher pass leaves to the student's step on one GPU (0 = shared pool); profiles/r05_a_partition_sweep.md
+DEFAULT_PARTITION_CUS = "0"
+
+
 class CLIPSelf:
     """Besides the reference's call contract, the method can run the frozen teacher one batch ahead: `prefetch_teacher(next_batch,
     ...)` launches the teacher forward of the NEXT batch on a high-priority side stream, where it overlaps the student's backward,
@@ -59,9 +63,34 @@ class CLIPSelf:
     features do not depend on the student's update).  `__call__` picks the prefetched features up when it is handed that batch and
     otherwise computes them inline, exactly like the reference."""
 
-    def __init__(self):
+    def __init__(self, partition_cus=None, partition_mask=None, partition_cap=None):
         self._pending = None           # (image_crops tensor of the prefetched batch, features, side stream)
         self._side = None
+        # Static CU partition between the towers while a prefetched teacher pass is in flight: the teacher's persistent GEMMs leave
+        # `partition_cus` compute units free and the student's are capped at that many workgroups, so the student's kernels stop queueing
+        # behind 256-workgroup teacher launches (and the teacher's behind the student's).  0 = one shared pool, as before.
+        # CLIPSELF_PARTITION_CUS / CLIPSELF_PARTITION_MASK=1 (queues with hardware CU masks: cs_stream_create_cu_mask).
+        self.partition_cus = int(os.environ.get("CLIPSELF_PARTITION_CUS", DEFAULT_PARTITION_CUS)) if partition_cus is None else int(partition_cus)
+        self.partition_mask = (os.environ.get("CLIPSELF_PARTITION_MASK", "0") == "1") if partition_mask is None else bool(partition_mask)
+        # workgroups of the student's persistent GEMMs meanwhile (default: its share; CLIPSELF_PARTITION_CAP)
+        cap = os.environ.get("CLIPSELF_PARTITION_CAP") if partition_cap is None else partition_cap
+        self.partition_cap = int(cap) if cap not in (None, "") else self.partition_cus
+        self._student_ops = None
+        self._student_stream = None
+
+    def _cap_student(self, on: bool):
+        ops = self._student_ops
+        if ops is not None and hasattr(ops, "cap_compute_units"):
+            ops.cap_compute_units(self.partition_cap if on else 0)
+
+    def student_stream(self, ops):
+        """With partition_mask: the queue the student's step should run on (CU mask = the student's share); None otherwise."""
+        if not (self.partition_mask and self.partition_cus):
+            return None
+        if self._student_stream is None:
+            n = ops.num_compute_units()
+            self._student_stream = ops.stream_create_cu_mask(n - self.partition_cus, self.partition_cus)
+        return self._student_stream
 
     @staticmethod
     def _valid_crops(normed_boxes, image_crops, all_valid=None):
@@ -88,24 +117,34 @@ class CLIPSelf:
         crops_d = image_crops.to(device=device, dtype=cast_dtype, non_blocking=True)
         _, _, crops = self._valid_crops(boxes_d, crops_d, _known_all_valid(normed_boxes))
         main = torch.cuda.current_stream(device)
+        eng = getattr(getattr(dist_model, "visual", None), "engine", None)
+        tops = getattr(eng, "ops", None)
+        share = self.partition_cus if hasattr(tops, "share_compute_units") else 0
         if self._side is None:
-            # single GPU: the teacher is the long pole, let it win CUs.  Data parallel: normal priority, so that RCCL's kernels
-            # (launched at default priority) are not starved behind 3 ms persistent GEMMs
-            prio = os.environ.get("CLIPSELF_TEACHER_STREAM_PRIORITY")
-            self._side = torch.cuda.Stream(device=device, priority=int(prio) if prio is not None else (0 if distributed else -1))
+            if share and self.partition_mask:
+                self._side = tops.stream_create_cu_mask(0, tops.num_compute_units() - share)      # the teacher's CUs, enforced by the dispatcher
+            else:
+                # single GPU: the teacher is the long pole, let it win CUs.  Data parallel: normal priority, so that RCCL's kernels
+                # (launched at default priority) are not starved behind 3 ms persistent GEMMs
+                prio = os.environ.get("CLIPSELF_TEACHER_STREAM_PRIORITY")
+                self._side = torch.cuda.Stream(device=device, priority=int(prio) if prio is not None else (0 if distributed else -1))
         side = self._side
         side.wait_stream(main)
-        eng = getattr(getattr(dist_model, "visual", None), "engine", None)
         with torch.cuda.stream(side), torch.no_grad():
             if eng is not None:
                 eng.rccl_window = window
+            if share:
+                tops.share_compute_units(share)        # every persistent GEMM of this pass: grid = CUs - share (- RCCL's inside the window)
             try:
                 feats = dist_model.encode_image(crops, normalize=False)
             finally:
                 if eng is not None:
                     eng.rccl_window = (0, 0)
+                if share:
+                    tops.share_compute_units(0)
         crops.record_stream(side)
         self._pending = (image_crops, feats, side)
+        self._cap_student(bool(share))                 # what the student queues from here on runs beside this pass
 
     def _teacher_features(self, image_crops, crops, dist_model):
         pend, self._pending = self._pending, None
@@ -114,7 +153,9 @@ class CLIPSelf:
             main = torch.cuda.current_stream(feats.device)
             main.wait_stream(side)
             feats.record_stream(main)
+            self._cap_student(False)                   # that pass is over once the stream gets here; the next prefetch caps again
             return feats
+        self._cap_student(False)
         with torch.no_grad():
             return dist_model.encode_image(crops, normalize=False)
 
@@ -123,6 +164,8 @@ class CLIPSelf:
             model = model.module
             dist_model = dist_model.module
         images, normed_boxes, image_crops_in = batch    # note texts are not paired with images
+        self._student_ops = getattr(getattr(getattr(model, "visual", None), "engine", None), "ops", None)
+        self._cap_student(self._pending is not None and self.partition_cus > 0)      # a prefetched teacher pass is running beside this forward
 
         images = images.to(device=device, dtype=cast_dtype, non_blocking=True)
         normed_boxes = normed_boxes.to(device=device, dtype=torch.float32, non_blocking=True)

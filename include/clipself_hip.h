@@ -217,6 +217,16 @@ int cs_crop_resize_u8(const void* src, int H, int W, const float* boxes, int K, 
  * in [planes,H,W] f32 -> out [planes,Ho,Wo] f32, align_corners=False arithmetic of torch. */
 int cs_resize_bilinear_f32(const float* in, float* out, int planes, int H, int W, int Ho, int Wo, cs_stream_t stream);
 
+/* --- sharing one GPU between the two towers of a step.  src/training/clipself.py:36-40 runs the frozen teacher (`dist_model.encode_image`
+ * under no_grad) and the student one after the other on one CUDA stream; here the teacher's pass over the NEXT batch runs beside the
+ * student's step (src/training/train.py:90-115), each on its own share of the compute units: persistent GEMM grids sized by cs_gemm_nt's
+ * flags bits 20-27 and, optionally, queues restricted by a CU mask.  cs_num_compute_units: CUs of the current device (256 on MI355X).
+ * cs_stream_create_cu_mask: a stream whose kernels only run on mask bits [first_cu, first_cu + n_cus) (multiples of 8: the driver deals
+ * bit i to XCD i % 8, so such a range takes n_cus / 8 CUs from every XCD); destroy it with cs_stream_destroy. */
+int cs_num_compute_units(void);
+int cs_stream_create_cu_mask(int first_cu, int n_cus, cs_stream_t* out);
+int cs_stream_destroy(cs_stream_t stream);
+
 /* --- optimizer: torch.optim.AdamW built at src/training/main.py:198-213, stepped at src/training/train.py:115.
  * Flat fp32 master/grad/moment buffers; flags[n/64]: bit0 = tensor has a gradient this step, bit1 = weight decay applies. */
 int cs_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, const uint8_t* flags, long n, float lr,

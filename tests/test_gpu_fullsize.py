@@ -102,6 +102,51 @@ def test_cfg1_full_size_step_inline_and_prefetch_schedules_agree():
         assert r < 1.5e-2 and c < 2e-4
 
 
+@pytest.mark.parametrize("share,mask", [(32, False), (48, True)])
+def test_cfg1_full_size_step_with_cu_partition_equals_the_shared_pool(share, mask):
+    """The single-GPU tower partition (CLIPSelf(partition_cus=R): the prefetched teacher pass launches its persistent GEMMs on 256 - R
+    workgroups and the student's are capped at R, optionally on queues with hardware CU masks) changes WHERE tiles run, not what they hold:
+    loss and every gradient bit equal the shared-pool schedule, and the grids really were the partition's."""
+    from clipself_amd.training.clipself import CLIPSelf
+    from clipself_amd.training.optim import FlatAdamW
+    from clipself_amd.training.train import train_step
+    cfg = get_tower_cfg("EVA02-CLIP-B-16")
+    batch = tuple(t.cuda() for t in synthetic_batch(64, 32, 224, 224, seed=1234))
+    nxt = tuple(t.cuda() for t in synthetic_batch(64, 32, 224, 224, seed=2211))
+
+    def run(share, mask):
+        student, teacher = _pair(cfg, 0)
+        sops, tops = student.visual.engine.ops, teacher.visual.engine.ops
+        seen = {"teacher": set(), "student": set()}
+        for who, ops in (("teacher", tops), ("student", sops)):
+            inner = ops.gemm_nt_ln_split if who == "teacher" else ops.gemm_nt
+            def spy(*a, _inner=inner, _ops=ops, _who=who, **k):
+                seen[_who].add(_ops.persistent_grid())
+                return _inner(*a, **k)
+            setattr(ops, "gemm_nt_ln_split" if who == "teacher" else "gemm_nt", spy)
+        method = CLIPSelf(partition_cus=share, partition_mask=mask)
+        a = _args(skip_scheduler=True)
+        a.teacher_prefetch = True
+        sstream = method.student_stream(sops)
+        torch.cuda.synchronize()
+        with (torch.cuda.stream(sstream) if sstream is not None else torch.cuda.stream(torch.cuda.current_stream())):
+            train_step(student, method, nxt, FlatAdamW(student, lr=0.0, weight_decay=0.0), None, 0, teacher, a, next_batch=batch)
+            assert method._pending is not None
+            seen["student"].clear()                   # from here on the student runs beside the prefetched pass over `batch`
+            out, _, _ = train_step(student, method, batch, FlatAdamW(student, lr=1e-5, weight_decay=0.1), None, 0, teacher, a, next_batch=nxt)
+        torch.cuda.synchronize()
+        return float(out["loss"].detach()), student.visual.engine.grad.clone(), seen, sops.num_compute_units()
+
+    loss0, grad0, seen0, n = run(0, False)
+    loss1, grad1, seen1, _ = run(share, mask)
+    assert seen0 == {"teacher": {n}, "student": {n}}
+    # (the very first teacher pass, over `nxt`, has nothing to run beside and is inline on the whole chip)
+    assert seen1["teacher"] == {n, n - share} and seen1["student"] == {share}, seen1
+    diff = int((grad0 != grad1).sum())
+    _log(f"cfg1 full size step, CU partition {share} (masks {mask}) vs shared pool: loss {loss1:.7f} vs {loss0:.7f}, {diff} gradient elements differ")
+    assert loss0 == loss1 and diff == 0
+
+
 def _regionclip_batch(cfg, B, n_nouns=4764, max_boxes=20, seed=77):
     g = np.random.Generator(np.random.PCG64(seed))
     images, nb, _ = synthetic_batch(B, max_boxes, cfg.image_size, 32, seed=seed)

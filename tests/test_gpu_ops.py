@@ -839,7 +839,8 @@ def test_layernorm_fwd_f32_out(hip, ref, C):
 
 
 # ------------------------------------------------------------------------------------------------ persistent-kernel raster / cache-policy modes
-@pytest.mark.parametrize("mode", [0x10090, 0x10190, 0x10290, 0x10490, 0x10890, 0x20090, 0x20290, 0x30090, 0xB0, 0x10B0, 0xB0 | (24 << 20)])      # last: streaming kernel with 24 CUs left free
+@pytest.mark.parametrize("mode", [0x10090, 0x10190, 0x10290, 0x10490, 0x10890, 0x20090, 0x20290, 0x30090, 0xB0, 0x10B0, 0xB0 | (24 << 20), 0x10090 | (16 << 20),
+                                  0x10290 | (232 << 20), 0xB0 | (232 << 20)])      # bits 20-27: 24 / 16 / 232 CUs left free (streaming kernel, B-stationary raster)
 @pytest.mark.parametrize("M,N,K,epi", [(65536 + 300, 2304, 128, 0), (70000, 4096, 64, 3), (66000, 768, 192, 0), (300, 512, 64, 0)])
 def test_gemm_persistent_raster_modes_cover_every_tile(hip, ref, M, N, K, epi, mode):
     """flags bits 16-17: B-stationary raster (N parts in bits 8-11; 0 = automatic), with non-temporal A loads, and non-temporal B loads on the
