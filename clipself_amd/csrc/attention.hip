@@ -764,14 +764,15 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const __bf16* __restrict_
         float mx = -INFINITY;
         for (int key = lane; key < Ntok; key += 64) mx = fmaxf(mx, row[key]);
         mx = wave_max(mx);
-        float sum = 0.f;
+        if (mx == -INFINITY) mx = 0.f;             // a query row that allows no key at all (the reference always allows key 0): p = 0 everywhere,
+        float sum = 0.f;                           // output row = 0 instead of exp2(-inf + inf) = NaN
         for (int key = lane; key < Ntok; key += 64) {
             const float e = __builtin_amdgcn_exp2f(row[key] - mx);
             sum += e;
             row[key] = bf2f(f2bf(e));
         }
         sum = wave_sum(sum);
-        if (lane == 0) rsum[h] = sum;
+        if (lane == 0) rsum[h] = sum > 0.f ? sum : 1.f;
     }
     __syncthreads();
     float acc[HG][8];

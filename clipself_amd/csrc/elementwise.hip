@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
 // out[n] += sum over the row blocks' partials in a fixed order (no atomics: the bias gradients are bit-reproducible):
 // (s0 + s1) + (s2 + s3) with s_r = the partials of blocks r, r + 4, r + 8, ... added in ascending order.  64 columns x the 4 residues per
 // workgroup, eight loads in flight per thread (round 4; the one-thread-per-column form walked ~200 dependent L2 round trips: 16.6 us for
-// 3 MB of partials, now the same bits in a few microseconds).
+// 3 MB of partials, now a few microseconds).  Deterministic, but NOT bit-identical to that older kernel when nblocks % 4 != 0: it added the
+// leftover blocks to s0, here every block goes to its residue's sum.
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int nblocks, int N, float* __restrict__ out) {
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, r = threadIdx.x >> 6;

@@ -969,6 +969,9 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
             for (int j = 0; j < FN; ++j) tr_read(b[set][j], tb, 16 * ts + trow, (wn * TN + j * 32) * 2 + segbyte);
         };
         // every asm read issued so far has landed; the fragment registers of `set` are operands of the wait, so their consumers stay below it
+        // (the operand list names a[set][0..3] and b[set][0..1]; the asm reads carry no memory clobber -- their order against the LDS-DMA
+        // writes of the ring is kept by the K tile's barrier and the hand-counted vmcnt in front of it, not by the compiler)
+        static_assert(FM == 4 && FN == 2, "tr_wait names exactly FM = 4 and FN = 2 fragment pairs: extend its operand list with the tile");
         auto tr_wait = [&](int set) {
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(a[set][0].lo), "+v"(a[set][0].hi), "+v"(a[set][1].lo), "+v"(a[set][1].hi), "+v"(a[set][2].lo), "+v"(a[set][2].hi),

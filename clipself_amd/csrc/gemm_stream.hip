@@ -996,7 +996,24 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(GemmArgs p) {
                                : (BM == 192 && wave == 3) ? b_ring + 2 * B_BYTES
                                                           : smem + (curA == 0 ? 2 : curA - 1) * A_BYTES + wave * 8192;
             load_epi_ops(lane_e);
-            if constexpr (RES) {
+#ifndef CS_NO_KERNARG_RELOAD
+            constexpr bool RELOAD = RES && LN && AUX;
+#else
+            constexpr bool RELOAD = false;         // A/B switch (tools/build_variant.sh): the round-4 form with its SGPR spills
+#endif
+            if constexpr (RELOAD) {
+                // The folded-LayerNorm residual epilogue with statistics uses eleven pointers of GemmArgs (seven buffer descriptors): held in
+                // SGPRs across the K loop they were spilled to VGPR lanes (8-32 SGPRs, and 3 VGPRs to scratch in the fp32-stream form).  The
+                // epilogue reads the arguments from the kernarg segment again instead -- scalar loads that hit the constant cache --
+                // through a pointer the compiler cannot see through, so nothing of it is live in the loop.
+                const __attribute__((address_space(4))) GemmArgs* pk = (const __attribute__((address_space(4))) GemmArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(pk));
+                GemmArgs pe;                                     // field by field: scalar (s_load) reads of what the epilogue uses, the rest is dead
+                pe.A = pk->A; pe.C = pk->C; pe.bias = pk->bias; pe.extra = pk->extra; pe.M = pk->M; pe.N = pk->N; pe.ldc = pk->ldc;
+                pe.ln_colsum = pk->ln_colsum; pe.stats_part = pk->stats_part; pe.xb_out = pk->xb_out; pe.ldxb = pk->ldxb; pe.lo = pk->lo;
+                pe.dbg = pk->dbg;
+                epi_resid_slab<LN, AUX, CP, F8, SPLIT, FM>(pe, acc, lane_e, row0, colw, tn, wn, eo, slab);
+            } else if constexpr (RES) {
                 epi_resid_slab<LN, AUX, CP, F8, SPLIT, FM>(p, acc, lane_e, row0, colw, tn, wn, eo, slab);
             } else {
                 static_assert(FM == 4, "the slab forms of the bf16 / SwiGLU epilogues exist for 256-row tiles");

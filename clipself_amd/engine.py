@@ -669,12 +669,22 @@ class EvaEngine:
         return self._block_post(i, b, xc, att, B, lambda: (None, None), None, True)
 
     # ------------------------------------------------------------------------------------------ teacher
-    def block_fold_statistic(self, images, crops: int = 16):
-        """max over blocks of mean over rows of |row mean| / row sigma of the residual stream entering the block, on the first `crops`
-        images through the plain block schedule.  One-time calibration after a weight load (a few torch reductions and one host read-back,
-        not part of the step)."""
+    def fold_probe(self, crops: int = 16):
+        """The crops the guard is calibrated on: seeded N(0, 1) images at the tower's native size (numpy PCG64, version-stable) -- the same
+        on every rank, in every run and whatever the first batch holds, so that all ranks of a data-parallel job choose the same teacher
+        schedule and two runs of one checkpoint produce the same distillation targets.  (The statistic is a property of the weights --
+        massive-activation channels, bias-driven row means -- far more than of the pixels; oracle/stress_weights.py builds it from them.)"""
+        import numpy as np
+        S = self.cfg.image_size
+        g = np.random.Generator(np.random.PCG64(20250927))
+        return torch.from_numpy(g.standard_normal((crops, 3, S, S), dtype=np.float32)).to(self.device)
+
+    def block_fold_statistic(self, images=None, crops: int = 16):
+        """max over blocks of mean over rows of |row mean| / row sigma of the residual stream entering the block, on `images[:crops]`
+        (default: fold_probe()) through the plain block schedule.  One-time calibration after a weight load (a few torch reductions and
+        one host read-back, not part of the step)."""
         with torch.no_grad():
-            img = images[:crops]
+            img = self.fold_probe(crops) if images is None else images[:crops]
             B = img.shape[0]
             x, g = self._stem(img)
             N = g * g + 1
@@ -689,7 +699,10 @@ class EvaEngine:
 
     def block_folds_active(self, images=None) -> bool:
         """Whether encode_image() folds norm1 / norm2 into the q|k|v and W1|W2 GEMMs: the switch, and -- with the guard armed -- the
-        calibration of the current weights (measured on `images` when it has not been yet)."""
+        calibration of the current weights, measured on the fixed probe the first time a caller with data in hand asks (`images` only says
+        that the tower is about to run; its content does not enter the decision).  In a process group every rank takes the MAX over ranks
+        (one scalar all-reduce per weight load), so the ranks cannot disagree even if their devices rounded differently.  The statistic and
+        the decision are logged once per weight load."""
         if not self.fold_block_ln:
             return False
         if not self.block_fold_guard:
@@ -697,11 +710,24 @@ class EvaEngine:
         if self.block_fold_ratio is None:
             if images is None:
                 return True
-            self.block_fold_ratio = self.block_fold_statistic(images)
-            if self.block_fold_ratio > self.block_fold_limit:
-                import logging
-                logging.warning("frozen tower: mean |row mean| / row sigma of the residual stream = %.2f > %.1f -- norm1 / norm2 stay "
-                                "LayerNorm kernels (the folded form would lose precision on these weights)", self.block_fold_ratio, self.block_fold_limit)
+            import logging
+            ratio = self.block_fold_statistic()
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    t = torch.tensor([ratio], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    ratio = float(t[0])
+            except (RuntimeError, ValueError):                      # no usable process group: the local value stands
+                pass
+            self.block_fold_ratio = ratio
+            folded = ratio <= self.block_fold_limit
+            near = abs(ratio - self.block_fold_limit) <= 0.1 * self.block_fold_limit
+            logging.log(logging.WARNING if (near or not folded) else logging.INFO,
+                        "frozen tower: mean |row mean| / row sigma of the residual stream = %.3f on the seeded probe (limit %.1f%s) -- norm1 / norm2 %s",
+                        ratio, self.block_fold_limit, ", within 10 % of it" if near else "",
+                        "folded into the q|k|v and W1|W2 GEMMs" if folded else
+                        "stay LayerNorm kernels (the folded form would lose precision on these weights)")
         return self.block_fold_ratio <= self.block_fold_limit
 
     def _rccl_window_step(self, i, k0):

@@ -368,9 +368,11 @@ class ClipVitEngine(EvaEngine):
         ops, cfg, P = self.ops, self.cfg, self.prefix
         C, Hd, H, eps, E = cfg.width, cfg.hidden, cfg.heads, cfg.ln_eps, cfg.embed_dim
         counts = [int(m.shape[0]) for m in masks]
-        assert len(masks) == images.shape[0] and min(counts) > 0, "one non-empty mask list per image"
-        Q = max(counts)
-        outs = []
+        assert len(masks) == images.shape[0], "one mask list per image"
+        Q = max(counts) if counts else 0
+        if Q == 0:                                   # no image has a mask: transformer.py:823-824 returns zero rows
+            return torch.zeros((0, E), dtype=F32, device=self.device)
+        outs = []                                    # an image WITHOUT masks is all padding: see-everything queries whose rows are dropped (:793-795)
         act = EPI_QGELU_BF16 if cfg.quick_gelu else EPI_GELU_BF16
         for k0 in range(0, images.shape[0], chunk):
             img = images[k0:k0 + chunk]

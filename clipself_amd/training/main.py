@@ -101,9 +101,10 @@ def main(argv):
     elif args.train_data:
         # Without --lock-image the reference trains the whole visual tower -- stem, positional embedding, final norm and head besides the
         # blocks -- through the dense path (main.py:161-166; eva_vit_model.py:537-544,615-623).  A freshly built EVA02 tower is in that
-        # state (EvaEngine.set_trainable_all); the OpenAI-CLIP ViT family differentiates its transformer blocks only.
+        # state (EvaEngine.set_trainable_all), and so is an OpenAI-CLIP ViT (ClipVitEngine: stem, positional embedding, ln_post and proj
+        # train as well; UNLOCKED_TRAINS_ALL on both tower classes).  A tower class without that flag raises.
         if not getattr(model.visual, "UNLOCKED_TRAINS_ALL", False):
-            raise NotImplementedError("training without --lock-image is supported for the EVA02 towers; pass --lock-image "
+            raise NotImplementedError("training without --lock-image is supported for the EVA02 and OpenAI-CLIP ViT towers; pass --lock-image "
                                       "--lock-image-unlocked-groups N for this model family")
         model.visual.unlock()
     if is_master(args):

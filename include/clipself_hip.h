@@ -142,7 +142,8 @@ int cs_attn_cls_fwd(const void* q, const void* kv, const float* cos_t, const flo
  * (src/open_clip/transformer.py:736-834), reached through extract_type='v1' (:660-671) and CLIP.encode_masks(mask_attn=True)
  * (src/open_clip/model.py:245-247).  Q query rows per image attend the image's own keys / values of the same depth: key j of query row r
  * is allowed iff allow[r * Ntok + j] != 0 (the reference's bool attn_mask, inverted; key 0 = the CLS token).  q [B*Q, ldq] bf16;
- * kv [B*Ntok, ldkv] bf16 = k|v; out [B*Q, ldo] bf16.  No rotary embedding in this family.  Inference only (no backward). */
+ * kv [B*Ntok, ldkv] bf16 = k|v; out [B*Q, ldo] bf16.  No rotary embedding in this family.  Inference only (no backward).  A row that allows
+ * no key at all (the reference always allows key 0) yields a zero output row, not NaN. */
 int cs_attn_query_fwd(const void* q, const void* kv, const unsigned char* allow, void* out, int B, int Q, int Ntok, int H,
                       int ldq, int ldkv, int ldo, float scale, cs_stream_t stream);
 /* cs_attn_fwd that also emits stats_part [H][B*Ntok][2] f32 = per head (sum, sum of squares) of each output row's 64 values. */

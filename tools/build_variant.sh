@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../clipself_amd/csrc"
 mkdir -p ab
 units=${VARIANT_UNITS:-gemm_stream}
 objs=""
-for f in gemm gemm_stream attention norm elementwise roialign_loss adamw preprocess; do
+for f in gemm gemm_stream attention norm elementwise roialign_loss adamw preprocess runtime; do
   if [[ " $units " == *" $f "* ]]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -munsafe-fp-atomics $flags -c $f.hip -o ab/_obj_${f}_$name.o &
     objs="$objs ab/_obj_${f}_$name.o"
