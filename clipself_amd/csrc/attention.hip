@@ -195,6 +195,54 @@ __device__ __forceinline__ void stage_vt(const __bf16* __restrict__ src, size_t 
     }
 }
 
+// ---- round 5: row-major images + transposing reads (attention backward, long-sequence forward) -------------------------------------
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+
+// lane-constant part of a transposing fragment read from a row-major [rows][64] image in the k_off layout: the lane's column is
+// d0 + (lane & 31); its 16-lane group addresses rows rr .. rr + 3 (rr = first row of the 4-row block, relative to a 32-row tile).  The
+// tile index only adds t * 4096: (r >> 1) & 15 does not see multiples of 32 rows.
+__device__ __forceinline__ int tr_lane_off(int rr, int d0, int lane) {
+    const int li = lane & 15, g1 = (lane >> 4) & 1;
+    const int col = d0 + 16 * g1 + 4 * (li & 3);
+    return k_off(rr + (li >> 2), col >> 3) + ((col >> 2) & 1) * 8;
+}
+__device__ __forceinline__ bf16x8 tr_join2(s16x4v lo, s16x4v hi) {
+    typedef short s16x8v __attribute__((ext_vector_type(8)));
+    const s16x8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ s16x4v tr_read4(const char* addr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)addr);
+}
+
+// rows tok0 .. tok0 + CHK - 1 of one head's 64 columns into registers (rows past the sequence repeat its last row: finite values that
+// only meet p = 0), and from registers into a row-major LDS image, rotated on the way (ROPE) from the LDS tables
+template <int CHK>
+struct RowRegs {
+    static constexpr int ITEMS = (CHK * 8 + 511) / 512;
+    uint4 v[ITEMS];                 // plain vectors: a union that lives across the chunk loop is kept on the stack
+    __device__ __forceinline__ void load(const __bf16* __restrict__ src, size_t rowbase, int ld, int coloff, int tok0, int Ntok, int tid) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int idx = min(tid + it * 512, CHK * 8 - 1), tok = min(tok0 + (idx >> 3), Ntok - 1);
+            v[it] = *(const uint4*)(src + (rowbase + tok) * ld + coloff + (idx & 7) * 8);
+        }
+    }
+    template <bool ROPE>
+    __device__ __forceinline__ void store(char* tile, const float* rt, int g, float inv_g, int tok0, int Ntok, int tid) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int idx = tid + it * 512, r = idx >> 3, c = idx & 7, tok = tok0 + r;
+            if (idx < CHK * 8) {
+                U128 t;
+                t.u = v[it];
+                if (ROPE && tok > 0 && tok < Ntok) rope8_lds(t, rt, g, inv_g, tok, c);
+                *(uint4*)(tile + k_off(r, c)) = t.u;
+            }
+        }
+    }
+};
+
 // P^T accumulator registers [8*c2, 8*c2+8) of both wave halves -> B fragment in the conventional slot order
 // (half h supplies keys 8h..8h+7 of the 16-key step): pack to bf16 pairs, then exchange half 0's keys 8-11 with
 // half 1's keys 4-7 (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second).
@@ -225,7 +273,9 @@ __device__ __forceinline__ void load_q_frags(const AttnArgs& p, const float* rt,
 // one key chunk against one 32-query tile: S^T = K Q^T, online-softmax update of (m, l), O^T += V^T P^T
 // t0: first key tile of the chunk inside the LDS images (0 when the images hold only this chunk; the V^T key-block swizzle is a function of
 // the absolute block index, so a chunk of a whole-sequence image cannot be addressed through an offset pointer)
-template <int CH, bool TAIL>
+// VROW: Vt points at a ROW-MAJOR [keys][64] image in the k_off layout instead of the transposed one; the V^T fragments are then read with
+// ds_read_b64_tr_b16 (half hf supplies keys 8 hf .. 8 hf + 7 of the 16-key step, the conventional order pack8_swapped produces).
+template <int CH, bool TAIL, bool VROW = false>
 __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, const bf16x8 (&qf)[4], int key0, int Ntok, float sl2,
                                              int lane, bool first, float& m, float& l, f32x16 (&o)[2], int t0 = 0) {
     const int hf = lane >> 5, l31 = lane & 31;
@@ -307,8 +357,14 @@ __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, c
             const int kb = (t0 + t) * 4 + c2 * 2 + hf;       // key block (8 keys) this half supplies
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const int d = dt * 32 + l31;
-                const bf16x8 vfrag = *(const bf16x8*)(Vt + d * VT_LD + ((kb ^ ((d >> 3) & 7)) << 3));
+                bf16x8 vfrag;
+                if constexpr (VROW) {
+                    const char* Vl = (const char*)Vt + (t0 + t) * (16 * 256);
+                    vfrag = tr_join2(tr_read4(Vl + tr_lane_off(c2 * 16 + 8 * hf, dt * 32, lane)), tr_read4(Vl + tr_lane_off(c2 * 16 + 8 * hf + 4, dt * 32, lane)));
+                } else {
+                    const int d = dt * 32 + l31;
+                    vfrag = *(const bf16x8*)(Vt + d * VT_LD + ((kb ^ ((d >> 3) & 7)) << 3));
+                }
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pb, o[dt], 0, 0, 0);
             }
         }
@@ -379,6 +435,53 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnArgs p) {
         stage_vt<CHK, NT>(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0, p.Ntok, Vt, tid);
         __syncthreads();
         if (active) attend_chunk<CH, false>(Kl, Vt, qf, key0, p.Ntok, sl2, lane, key0 == 0, m, l, o);
+    }
+    if (active && q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
+}
+
+// Round 5, sequences longer than one LDS image.  attn_fwd_kernel above stages a chunk (K rotated, V transposed in registers: 8 rows per
+// thread on 224 of the 512 threads) and only then attends it -- two barriers and a full memory round trip per chunk with nothing
+// overlapping them: 234 us per block at the recipe's 4097 tokens (0.18 of the MFMA peak).  Here the NEXT chunk's K and V rows are
+// requested before the current chunk is attended (register prefetch, 4 + 4 x 16 bytes per thread), V stays row-major in LDS and its
+// transposed fragments come from ds_read_b64_tr_b16, and a staged chunk of CH tiles is attended as two online-softmax steps of CH1 and
+// CH - CH1 tiles so that the score registers (16 per tile) leave room for the prefetch.
+template <int CH, int CH1>
+__global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnArgs p) {
+    constexpr int CHK = CH * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kl = smem;
+    char* Vl = smem + CHK * 128;
+    float* rt = (float*)(smem + 2 * CHK * 128);          // compact RoPE tables [4][g][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int C = p.H * HD;
+    const size_t rowbase = (size_t)b * p.Ntok;
+    const float sl2 = p.scale * LOG2E;
+    const int q0 = blockIdx.x * 256 + wave * 32, q = q0 + l31, qc = min(q, p.Ntok - 1);
+    const bool active = q0 < p.Ntok;
+    RowRegs<CHK> kr, vr;
+    kr.load(p.qkv, rowbase, p.ldqkv, C + h * HD, 0, p.Ntok, tid);
+    vr.load(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, 0, p.Ntok, tid);
+    load_rope_tables<512>(rt, p.cos_t, p.sin_t, p.grid, tid);
+    __syncthreads();
+    bf16x8 qf[4];
+    load_q_frags(p, rt, rowbase, qc, h, hf, qf);
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[2] = {zero16(), zero16()};
+    for (int key0 = 0; key0 < p.Ntok; key0 += CHK) {
+        if (key0) __syncthreads();
+        kr.template store<true>(Kl, rt, p.grid, p.inv_grid, key0, p.Ntok, tid);
+        vr.template store<false>(Vl, rt, p.grid, p.inv_grid, key0, p.Ntok, tid);
+        __syncthreads();
+        if (key0 + CHK < p.Ntok) {
+            kr.load(p.qkv, rowbase, p.ldqkv, C + h * HD, key0 + CHK, p.Ntok, tid);
+            vr.load(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0 + CHK, p.Ntok, tid);
+        }
+        if (!active) continue;
+        attend_chunk<CH1, false, true>(Kl, (const __bf16*)Vl, qf, key0, p.Ntok, sl2, lane, key0 == 0, m, l, o, 0);
+        if (key0 + CH1 * 32 < p.Ntok)                     // (wave-uniform) the second step holds at least one real key
+            attend_chunk<CH - CH1, false, true>(Kl, (const __bf16*)Vl, qf, key0 + CH1 * 32, p.Ntok, sl2, lane, false, m, l, o, CH1);
     }
     if (active && q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
 }
@@ -694,6 +797,209 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs p) {
     }
 }
 
+// ---- round 5: the backward kernels re-staged ----------------------------------------------------------------------------------------
+// The round-1 kernels above stage a chunk with a loop of (global load -> RoPE from the global tables -> LDS store): 3.5 serial memory round
+// trips per operand and chunk, 64 bytes of table per 16 bytes of q / k, a second, transposed image written with 2-byte LDS stores, and no
+// overlap with the MFMA phase -- at the reference's recipe shape (4097 tokens) a chunk took ~11.8 us for ~3.2 us of MFMA work and the two
+// kernels were 43 % of the step (profiles/r05_c_recipe_shape.md).  Here: every row of a chunk is requested up front, the NEXT chunk's rows
+// are requested before the current chunk is consumed (register prefetch), RoPE comes from the compact LDS tables of the forward kernel, and
+// the transposed operands (K^T, Q^T, dO^T) are read straight from the row-major images with ds_read_b64_tr_b16 -- no transposed images.
+// Same products, same accumulation order, same rotated values: bit-identical gradients (tests/test_gpu_ops.py).
+// dQ: wave = 32 queries, loops over key chunks.  dS^T = P^T o (dP^T - D) * scale ; dQ^T += K^T . dS^T
+// SINGLE: the whole sequence is one chunk (Ntok <= CH * 32: the 14x14 grid) -- no chunk loop, no prefetch registers, 128 VGPRs: two
+// workgroups per CU
+template <int CH, bool SINGLE>
+__global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnArgs p) {
+    constexpr int CHK = CH * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kl = smem;
+    char* Vl = smem + CHK * 128;
+    float* rt = (float*)(smem + 2 * CHK * 128);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int C = p.H * HD;
+    const size_t rowbase = (size_t)b * p.Ntok;
+    const int q = blockIdx.x * 256 + wave * 32 + l31;
+    const int qc = min(q, p.Ntok - 1);
+    const bool wave_active = (blockIdx.x * 256 + wave * 32) < p.Ntok;
+    const float sl2 = p.scale * LOG2E;
+
+    RowRegs<CHK> kr, vr;
+    kr.load(p.qkv, rowbase, p.ldqkv, C + h * HD, 0, p.Ntok, tid);
+    vr.load(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, 0, p.Ntok, tid);
+    load_rope_tables<512>(rt, p.cos_t, p.sin_t, p.grid, tid);
+    __syncthreads();
+    bf16x8 qf[4], dof[4];
+    load_q_frags(p, rt, rowbase, qc, h, hf, qf);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) dof[ks] = *(const bf16x8*)(p.dout + (rowbase + qc) * p.ldo + h * HD + ks * 16 + hf * 8);
+    const float lse2 = p.lse_in[(size_t)bh * p.Ntok + qc] * LOG2E;
+    const float dq_sum = p.dsum[(size_t)bh * p.Ntok + qc];
+    f32x16 dq[2] = {zero16(), zero16()};
+    // row fragments (lane = key row): LDS row (row >> 1), slot ((row & 1) * 8 | chunk) ^ ((row >> 1) & 15), as attend_chunk
+    const int k_base = (l31 >> 1) << 8, par8 = (l31 & 1) << 3, sw = l31 >> 1;
+    // transposed fragments (lane = head dim): contraction slots in the accumulator order -- half hf supplies keys base + 4 hf + {0..3, 8..11}
+    int toff[2][2][2];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            toff[c2][dt][0] = tr_lane_off(c2 * 16 + 4 * hf, dt * 32, lane);
+            toff[c2][dt][1] = tr_lane_off(c2 * 16 + 8 + 4 * hf, dt * 32, lane);
+        }
+
+    for (int key0 = 0; key0 < (SINGLE ? 1 : p.Ntok); key0 += CHK) {
+        if (key0) __syncthreads();                     // every wave is done with the previous chunk's images
+        kr.template store<true>(Kl, rt, p.grid, p.inv_grid, key0, p.Ntok, tid);
+        vr.template store<false>(Vl, rt, p.grid, p.inv_grid, key0, p.Ntok, tid);
+        __syncthreads();
+        if (!SINGLE && key0 + CHK < p.Ntok) {          // the next chunk's rows travel while this one is consumed
+            kr.load(p.qkv, rowbase, p.ldqkv, C + h * HD, key0 + CHK, p.Ntok, tid);
+            vr.load(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0 + CHK, p.Ntok, tid);
+        }
+        if (!wave_active) continue;
+#pragma nounroll
+        for (int t = 0; t < CH; ++t) {
+            if (key0 + t * 32 >= p.Ntok) break;        // wave-uniform: a tile of padding keys only (p = 0 everywhere)
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = t * (16 * 256) + k_base + (((par8 | (ks * 2 + hf)) ^ sw) << 4);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Kl + off), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Vl + off), dof[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = key0 + t * 32 + mfma32_row(e, lane);
+                const float pv = key < p.Ntok ? exp2f(s[e] * sl2 - lse2) : 0.f;
+                s[e] = pv * (dp[e] - dq_sum) * p.scale;
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const bf16x8 db = pack8(s, c2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x8 kt = tr_join2(tr_read4(Kl + t * (16 * 256) + toff[c2][dt][0]), tr_read4(Kl + t * (16 * 256) + toff[c2][dt][1]));
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, db, dq[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (wave_active && q < p.Ntok) {
+        const size_t pos = (size_t)(q > 0 ? q - 1 : 0) * HD;
+        store_grad_tile(dq, p.out + (rowbase + q) * p.ldqkv + h * HD, q > 0, p.cos_t + pos, p.sin_t + pos, hf);
+    }
+}
+
+// dK, dV: wave = 32 keys, loops over query chunks.  S = Q K^T (lane = key, registers = queries);  dV^T += dO^T . P ;  dK^T += Q^T . dS
+template <int CH, bool SINGLE>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {       // 64 + 32 + 32 accumulator / operand registers: no 128-register form
+    constexpr int CHQ = CH * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ql = smem;
+    char* Gl = smem + CHQ * 128;
+    float* lse_s = (float*)(smem + 2 * CHQ * 128);
+    float* dsum_s = lse_s + CHQ;
+    float* rt = dsum_s + CHQ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int C = p.H * HD;
+    const size_t rowbase = (size_t)b * p.Ntok;
+    const int key = blockIdx.x * 256 + wave * 32 + l31;
+    const int kc = min(key, p.Ntok - 1);
+    const bool wave_active = (blockIdx.x * 256 + wave * 32) < p.Ntok;
+    const float sl2 = p.scale * LOG2E;
+
+    RowRegs<CHQ> qr, gr;
+    qr.load(p.qkv, rowbase, p.ldqkv, h * HD, 0, p.Ntok, tid);
+    gr.load(p.dout, rowbase, p.ldo, h * HD, 0, p.Ntok, tid);
+    float lse_r = 0.f, dsum_r = 0.f;                   // thread i < CHQ carries query q0 + i's statistics
+    auto load_stats = [&](int q0) {
+        if (tid < CHQ) {
+            const int qi = q0 + tid;
+            lse_r = qi < p.Ntok ? p.lse_in[(size_t)bh * p.Ntok + qi] * LOG2E : INFINITY;      // +inf -> P = 0 for padded queries
+            dsum_r = qi < p.Ntok ? p.dsum[(size_t)bh * p.Ntok + qi] : 0.f;
+        }
+    };
+    load_stats(0);
+    load_rope_tables<512>(rt, p.cos_t, p.sin_t, p.grid, tid);
+    __syncthreads();
+    bf16x8 kf[4], vf[4];
+    {
+        U128 t[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            t[ks].u = *(const uint4*)(p.qkv + (rowbase + kc) * p.ldqkv + C + h * HD + ks * 16 + hf * 8);
+            vf[ks] = *(const bf16x8*)(p.qkv + (rowbase + kc) * p.ldqkv + 2 * C + h * HD + ks * 16 + hf * 8);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (kc > 0) rope8_lds(t[ks], rt, p.grid, p.inv_grid, kc, ks * 2 + hf);
+            kf[ks] = t[ks].h;
+        }
+    }
+    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+    const int k_base = (l31 >> 1) << 8, par8 = (l31 & 1) << 3, sw = l31 >> 1;
+    int toff[2][2][2];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            toff[c2][dt][0] = tr_lane_off(c2 * 16 + 4 * hf, dt * 32, lane);
+            toff[c2][dt][1] = tr_lane_off(c2 * 16 + 8 + 4 * hf, dt * 32, lane);
+        }
+
+    for (int q0 = 0; q0 < (SINGLE ? 1 : p.Ntok); q0 += CHQ) {
+        if (q0) __syncthreads();
+        qr.template store<true>(Ql, rt, p.grid, p.inv_grid, q0, p.Ntok, tid);
+        gr.template store<false>(Gl, rt, p.grid, p.inv_grid, q0, p.Ntok, tid);
+        if (tid < CHQ) { lse_s[tid] = lse_r; dsum_s[tid] = dsum_r; }
+        __syncthreads();
+        if (!SINGLE && q0 + CHQ < p.Ntok) {
+            qr.load(p.qkv, rowbase, p.ldqkv, h * HD, q0 + CHQ, p.Ntok, tid);
+            gr.load(p.dout, rowbase, p.ldo, h * HD, q0 + CHQ, p.Ntok, tid);
+            load_stats(q0 + CHQ);
+        }
+        if (!wave_active) continue;
+#pragma nounroll
+        for (int t = 0; t < CH; ++t) {
+            if (q0 + t * 32 >= p.Ntok) break;          // a tile of padding queries only: P = 0
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = t * (16 * 256) + k_base + (((par8 | (ks * 2 + hf)) ^ sw) << 4);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Ql + off), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Gl + off), vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qi = t * 32 + mfma32_row(e, lane);
+                const float pv = key < p.Ntok ? exp2f(s[e] * sl2 - lse_s[qi]) : 0.f;
+                s[e] = pv;
+                dp[e] = pv * (dp[e] - dsum_s[qi]) * p.scale;
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const bf16x8 pb = pack8(s, c2), db = pack8(dp, c2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int o0 = t * (16 * 256) + toff[c2][dt][0], o1 = t * (16 * 256) + toff[c2][dt][1];
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join2(tr_read4(Gl + o0), tr_read4(Gl + o1)), pb, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join2(tr_read4(Ql + o0), tr_read4(Ql + o1)), db, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (wave_active && key < p.Ntok) {
+        const size_t pos = (size_t)(key > 0 ? key - 1 : 0) * HD;
+        __bf16* row = p.out + (rowbase + key) * p.ldqkv + h * HD;
+        store_grad_tile(dk, row + C, key > 0, p.cos_t + pos, p.sin_t + pos, hf);
+        store_grad_tile(dv, row + 2 * C, false, nullptr, nullptr, hf);
+    }
+}
+
 template <typename K>
 void set_lds(K kernel, size_t bytes) { (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); }
 
@@ -857,9 +1163,14 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
         if (Ntok > (CH - 1) * 32) hipLaunchKernelGGL((attn_fwd8_kernel<true>), dim3(1, B * H), dim3(512), lds, stream, a);
         else hipLaunchKernelGGL((attn_fwd8_kernel<false>), dim3(1, B * H), dim3(512), lds, stream, a);
     } else {
-        static bool once = (set_lds(attn_fwd_kernel<CH>, 160 * 1024), true);
+        static bool once = (set_lds(attn_fwd_kernel<CH>, 160 * 1024), set_lds(attn_fwd2_kernel<CH, 4>, 160 * 1024), true);
         (void)once;
-        hipLaunchKernelGGL((attn_fwd_kernel<CH>), dim3((Ntok + 255) / 256, B * H), dim3(512), lds, stream, a);
+        if (getenv("CS_ATTN_FWD_V1")) {                    // A/B switch, read per launch: the synchronous round-1 form
+            hipLaunchKernelGGL((attn_fwd_kernel<CH>), dim3((Ntok + 255) / 256, B * H), dim3(512), lds, stream, a);
+        } else {
+            const size_t lds2 = (size_t)2 * CH * 32 * 128 + (size_t)4 * g * 32 * sizeof(float);
+            hipLaunchKernelGGL((attn_fwd2_kernel<CH, 4>), dim3((Ntok + 255) / 256, B * H), dim3(512), lds2, stream, a);
+        }
     }
     CS_LAUNCH_CHECK();
 #ifdef CS_ABLATION_SWITCHES
@@ -903,6 +1214,29 @@ extern "C" int cs_attn_bwd(const void* qkv, const void* o, const void* dout, con
     dim3 grid((Ntok + 255) / 256, B * H), block(512);
     constexpr int CH = 7;
     constexpr int CHK = CH * 32, VLD = CHK + 4;
+    const int g = (int)(sqrtf((float)(Ntok - 1)) + 0.5f);
+    const bool v1 = getenv("CS_ATTN_BWD_V1") != nullptr;                 // A/B switch, read per launch: the round-1 kernels (transposed images, global RoPE tables)
+    if (!v1) {
+        CS_CHECK_ARG(g * g == Ntok - 1, "cs_attn_bwd: Ntok - 1 = %d is not a square token grid (the RoPE tables are read separably, as in cs_attn_fwd)", Ntok - 1);
+        a.grid = g; a.inv_grid = 1.f / (float)g;
+        const size_t rope = (size_t)4 * g * 32 * sizeof(float);
+        const size_t lds_dq = (size_t)2 * CHK * 128 + rope, lds_dkv = (size_t)2 * CHK * 128 + (size_t)2 * CHK * sizeof(float) + rope;
+        CS_CHECK_ARG(lds_dkv <= 160 * 1024, "cs_attn_bwd: token grid %d too large for the LDS RoPE tables", g);
+        static bool once = (set_lds(attn_bwd_dq2_kernel<CH, false>, 160 * 1024), set_lds(attn_bwd_dkv2_kernel<CH, false>, 160 * 1024),
+                            set_lds(attn_bwd_dq2_kernel<CH, true>, 160 * 1024), set_lds(attn_bwd_dkv2_kernel<CH, true>, 160 * 1024), true);
+        (void)once;
+        if (Ntok <= CHK) {
+            hipLaunchKernelGGL((attn_bwd_dq2_kernel<CH, true>), grid, block, lds_dq, stream, a);
+            CS_LAUNCH_CHECK();
+            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<CH, true>), grid, block, lds_dkv, stream, a);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dq2_kernel<CH, false>), grid, block, lds_dq, stream, a);
+            CS_LAUNCH_CHECK();
+            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<CH, false>), grid, block, lds_dkv, stream, a);
+        }
+        CS_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds_dq = (size_t)2 * CHK * 128 + (size_t)HD * VLD * 2;
     const size_t lds_dkv = (size_t)2 * CHK * 128 + (size_t)2 * HD * VLD * 2 + (size_t)2 * CHK * sizeof(float);
     static bool once = (set_lds(attn_bwd_dq_kernel<CH>, lds_dq), set_lds(attn_bwd_dkv_kernel<CH>, lds_dkv), true);

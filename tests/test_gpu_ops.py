@@ -326,6 +326,39 @@ def test_attention_fwd_bwd(hip, ref, B, Ntok, H, qscale):
     check(tag + ".dv", dq_d[:, 2 * C:], dq_r[:, 2 * C:], 1.5e-2)
 
 
+@pytest.mark.parametrize("B,Ntok,H,qscale", [(9, 197, 12, 1.0), (3, 17, 2, 3.0), (2, 65, 2, 2.0), (2, 577, 3, 1.5), (1, 785, 2, 4.0), (2, 4097, 3, 1.0)])
+def test_attention_bwd_restaged_kernels_equal_the_round1_kernels_bit_for_bit(hip, B, Ntok, H, qscale):
+    """Round 5 re-staged the attention backward (all rows of a chunk requested up front, next chunk prefetched into registers, RoPE from the
+    LDS tables, K^T / Q^T / dO^T read from the row-major images with ds_read_b64_tr_b16): same products in the same order, so d(q|k|v)
+    must equal the round-1 kernels (CS_ATTN_BWD_V1, read per launch) in every bit -- one chunk (<= 224 tokens), several, and the recipe's
+    4097 tokens (19 chunks, ragged last one)."""
+    import os
+    C = H * 64
+    qkv = rnd((B * Ntok, 3 * C), F32, 1.0, seed=36)
+    qkv[:, :2 * C] *= qscale
+    qkv = qkv.to(BF).cuda()
+    cos, sin = (t.cuda() for t in _rope(Ntok, 0))
+    scale = 64 ** -0.5
+    dout = rnd((B * Ntok, C), BF, seed=37).cuda()
+    o = torch.empty(B * Ntok, C, dtype=BF, device="cuda")
+    lse = torch.empty(B * H, Ntok, device="cuda")
+    hip.attn_fwd(qkv, cos, sin, o, lse, B, Ntok, H, scale)
+    ws = torch.empty(hip.attn_bwd_workspace(B, Ntok, H), dtype=torch.uint8, device="cuda")
+    got = torch.full((B * Ntok, 3 * C), float("nan"), dtype=BF, device="cuda")
+    hip.attn_bwd(qkv, o, dout, lse, cos, sin, got, ws, B, Ntok, H, scale)
+    assert torch.isfinite(got.float()).all()
+    old = torch.full((B * Ntok, 3 * C), float("nan"), dtype=BF, device="cuda")
+    os.environ["CS_ATTN_BWD_V1"] = "1"
+    try:
+        hip.attn_bwd(qkv, o, dout, lse, cos, sin, old, ws, B, Ntok, H, scale)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["CS_ATTN_BWD_V1"]
+    for name, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
+        diff = int((got[:, sl] != old[:, sl]).sum())
+        assert diff == 0, f"{name}: {diff} of {got[:, sl].numel()} elements differ from the round-1 kernel"
+
+
 @pytest.mark.parametrize("B,Ntok,H", [(120, 197, 12), (700, 17, 2), (90, 65, 12)])
 def test_attention_units_are_launch_size_invariant(hip, B, Ntok, H):
     """A (crop, head) unit's result must not depend on the size of the launch it is part of (more units than resident workgroups: 12
