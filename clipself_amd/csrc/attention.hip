@@ -25,6 +25,7 @@ namespace {
 constexpr int HD = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 
+#define Z16 (f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f})
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -228,7 +229,9 @@ struct RowRegs {
             v[it] = *(const uint4*)(src + (rowbase + tok) * ld + coloff + (idx & 7) * 8);
         }
     }
-    template <bool ROPE>
+    // ZPAD: rows past the sequence are stored as zeros (the dQ kernel: a zero K row contributes nothing to dQ^T += K^T . dS^T whatever its
+    // dS column holds, so the hot loop masks nothing)
+    template <bool ROPE, bool ZPAD = false>
     __device__ __forceinline__ void store(char* tile, const float* rt, int g, float inv_g, int tok0, int Ntok, int tid) {
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
@@ -237,6 +240,7 @@ struct RowRegs {
                 U128 t;
                 t.u = v[it];
                 if (ROPE && tok > 0 && tok < Ntok) rope8_lds(t, rt, g, inv_g, tok, c);
+                if (ZPAD && tok >= Ntok) t.u = make_uint4(0, 0, 0, 0);
                 *(uint4*)(tile + k_off(r, c)) = t.u;
             }
         }
@@ -835,7 +839,7 @@ __global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnA
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) dof[ks] = *(const bf16x8*)(p.dout + (rowbase + qc) * p.ldo + h * HD + ks * 16 + hf * 8);
     const float lse2 = p.lse_in[(size_t)bh * p.Ntok + qc] * LOG2E;
-    const float dq_sum = p.dsum[(size_t)bh * p.Ntok + qc];
+    const float dq_sum_s = p.dsum[(size_t)bh * p.Ntok + qc] * p.scale;
     f32x16 dq[2] = {zero16(), zero16()};
     // row fragments (lane = key row): LDS row (row >> 1), slot ((row & 1) * 8 | chunk) ^ ((row >> 1) & 15), as attend_chunk
     const int k_base = (l31 >> 1) << 8, par8 = (l31 & 1) << 3, sw = l31 >> 1;
@@ -851,7 +855,7 @@ __global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnA
 
     for (int key0 = 0; key0 < (SINGLE ? 1 : p.Ntok); key0 += CHK) {
         if (key0) __syncthreads();                     // every wave is done with the previous chunk's images
-        kr.template store<true>(Kl, rt, p.grid, p.inv_grid, key0, p.Ntok, tid);
+        kr.template store<true, true>(Kl, rt, p.grid, p.inv_grid, key0, p.Ntok, tid);
         vr.template store<false>(Vl, rt, p.grid, p.inv_grid, key0, p.Ntok, tid);
         __syncthreads();
         if (!SINGLE && key0 + CHK < p.Ntok) {          // the next chunk's rows travel while this one is consumed
@@ -859,22 +863,21 @@ __global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnA
             vr.load(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0 + CHK, p.Ntok, tid);
         }
         if (!wave_active) continue;
-#pragma nounroll
+#pragma unroll                                         // t * 4096 becomes the immediate offset of every LDS read
         for (int t = 0; t < CH; ++t) {
             if (key0 + t * 32 >= p.Ntok) break;        // wave-uniform: a tile of padding keys only (p = 0 everywhere)
-            f32x16 s = zero16(), dp = zero16();
+            f32x16 s, dp;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int off = t * (16 * 256) + k_base + (((par8 | (ks * 2 + hf)) ^ sw) << 4);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Kl + off), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Vl + off), dof[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Kl + off), qf[ks], ks ? s : Z16, 0, 0, 0);       // first step onto the inline 0
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Vl + off), dof[ks], ks ? dp : Z16, 0, 0, 0);
             }
+            // the softmax recomputation is the VALU half of this kernel (16 elements per lane and tile against 12 MFMAs): one FMA + the raw
+            // v_exp_f32 (argument <= ~0, p in [0, 1]) + one FMA + one multiply per element.  Padding keys need no mask: their K rows are
+            // zeros in the image (ZPAD), so their dS columns meet a zero K^T column.
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = key0 + t * 32 + mfma32_row(e, lane);
-                const float pv = key < p.Ntok ? exp2f(s[e] * sl2 - lse2) : 0.f;
-                s[e] = pv * (dp[e] - dq_sum) * p.scale;
-            }
+            for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(fmaf(s[e], sl2, -lse2)) * fmaf(dp[e], p.scale, -dq_sum_s);
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
                 const bf16x8 db = pack8(s, c2);
@@ -920,7 +923,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {    
         if (tid < CHQ) {
             const int qi = q0 + tid;
             lse_r = qi < p.Ntok ? p.lse_in[(size_t)bh * p.Ntok + qi] * LOG2E : INFINITY;      // +inf -> P = 0 for padded queries
-            dsum_r = qi < p.Ntok ? p.dsum[(size_t)bh * p.Ntok + qi] : 0.f;
+            dsum_r = qi < p.Ntok ? p.dsum[(size_t)bh * p.Ntok + qi] * p.scale : 0.f;    // D * scale: dS = P (dP * scale - D * scale)
         }
     };
     load_stats(0);
@@ -963,22 +966,29 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {    
             load_stats(q0 + CHQ);
         }
         if (!wave_active) continue;
-#pragma nounroll
+#pragma unroll
         for (int t = 0; t < CH; ++t) {
             if (q0 + t * 32 >= p.Ntok) break;          // a tile of padding queries only: P = 0
-            f32x16 s = zero16(), dp = zero16();
+            f32x16 s, dp;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int off = t * (16 * 256) + k_base + (((par8 | (ks * 2 + hf)) ^ sw) << 4);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Ql + off), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Gl + off), vf[ks], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Ql + off), kf[ks], ks ? s : Z16, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Gl + off), vf[ks], ks ? dp : Z16, 0, 0, 0);
             }
+            // a lane owns ONE key: a padding key's column is never stored, so nothing is masked here; padding queries carry lse = +inf
+            // (p = exp2(-inf) = 0).  Four consecutive queries' statistics per 16-byte LDS read (accumulator rows 4k .. 4k + 3 of a half).
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int qi = t * 32 + mfma32_row(e, lane);
-                const float pv = key < p.Ntok ? exp2f(s[e] * sl2 - lse_s[qi]) : 0.f;
-                s[e] = pv;
-                dp[e] = pv * (dp[e] - dsum_s[qi]) * p.scale;
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const float4 l4 = *(const float4*)(lse_s + t * 32 + 8 * k4 + 4 * hf), d4 = *(const float4*)(dsum_s + t * 32 + 8 * k4 + 4 * hf);
+                const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, ds[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = k4 * 4 + r;
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[e], sl2, -ls[r]));
+                    s[e] = pv;
+                    dp[e] = pv * fmaf(dp[e], p.scale, -ds[r]);
+                }
             }
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {

@@ -31,6 +31,12 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+def _metric(line):
+    _LOG.parent.mkdir(exist_ok=True)
+    with open(_LOG, "a") as f:
+        f.write(line + "\n")
+
+
 def check(name, got, want, tol):
     r = rel(got, want)
     bad = not torch.isfinite(got.float()).all().item()
@@ -327,11 +333,14 @@ def test_attention_fwd_bwd(hip, ref, B, Ntok, H, qscale):
 
 
 @pytest.mark.parametrize("B,Ntok,H,qscale", [(9, 197, 12, 1.0), (3, 17, 2, 3.0), (2, 65, 2, 2.0), (2, 577, 3, 1.5), (1, 785, 2, 4.0), (2, 4097, 3, 1.0)])
-def test_attention_bwd_restaged_kernels_equal_the_round1_kernels_bit_for_bit(hip, B, Ntok, H, qscale):
+def test_attention_bwd_restaged_kernels_against_the_round1_kernels(hip, B, Ntok, H, qscale):
     """Round 5 re-staged the attention backward (all rows of a chunk requested up front, next chunk prefetched into registers, RoPE from the
-    LDS tables, K^T / Q^T / dO^T read from the row-major images with ds_read_b64_tr_b16): same products in the same order, so d(q|k|v)
-    must equal the round-1 kernels (CS_ATTN_BWD_V1, read per launch) in every bit -- one chunk (<= 224 tokens), several, and the recipe's
-    4097 tokens (19 chunks, ragged last one)."""
+    LDS tables, K^T / Q^T / dO^T read from the row-major images with ds_read_b64_tr_b16): the same products in the same order -- the first
+    form was bit-identical to the round-1 kernels (CS_ATTN_BWD_V1, read per launch) on all six shapes (profiles/r05_c_*).  The hot loop then
+    lost its masking (zero K rows / +inf lse for the padding), took the raw v_exp_f32 and folds the softmax scale into one FMA
+    (dS = P (dP * scale - D * scale)): fp32 roundings in front of the bf16 store differ, so the comparison is a distance now: rel-L2 <= 2e-3
+    per gradient (a 1-ulp flip of a bf16 value is 4e-3 of that value), no isolated outlier (worst |difference| <= 0.1 rms), and two launches
+    of the new kernels agree in every bit."""
     import os
     C = H * 64
     qkv = rnd((B * Ntok, 3 * C), F32, 1.0, seed=36)
@@ -347,6 +356,9 @@ def test_attention_bwd_restaged_kernels_equal_the_round1_kernels_bit_for_bit(hip
     got = torch.full((B * Ntok, 3 * C), float("nan"), dtype=BF, device="cuda")
     hip.attn_bwd(qkv, o, dout, lse, cos, sin, got, ws, B, Ntok, H, scale)
     assert torch.isfinite(got.float()).all()
+    again = torch.full_like(got, float("nan"))
+    hip.attn_bwd(qkv, o, dout, lse, cos, sin, again, ws, B, Ntok, H, scale)
+    assert torch.equal(got, again), "the backward is not reproducible from launch to launch"
     old = torch.full((B * Ntok, 3 * C), float("nan"), dtype=BF, device="cuda")
     os.environ["CS_ATTN_BWD_V1"] = "1"
     try:
@@ -355,8 +367,11 @@ def test_attention_bwd_restaged_kernels_equal_the_round1_kernels_bit_for_bit(hip
     finally:
         del os.environ["CS_ATTN_BWD_V1"]
     for name, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
-        diff = int((got[:, sl] != old[:, sl]).sum())
-        assert diff == 0, f"{name}: {diff} of {got[:, sl].numel()} elements differ from the round-1 kernel"
+        a, b = got[:, sl].float(), old[:, sl].float()
+        r = float((a - b).norm() / b.norm())
+        worst = float((a - b).abs().max() / b.pow(2).mean().sqrt())
+        _metric(f"attn_bwd v2 vs v1 [{B},{Ntok},{H},x{qscale}] {name}: rel-L2 {r:.2e}, worst |diff| / rms {worst:.2e}, differing {float((a != b).float().mean()):.2%}")
+        assert r <= 2e-3 and worst <= 0.1, (name, r, worst)
 
 
 @pytest.mark.parametrize("B,Ntok,H", [(120, 197, 12), (700, 17, 2), (90, 65, 12)])
