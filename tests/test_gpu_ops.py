@@ -372,6 +372,9 @@ def test_attention_bwd_restaged_kernels_against_the_round1_kernels(hip, B, Ntok,
         worst = float((a - b).abs().max() / b.pow(2).mean().sqrt())
         _metric(f"attn_bwd v2 vs v1 [{B},{Ntok},{H},x{qscale}] {name}: rel-L2 {r:.2e}, worst |diff| / rms {worst:.2e}, differing {float((a != b).float().mean()):.2%}")
         assert r <= 2e-3 and worst <= 0.1, (name, r, worst)
+        # head width 64: the softmax scale is 2^-3, a multiplication by it commutes with every rounding, and no probability is denormal --
+        # the trimmed arithmetic then still produces the round-1 bits (measured on all six shapes: 0 elements differ)
+        assert torch.equal(got[:, sl], old[:, sl]), f"{name}: {int((a != b).sum())} elements differ from the round-1 kernel"
 
 
 @pytest.mark.parametrize("B,Ntok,H", [(120, 197, 12), (700, 17, 2), (90, 65, 12)])
