@@ -188,21 +188,18 @@ __global__ __launch_bounds__(256) void ln_stats_finalize2_kernel(const float* __
         s[0] += v.x; q[0] += fmaxf(v.y - t0, 0.f); b[0] += t0;
         s[1] += v.z; q[1] += fmaxf(v.w - t1, 0.f); b[1] += t1;
     };
-    int p = 0;
-    for (; p + 8 <= P; p += 8) {
-        float4 v[8];
+    // sixteen slices in flight per thread, the ragged last batch included (slices past P re-read slice P - 1 and are not added): round 4's
+    // form walked the last P % 8 slices one dependent load at a time -- for the 12-slice launches (three of a block's four) that was four
+    // of its five memory round trips.  Same additions in the same order: bit-identical statistics.
+    for (int p = 0; p < P; p += 16) {
+        float4 v[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(p + j) * stride];
+        for (int j = 0; j < 16; ++j) v[j] = src[(size_t)min(p + j, P - 1) * stride];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 16; ++j) {
             const int n = min(npp, C - (p + j) * npp);
-            if (n > 0) add(v[j], n);
+            if (p + j < P && n > 0) add(v[j], n);
         }
-    }
-    for (; p < P; ++p) {
-        const int n = min(npp, C - p * npp);
-        if (n <= 0) break;
-        add(src[(size_t)p * stride], n);
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
