@@ -59,13 +59,20 @@ __global__ __launch_bounds__(256) void roialign_fwd_kernel(const float* __restri
     __syncthreads();
     const bool empty = g.gh <= 0 || g.gw <= 0;
     const float* fb = feat + ((size_t)g.b * Ntok + tok_off) * E;
+    // the cells a box touches are a sub-rectangle of the map: walk that, not the whole map (the recipe's 64 x 64 grid: 4096 cells per box and
+    // thread, ~250 of them with a weight; zero weights inside the range are still skipped, so the additions and their order are unchanged)
+    int r_lo = 0, r_hi = gh_map, c_lo = 0, c_hi = gw_map;
+    while (r_lo < r_hi && Wy[r_lo] == 0.f) ++r_lo;
+    while (r_hi > r_lo && Wy[r_hi - 1] == 0.f) --r_hi;
+    while (c_lo < c_hi && Wx[c_lo] == 0.f) ++c_lo;
+    while (c_hi > c_lo && Wx[c_hi - 1] == 0.f) --c_hi;
     for (int ch = tid * 4; ch < E; ch += 1024) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!empty) {
-            for (int r = 0; r < gh_map; ++r) {
+            for (int r = r_lo; r < r_hi; ++r) {
                 const float wy = Wy[r];
                 if (wy == 0.f) continue;
-                for (int c = 0; c < gw_map; ++c) {
+                for (int c = c_lo; c < c_hi; ++c) {
                     const float w = wy * Wx[c];
                     if (w == 0.f) continue;
                     const float4 v = *(const float4*)(fb + (size_t)(r * gw_map + c) * E + ch);
