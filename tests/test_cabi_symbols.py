@@ -72,3 +72,29 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
                         f"-L{lib.parent}", "-l:" + lib.name, f"-Wl,-rpath,{lib.parent}", "-Wl,--unresolved-symbols=ignore-in-shared-libs"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_compute_unit_reservations_compose():
+    """HipOps folds three requests into cs_gemm_nt's flags bits 20-27 (compute units a persistent grid leaves free): RCCL's reserve
+    (training/distributed.py), the share a prefetched teacher pass leaves to the student, and the cap of the student's own grids.  Teacher side:
+    reserve + share; student side: max(reserve, CUs - cap); never fewer than 8 workgroups.  (No GPU: the object is built around the logic.)"""
+    from clipself_amd import hip
+    ops = hip.HipOps.__new__(hip.HipOps)
+    ops.gemm_flags, ops._rccl_reserve, ops._share, ops._cap, ops.num_cus = 0x90, 0, 0, 0, 256
+    ops.reserve_compute_units(16)
+    assert ops.persistent_grid() == 240 and ops.gemm_flags & 0xFFFFF == 0x90
+    ops.share_compute_units(48)                      # the teacher inside the RCCL window of a partitioned run
+    assert ops.persistent_grid() == 256 - 64
+    ops.reserve_compute_units(0)
+    assert ops.persistent_grid() == 208
+    ops.share_compute_units(0)
+    assert ops.persistent_grid() == 256 and ops.gemm_flags == 0x90
+    ops.cap_compute_units(48)                        # the student beside a prefetched pass ...
+    assert ops.persistent_grid() == 48
+    ops.reserve_compute_units(16)                    # ... with gradient buckets in flight: the cap already leaves RCCL its CUs
+    assert ops.persistent_grid() == 48
+    ops.cap_compute_units(0)
+    assert ops.persistent_grid() == 240
+    ops.reserve_compute_units(0)
+    with pytest.raises(AssertionError):
+        ops.cap_compute_units(4)                     # fewer than 8 workgroups: cs_persistent_cap() would ignore it
