@@ -496,13 +496,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnArgs p) {
 // exp -> P.V per tile; global loads -> LDS images -> barrier per unit), not by MFMA or VALU throughput: twice the waves per SIMD is
 // what hides them.  Same arithmetic per element as the single-chunk form except that the running maximum of the first chunks rescales
 // the output accumulators (exact when the maximum does not change, one fp32 rounding of alpha * o otherwise).
-template <bool TAIL>
+// VROW (round 5): V stays row-major in LDS (staged like K, four 16-byte items per thread on all 512 threads) and its transposed fragments come
+// from ds_read_b64_tr_b16 -- no 8 x 8 in-register transposes on 224 of the 512 threads, 16 instead of 32 staging registers; same values into the
+// same MFMAs: bit-identical outputs (CS_ATTN_FWD8_VT=1 runs the transposed-image form, A/B switch).
+template <bool TAIL, bool VROW>
 __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
     constexpr int CH = 7, CHK = CH * 32, NT = 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kl = smem;
     __bf16* Vt = (__bf16*)(smem + CHK * 128);
-    float* rt = (float*)(smem + CHK * 128 + HD * VT_LD * 2);      // compact RoPE tables [4][g][32]
+    float* rt = (float*)(smem + CHK * 128 + (VROW ? CHK * 128 : HD * VT_LD * 2));      // compact RoPE tables [4][g][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int C = p.H * HD;
@@ -533,19 +536,25 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     constexpr int KI = (CHK * 8 + NT - 1) / NT;
-    U128 kr[KI], vin[8], qraw[4];
+    U128 kr[VROW ? 1 : KI], vin[VROW ? 1 : 8], qraw[4];
+    RowRegs<CHK> krow, vrow;               // VROW: K and V rows as plain vectors, staged by the same routine as the backward's images
     const __bf16* kbase = p.qkv + C + h * HD;
     const __bf16* vbase = p.qkv + 2 * C + h * HD;
-#pragma unroll
-    for (int it = 0; it < KI; ++it) {      // branch-free: rows past the sequence re-read its last row (masked to p = 0 exactly)
-        const int idx = min(tid + it * NT, CHK * 8 - 1), tok = min(idx >> 3, last);
-        kr[it].u = *(const uint4*)(kbase + (rowbase + tok) * p.ldqkv + (idx & 7) * 8);
-    }
     const int vkb = min(tid, CHK - 1) >> 3, vc = tid & 7;      // one (key block, dim chunk) item per thread, threads >= 224 repeat the last
+    if constexpr (VROW) {
+        krow.load(p.qkv, rowbase, p.ldqkv, C + h * HD, 0, p.Ntok, tid);
+        vrow.load(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, 0, p.Ntok, tid);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int tok = min(vkb * 8 + i, last);
-        vin[i].u = *(const uint4*)(vbase + (rowbase + tok) * p.ldqkv + vc * 8);
+        for (int it = 0; it < KI; ++it) {      // branch-free: rows past the sequence re-read its last row (masked to p = 0 exactly)
+            const int idx = min(tid + it * NT, CHK * 8 - 1), tok = min(idx >> 3, last);
+            kr[it].u = *(const uint4*)(kbase + (rowbase + tok) * p.ldqkv + (idx & 7) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tok = min(vkb * 8 + i, last);
+            vin[i].u = *(const uint4*)(vbase + (rowbase + tok) * p.ldqkv + vc * 8);
+        }
     }
     const int q0 = wave * 32, q = q0 + l31, qc = min(q, last);
 #pragma unroll
@@ -558,22 +567,27 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
     }
     __syncthreads();
     ATT_TRACE(3);
+    if constexpr (VROW) {
+        krow.template store<true>(Kl, rt, p.grid, p.inv_grid, 0, p.Ntok, tid);
+        vrow.template store<false>((char*)Vt, rt, p.grid, p.inv_grid, 0, p.Ntok, tid);
+    } else {
 #pragma unroll
-    for (int it = 0; it < KI; ++it) {      // K: rotate + swizzled LDS image
-        const int idx = tid + it * NT, r = idx >> 3, c = idx & 7;
-        if (idx < CHK * 8) {
-            if (r > 0 && r < p.Ntok && !ATT_ABL(p, 2)) rope8_lds(kr[it], rt, p.grid, p.inv_grid, r, c);
-            *(uint4*)(Kl + k_off(r, c)) = kr[it].u;
+        for (int it = 0; it < KI; ++it) {      // K: rotate + swizzled LDS image
+            const int idx = tid + it * NT, r = idx >> 3, c = idx & 7;
+            if (idx < CHK * 8) {
+                if (r > 0 && r < p.Ntok && !ATT_ABL(p, 2)) rope8_lds(kr[it], rt, p.grid, p.inv_grid, r, c);
+                *(uint4*)(Kl + k_off(r, c)) = kr[it].u;
+            }
         }
-    }
-    if (tid < CHK) {                       // V: 8x8 in-register transpose -> V^T image
-        const int pos = (vkb ^ vc) * 8;
+        if (tid < CHK) {                   // V: 8x8 in-register transpose -> V^T image
+            const int pos = (vkb ^ vc) * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            U128 o;
+            for (int j = 0; j < 8; ++j) {
+                U128 o;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o.e[i] = vin[i].e[j];
-            *(uint4*)(Vt + (vc * 8 + j) * VT_LD + pos) = o.u;
+                for (int i = 0; i < 8; ++i) o.e[i] = vin[i].e[j];
+                *(uint4*)(Vt + (vc * 8 + j) * VT_LD + pos) = o.u;
+            }
         }
     }
     __syncthreads();
@@ -589,13 +603,13 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
     f32x16 o[2] = {zero16(), zero16()};
     if (ATT_ABL(p, 1)) { l = 1.f; m = 0.f; o[0][0] = bf2f(qf[0][0]); }
     else if (TAIL) {                       // 192 < Ntok <= 224 (the 14x14 + CLS grid): two full chunks and the ragged last tile
-        attend_chunk<3, false>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o, 0);
-        attend_chunk<3, false>(Kl, Vt, qf, 96, p.Ntok, sl2, lane, false, m, l, o, 3);
-        attend_chunk<1, true>(Kl, Vt, qf, 192, p.Ntok, sl2, lane, false, m, l, o, 6);
+        attend_chunk<3, false, VROW>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o, 0);
+        attend_chunk<3, false, VROW>(Kl, Vt, qf, 96, p.Ntok, sl2, lane, false, m, l, o, 3);
+        attend_chunk<1, true, VROW>(Kl, Vt, qf, 192, p.Ntok, sl2, lane, false, m, l, o, 6);
     } else {
-        attend_chunk<3, false>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o, 0);
-        if (p.Ntok > 96) attend_chunk<3, false>(Kl, Vt, qf, 96, p.Ntok, sl2, lane, false, m, l, o, 3);
-        if (p.Ntok > 192) attend_chunk<1, false>(Kl, Vt, qf, 192, p.Ntok, sl2, lane, false, m, l, o, 6);
+        attend_chunk<3, false, VROW>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o, 0);
+        if (p.Ntok > 96) attend_chunk<3, false, VROW>(Kl, Vt, qf, 96, p.Ntok, sl2, lane, false, m, l, o, 3);
+        if (p.Ntok > 192) attend_chunk<1, false, VROW>(Kl, Vt, qf, 192, p.Ntok, sl2, lane, false, m, l, o, 6);
     }
     ATT_TRACE(5);
     if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
@@ -1163,15 +1177,24 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
     if (Ntok <= CH * 32) {
         // whole sequence in one LDS image: eight waves, one query tile each, two workgroups (16 waves) per CU; when only the last key tile is
         // ragged (Ntok > 32 (CH - 1): the 14x14 grid), the variant whose ragged-tile code exists once
-        static bool once = (set_lds(attn_fwd8_kernel<false>, 160 * 1024), set_lds(attn_fwd8_kernel<true>, 160 * 1024), true);
+        static bool once = (set_lds(attn_fwd8_kernel<false, false>, 160 * 1024), set_lds(attn_fwd8_kernel<true, false>, 160 * 1024),
+                            set_lds(attn_fwd8_kernel<false, true>, 160 * 1024), set_lds(attn_fwd8_kernel<true, true>, 160 * 1024), true);
         (void)once;
+        const bool vt = getenv("CS_ATTN_FWD8_VT") != nullptr;          // A/B switch, read per launch: the transposed V image of rounds 1-4
+        const size_t lds8 = vt ? lds : (size_t)2 * CH * 32 * 128 + (size_t)4 * g * 32 * sizeof(float) + lds_pad;
         if (getenv("CS_ATTN_DEBUG")) {
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_fwd8_kernel<true>, 512, lds);
-            fprintf(stderr, "[cs_attn] fwd8: %d resident workgroups per CU (lds %zu)\n", nb, lds);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_fwd8_kernel<true, true>, 512, lds8);
+            fprintf(stderr, "[cs_attn] fwd8: %d resident workgroups per CU (lds %zu)\n", nb, lds8);
         }
-        if (Ntok > (CH - 1) * 32) hipLaunchKernelGGL((attn_fwd8_kernel<true>), dim3(1, B * H), dim3(512), lds, stream, a);
-        else hipLaunchKernelGGL((attn_fwd8_kernel<false>), dim3(1, B * H), dim3(512), lds, stream, a);
+        const bool tail = Ntok > (CH - 1) * 32;
+        if (vt) {
+            if (tail) hipLaunchKernelGGL((attn_fwd8_kernel<true, false>), dim3(1, B * H), dim3(512), lds8, stream, a);
+            else hipLaunchKernelGGL((attn_fwd8_kernel<false, false>), dim3(1, B * H), dim3(512), lds8, stream, a);
+        } else {
+            if (tail) hipLaunchKernelGGL((attn_fwd8_kernel<true, true>), dim3(1, B * H), dim3(512), lds8, stream, a);
+            else hipLaunchKernelGGL((attn_fwd8_kernel<false, true>), dim3(1, B * H), dim3(512), lds8, stream, a);
+        }
     } else {
         static bool once = (set_lds(attn_fwd_kernel<CH>, 160 * 1024), set_lds(attn_fwd2_kernel<CH, 4>, 160 * 1024), true);
         (void)once;
