@@ -496,9 +496,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnArgs p) {
 // exp -> P.V per tile; global loads -> LDS images -> barrier per unit), not by MFMA or VALU throughput: twice the waves per SIMD is
 // what hides them.  Same arithmetic per element as the single-chunk form except that the running maximum of the first chunks rescales
 // the output accumulators (exact when the maximum does not change, one fp32 rounding of alpha * o otherwise).
-// VROW (round 5): V stays row-major in LDS (staged like K, four 16-byte items per thread on all 512 threads) and its transposed fragments come
-// from ds_read_b64_tr_b16 -- no 8 x 8 in-register transposes on 224 of the 512 threads, 16 instead of 32 staging registers; same values into the
-// same MFMAs: bit-identical outputs (CS_ATTN_FWD8_VT=1 runs the transposed-image form, A/B switch).
+// VROW (round 5, CS_ATTN_FWD8_VROW=1; NOT the default -- measured 2 % slower): V stays row-major in LDS (staged like K, four 16-byte items per
+// thread on all 512 threads) and its transposed fragments come from ds_read_b64_tr_b16 -- no 8 x 8 in-register transposes on 224 of the 512
+// threads, 16 instead of 32 staging registers; same values into the same MFMAs: bit-identical outputs.
 template <bool TAIL, bool VROW>
 __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
     constexpr int CH = 7, CHK = CH * 32, NT = 512;
@@ -1180,7 +1180,11 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
         static bool once = (set_lds(attn_fwd8_kernel<false, false>, 160 * 1024), set_lds(attn_fwd8_kernel<true, false>, 160 * 1024),
                             set_lds(attn_fwd8_kernel<false, true>, 160 * 1024), set_lds(attn_fwd8_kernel<true, true>, 160 * 1024), true);
         (void)once;
-        const bool vt = getenv("CS_ATTN_FWD8_VT") != nullptr;          // A/B switch, read per launch: the transposed V image of rounds 1-4
+        // A/B switch, read per launch.  Default: the transposed V image of rounds 1-4.  CS_ATTN_FWD8_VROW=1: V row-major + transposing reads --
+        // bit-identical outputs, measured 2 % SLOWER per 2048-crop launch (811-816 -> 830-831 us, profiles/r05_h_fwd8_row_major_v.txt): the
+        // 8-byte transposing reads double the V fragment instructions of the attend phase and meet 2-way bank conflicts, which costs more than
+        // the in-register transposes of the staging phase save.
+        const bool vt = getenv("CS_ATTN_FWD8_VROW") == nullptr;
         const size_t lds8 = vt ? lds : (size_t)2 * CH * 32 * 128 + (size_t)4 * g * 32 * sizeof(float) + lds_pad;
         if (getenv("CS_ATTN_DEBUG")) {
             int nb = -1;
