@@ -45,6 +45,65 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const __bf16* __restric
     }
 }
 
+// swiglu_bwd + the column sums of its output (the bias gradients of w1 | w2) in one pass: the row-block structure of colsum_bf16_kernel -- a
+// workgroup owns rows_per_block rows x 512 hidden units, four row phases (ty) x 64 lanes of 8 units -- so the partial row it writes is, bit
+// for bit, the one colsum_bf16_kernel would compute from the stored dx12 (same bf16-rounded values, same rows per thread in the same order,
+// same (r0 + r1) + (r2 + r3) combine); colsum_reduce_kernel finishes both halves.  Saves the 103 MB re-read of dx12 per block (round 5).
+__global__ __launch_bounds__(256) void swiglu_bwd_colsum_kernel(const __bf16* __restrict__ dh, long lddh, const __bf16* __restrict__ x12, long ldx,
+                                                                __bf16* __restrict__ dx12, long lddx, float* __restrict__ part, int M, int Hd,
+                                                                int rows_per_block) {
+    __shared__ float red[2][4][512];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = (blockIdx.x * 64 + tx) * 8;                           // first of the thread's 8 hidden units
+    const int m_begin = blockIdx.y * rows_per_block, m_end = min(M, m_begin + rows_per_block);
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (j < Hd) {
+        auto one = [&](const U128& a, const U128& b, const U128& g, int m) {
+            U128 o1, o2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x1 = bf2f(a.e[e]), x2 = bf2f(b.e[e]), d = bf2f(g.e[e]);
+                const float sig = 1.f / (1.f + __expf(-x1));
+                o1.e[e] = f2bf(d * x2 * (sig + x1 * sig * (1.f - sig)));
+                o2.e[e] = f2bf(d * x1 * sig);
+                s1[e] += bf2f(o1.e[e]);
+                s2[e] += bf2f(o2.e[e]);
+            }
+            *(uint4*)(dx12 + (size_t)m * lddx + j) = o1.u;
+            *(uint4*)(dx12 + (size_t)m * lddx + Hd + j) = o2.u;
+        };
+        int m = m_begin + ty;
+        for (; m + 4 < m_end; m += 8) {                                 // two rows = six 16-byte loads in flight per thread
+            U128 a[2], b[2], g[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                a[u].u = *(const uint4*)(x12 + (size_t)(m + 4 * u) * ldx + j);
+                b[u].u = *(const uint4*)(x12 + (size_t)(m + 4 * u) * ldx + Hd + j);
+                g[u].u = *(const uint4*)(dh + (size_t)(m + 4 * u) * lddh + j);
+            }
+            one(a[0], b[0], g[0], m);
+            one(a[1], b[1], g[1], m + 4);
+        }
+        for (; m < m_end; m += 4) {
+            U128 a, b, g;
+            a.u = *(const uint4*)(x12 + (size_t)m * ldx + j);
+            b.u = *(const uint4*)(x12 + (size_t)m * ldx + Hd + j);
+            g.u = *(const uint4*)(dh + (size_t)m * lddh + j);
+            one(a, b, g, m);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][ty][tx * 8 + e] = s1[e]; red[1][ty][tx * 8 + e] = s2[e]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int col = blockIdx.x * 512 + c;
+        if (col < Hd) {
+            part[(size_t)blockIdx.y * 2 * Hd + col] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+            part[(size_t)blockIdx.y * 2 * Hd + Hd + col] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+        }
+    }
+}
+
 // The same with the e4m3 copy of the output row for an fp8 dgrad (cs_gemm_nt_f8): one wave per row; the rounded bf16 outputs stay in
 // registers between the amax reduction and v_cvt_pk_fp8_f32, so q8 / q_scale are bit-identical to cs_quant_rows_fp8(dx12) without its
 // pass over the 2*Hd-wide matrix.  q8 row = [dx1 codes | dx2 codes | zero bytes up to Kp].  IT x 512 >= Hd.
@@ -367,6 +426,21 @@ extern "C" int cs_swiglu_bwd(const void* dh, long lddh, const void* x12, long ld
     CS_LAUNCH_CHECK();
     return 0;
 }
+constexpr int COLSUM_ROWS = 64;          // rows per block: 768 columns x 12608 rows -> 394 workgroups (100 were latency-bound at 0.7 TB/s)
+// cs_swiglu_bwd + colsum[2*Hd] += the column sums of dx12 (bias gradients of w1 | w2), bit-identical to cs_swiglu_bwd followed by
+// cs_colsum_bf16(dx12) (workspace: cs_colsum_workspace(M, 2*Hd) bytes).  Hd % 8 == 0.
+extern "C" int cs_swiglu_bwd_colsum(const void* dh, long lddh, const void* x12, long ldx, void* dx12, long lddx, float* colsum, void* workspace,
+                                    int M, int Hd, hipStream_t stream) {
+    CS_CHECK_ARG(Hd % 8 == 0 && ldx % 8 == 0 && lddh % 8 == 0 && lddx % 8 == 0 && M > 0, "cs_swiglu_bwd_colsum: Hd/ld must be multiples of 8");
+    CS_CHECK_ARG(colsum != nullptr && workspace != nullptr, "cs_swiglu_bwd_colsum: colsum and workspace (cs_colsum_workspace(M, 2*Hd) bytes) are required");
+    const int nblocks = (M + COLSUM_ROWS - 1) / COLSUM_ROWS;
+    hipLaunchKernelGGL(swiglu_bwd_colsum_kernel, dim3((Hd + 511) / 512, nblocks), dim3(256), 0, stream, (const __bf16*)dh, lddh, (const __bf16*)x12, ldx,
+                       (__bf16*)dx12, lddx, (float*)workspace, M, Hd, COLSUM_ROWS);
+    CS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((2 * Hd + 63) / 64), dim3(256), 0, stream, (const float*)workspace, nblocks, 2 * Hd, colsum);
+    CS_LAUNCH_CHECK();
+    return 0;
+}
 // cs_swiglu_bwd + the e4m3 copy of dx12 for an fp8 dgrad: q8 [M, ldq >= Kp = 2*Hd rounded up to 128] bytes, q_scale [M]; bit-identical to
 // cs_quant_rows_fp8(dx12).  Hd <= 4096.
 extern "C" int cs_swiglu_bwd_q8(const void* dh, long lddh, const void* x12, long ldx, void* dx12, long lddx, void* q8, long ldq, float* q_scale,
@@ -422,7 +496,6 @@ extern "C" int cs_transpose_bf16_batched(const void* desc, int count, int total_
     CS_LAUNCH_CHECK();
     return 0;
 }
-constexpr int COLSUM_ROWS = 64;          // rows per block: 768 columns x 12608 rows -> 394 workgroups (100 were latency-bound at 0.7 TB/s)
 extern "C" size_t cs_colsum_workspace(int M, int N) {
     return (size_t)((M + COLSUM_ROWS - 1) / COLSUM_ROWS) * (size_t)(N > 0 ? N : 0) * sizeof(float);
 }

@@ -29,6 +29,7 @@ backward -- against the monolithic autograd oracle without a GPU.  The product n
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -183,6 +184,9 @@ class EvaEngine:
         # CLIPSelf.prefetch_teacher in data-parallel runs, where those blocks run beside the student's gradient all-reduce
         self.rccl_window = (0, 0)
         self.wgrad_tn = True                   # weight gradients from the token-major operands (no transposed copies) where the shape allows
+        # the SwiGLU backward also reduces its output's columns (the w1 | w2 bias gradients): bit-identical to the separate colsum pass
+        # (A/B switch CLIPSELF_NO_FUSED_SWIGLU_COLSUM=1)
+        self.fused_swiglu_colsum = os.environ.get("CLIPSELF_NO_FUSED_SWIGLU_COLSUM") != "1"
         if trainable:
             self.grad = ops.zeros((self.numel,), F32)
             self.exp_avg = ops.zeros((self.numel,), F32)
@@ -870,14 +874,17 @@ class EvaEngine:
         ops.layernorm_bwd(d_fln[:, :Hl], s["hid"][:, :Hl], self.p[b + "mlp.ffn_ln.weight"], *s["st4"], d_hid[:, :Hl], DX_BF16,
                           G[b + "mlp.ffn_ln.weight"], G[b + "mlp.ffn_ln.bias"], True, ws[0])
         d_x12 = ops.empty((M, 2 * Hd), BF16)
+        ob = self.offsets[b + "mlp.w1.bias"][0]
         q12 = None
         if self.fp8_dgrad and Hd <= 4096:
             q12 = (ops.empty((M, _round_up(2 * Hd, 128)), torch.uint8), ops.empty((M,), F32))
             ops.swiglu_bwd(d_hid, s["x12"], d_x12, q8=q12[0], q_scale=q12[1])
+            ops.colsum_bf16(d_x12, self.grad[ob:ob + 2 * Hd], ws[1])
+        elif self.fused_swiglu_colsum:
+            ops.swiglu_bwd_colsum(d_hid, s["x12"], d_x12, self.grad[ob:ob + 2 * Hd], ws[1])      # d x1|x2 and the w1 | w2 bias gradients in one pass
         else:
             ops.swiglu_bwd(d_hid, s["x12"], d_x12)
-        ob = self.offsets[b + "mlp.w1.bias"][0]
-        ops.colsum_bf16(d_x12, self.grad[ob:ob + 2 * Hd], ws[1])
+            ops.colsum_bf16(d_x12, self.grad[ob:ob + 2 * Hd], ws[1])
         ow = self.offsets[b + "mlp.w1.weight"][0]
         self._wgrad(d_x12, s["ln2"], self.grad[ow:ow + 2 * Hd * C].view(2 * Hd, C))
         d_ln2 = ops.empty((M, C), BF16)

@@ -54,6 +54,7 @@ SIGNATURES = {
     "cs_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "cs_swiglu_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _vp]),
     "cs_swiglu_bwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _vp]),
+    "cs_swiglu_bwd_colsum": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _vp]),
     "cs_swiglu_bwd_q8": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _i, _i, _vp]),
     "cs_gelu_fwd": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp]),
     "cs_gelu_bwd": (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _i, _vp]),
@@ -439,6 +440,15 @@ class HipOps:
         assert q_scale is not None and q8.element_size() == 1 and q8.stride(1) == 1 and q8.shape[1] >= (2 * Hd + 127) // 128 * 128
         self._ok(self.lib.cs_swiglu_bwd_q8(_p(dh), dh.stride(0), _p(x12), x12.stride(0), _p(dx12), dx12.stride(0), _p(q8), q8.stride(0),
                                            _p(q_scale), M, Hd, self._stream()), "cs_swiglu_bwd_q8")
+
+    def swiglu_bwd_colsum(self, dh, x12, dx12, colsum, workspace):
+        """swiglu_bwd + colsum[2*Hd] += column sums of dx12 (the w1 | w2 bias gradients) in the same pass; = swiglu_bwd, colsum_bf16(dx12)."""
+        self._chk(dh, x12, dx12, colsum, workspace)
+        M, Hd = dh.shape
+        assert colsum.dtype == torch.float32 and colsum.numel() >= 2 * Hd and colsum.is_contiguous()
+        assert workspace.numel() * workspace.element_size() >= self.colsum_workspace(M, 2 * Hd)
+        self._ok(self.lib.cs_swiglu_bwd_colsum(_p(dh), dh.stride(0), _p(x12), x12.stride(0), _p(dx12), dx12.stride(0), _p(colsum), _p(workspace),
+                                               M, Hd, self._stream()), "cs_swiglu_bwd_colsum")
 
     def swiglu_bwd(self, dh, x12, dx12, q8=None, q_scale=None):
         if q8 is not None:

@@ -156,6 +156,10 @@ int cs_attn_bwd(const void* qkv, const void* o, const void* dout, const float* l
 /* --- SwiGLU elementwise: eva_vit_model.py:101  hidden = silu(x1) * x2   (x12 = [x1 | x2], each Hd wide) */
 int cs_swiglu_fwd(const void* x12, long ldx, void* h, long ldh, int M, int Hd, cs_stream_t stream);
 int cs_swiglu_bwd(const void* dh, long lddh, const void* x12, long ldx, void* dx12, long lddx, int M, int Hd, cs_stream_t stream);
+/* the same + colsum[2*Hd] += the column sums of dx12 = the bias gradients of w1 | w2 (autograd of F.linear's bias at eva_vit_model.py:99-100),
+   bit-identical to cs_swiglu_bwd followed by cs_colsum_bf16(dx12) without its pass over the matrix; workspace >= cs_colsum_workspace(M, 2*Hd) */
+int cs_swiglu_bwd_colsum(const void* dh, long lddh, const void* x12, long ldx, void* dx12, long lddx, float* colsum, void* workspace,
+                         int M, int Hd, cs_stream_t stream);
 /* the same + the e4m3 copy of dx12 (row-wise amax / 448 scales, bytes [dx1 | dx2 | zero padding to a multiple of 128]) for an fp8 dgrad through
    cs_gemm_nt_f8 -- bit-identical to cs_quant_rows_fp8(dx12), without its pass over the matrix; Hd <= 4096 */
 int cs_swiglu_bwd_q8(const void* dh, long lddh, const void* x12, long ldx, void* dx12, long lddx, void* q8, long ldq, float* q_scale,

@@ -385,6 +385,10 @@ class RefOps:
         if q8 is not None:                       # cs_swiglu_bwd_q8: = quant_rows_fp8 of the rounded output
             self.quant_rows_fp8(dx12[:, :2 * Hd], q8[:, :(2 * Hd + 127) // 128 * 128], q_scale)
 
+    def swiglu_bwd_colsum(self, dh, x12, dx12, colsum, workspace=None):
+        self.swiglu_bwd(dh, x12, dx12)
+        self.colsum_bf16(dx12[:, :2 * dh.shape[1]], colsum[:2 * dh.shape[1]])
+
     def swiglu_bwd_q8(self, dh, x12, dx12, q8, q_scale):
         self.swiglu_bwd(dh, x12, dx12, q8, q_scale)
 
