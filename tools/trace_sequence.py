@@ -25,11 +25,14 @@ def main():
     out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
     wall, busy = (step[-1][2] - t0) / 1e6, sum(r[2] - r[1] for r in step) / 1e6
     out.write(f"# last full step: {len(step)} kernels, wall {wall:.2f} ms, kernel time {busy:.2f} ms\n")
-    # phases by marker kernels: teacher = up to the last attn_cls launch; backward starts at the first backward-only kernel
-    cls = max((i for i, r in enumerate(step) if "attn_cls" in r[0]), default=-1)
+    # phases by marker kernels (inline schedule: CLIPSelf.__call__ runs the student's forward, then the teacher, then the loss): the step's two
+    # im2row launches open the student's and the teacher's forward; the backward starts at the first backward-only kernel
+    stems = [i for i, r in enumerate(step) if "im2row" in r[0]]
     bwd = next((i for i, r in enumerate(step) if "cosine_bwd" in r[0] or "l2norm_bwd" in r[0]), len(step))
-    teacher_end = next((i for i in range(cls + 1, len(step)) if "im2row" in step[i][0]), cls + 1) if cls >= 0 else 0
-    phases = (("teacher", 0, teacher_end), ("student forward + loss", teacher_end, bwd), ("student backward + AdamW", bwd, len(step)))
+    if len(stems) >= 2 and stems[1] < bwd:
+        phases = (("student forward", 0, stems[1]), ("teacher + loss", stems[1], bwd), ("student backward + AdamW", bwd, len(step)))
+    else:                                   # overlapped schedule / unknown order: forward part and backward part only
+        phases = (("forward (both towers) + loss", 0, bwd), ("student backward + AdamW", bwd, len(step)))
     for name, a, b in phases:
         if b <= a:
             continue
