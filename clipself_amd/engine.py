@@ -718,7 +718,8 @@ class EvaEngine:
             ratio = self.block_fold_statistic()
             try:
                 import torch.distributed as dist
-                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # (CLIPSELF_FORCE_DIST=1: the one-rank rehearsal of the N-rank path takes the collective too -- the only way to run this RCCL call on a one-GPU box)
+                if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("CLIPSELF_FORCE_DIST") == "1"):
                     t = torch.tensor([ratio], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     ratio = float(t[0])
