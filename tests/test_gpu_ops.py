@@ -299,7 +299,8 @@ def _rope(Ntok, seed):
     return rope_tables(g, 64)
 
 
-@pytest.mark.parametrize("B,Ntok,H,qscale", [(2, 197, 12, 1.0), (3, 17, 2, 3.0), (2, 65, 2, 2.0), (1, 577, 3, 1.5), (2, 197, 2, 6.0)])
+@pytest.mark.parametrize("B,Ntok,H,qscale", [(2, 197, 12, 1.0), (3, 17, 2, 3.0), (2, 65, 2, 2.0), (1, 577, 3, 1.5), (2, 197, 2, 6.0), (2, 226, 2, 1.0), (1, 257, 3, 2.0),
+                                              (1, 401, 2, 1.0)])      # 226 / 257 / 401: one key / 33 keys / a ragged chunk past the first 224-key image (multiscale grids)
 def test_attention_fwd_bwd(hip, ref, B, Ntok, H, qscale):
     C = H * 64
     qkv = rnd((B * Ntok, 3 * C), F32, 1.0, seed=30)
@@ -332,7 +333,8 @@ def test_attention_fwd_bwd(hip, ref, B, Ntok, H, qscale):
     check(tag + ".dv", dq_d[:, 2 * C:], dq_r[:, 2 * C:], 1.5e-2)
 
 
-@pytest.mark.parametrize("B,Ntok,H,qscale", [(9, 197, 12, 1.0), (3, 17, 2, 3.0), (2, 65, 2, 2.0), (2, 577, 3, 1.5), (1, 785, 2, 4.0), (2, 4097, 3, 1.0)])
+@pytest.mark.parametrize("B,Ntok,H,qscale", [(9, 197, 12, 1.0), (3, 17, 2, 3.0), (2, 65, 2, 2.0), (2, 577, 3, 1.5), (1, 785, 2, 4.0), (2, 4097, 3, 1.0),
+                                              (2, 226, 2, 1.0), (1, 257, 3, 2.0), (1, 401, 2, 1.0)])
 def test_attention_bwd_restaged_kernels_against_the_round1_kernels(hip, B, Ntok, H, qscale):
     """Round 5 re-staged the attention backward (all rows of a chunk requested up front, next chunk prefetched into registers, RoPE from the
     LDS tables, K^T / Q^T / dO^T read from the row-major images with ds_read_b64_tr_b16): the same products in the same order -- the first
