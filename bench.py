@@ -271,6 +271,58 @@ def measure_traffic_live(chunk_crops, timeout_s=150):
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, rec
 
 
+ALSO_WORKLOADS = ("recipe_b16", "recipe_l14", "cfg3", "cfg4_bf16", "cfg4_fp8")
+# one-GPU step time the multi-GPU expectation is built on (ms; the driver's BENCH_r05 run of this workload) -- refreshed at the end of a round
+ONE_GPU_MS_REFERENCE = 87.3
+
+
+def also_workloads(steps=8, timeout_s=240):
+    """The configurations beside the headline one, driver-observed: the reference's own recipe shape for both towers,
+    BASELINE configs[3] and configs[4] (bf16 and fp8) at one GPU's share, a few steps each in a process of their own
+    (tools/also_bench.py) after the timed region.  A workload that fails or times out is reported as such; the headline fields are not touched."""
+    import subprocess
+    res = []
+    for w in ALSO_WORKLOADS:
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, str(ROOT / "tools" / "also_bench.py"), w, str(steps)], capture_output=True, text=True, timeout=timeout_s)
+            line = next((ln for ln in reversed(r.stdout.strip().splitlines()) if ln.startswith("{")), None)
+            rec = json.loads(line) if line else {"id": w, "error": (r.stderr or "no output")[-300:]}
+        except subprocess.TimeoutExpired:
+            rec = {"id": w, "error": f"exceeded {timeout_s}s"}
+        except (OSError, ValueError) as e:
+            rec = {"id": w, "error": str(e)[-300:]}
+        rec["wall_s"] = round(time.time() - t0, 1)
+        res.append(rec)
+    return res
+
+
+def expected_data_parallel(world, cfg_blocks=12, bucket_mb=28.3, one_gpu_ms=ONE_GPU_MS_REFERENCE, backward_ms=10.0, link_gbs_dir=76.0,
+                           links=7, reserve_ms=1.3):
+    """What a `--gpus N` line should show if the data-parallel path works as designed (DESIGN.md section 5's table as a function of N), printed
+    beside the measured `data_parallel` fields so that the first multi-GPU line judges itself.  One node, xGMI fully connected: ~153 GB/s per
+    link = ~76 GB/s per direction; ring all-reduce puts 2 (N-1)/N of a bucket on a rank's links; RCCL may spread its rings over min(N-1, 7)
+    links (best case) or run one ring (worst case); ring latency ~ 2 (N-1) steps x ~10 us."""
+    n = max(world, 1)
+    per_bucket_link_mb = 2.0 * (n - 1) / n * bucket_mb
+    lat_ms = 2 * (n - 1) * 0.010
+    worst = per_bucket_link_mb / link_gbs_dir + lat_ms                 # MB / (GB/s) = ms
+    best = per_bucket_link_mb / (link_gbs_dir * max(1, min(n - 1, links))) + lat_ms
+    spacing = backward_ms / cfg_blocks
+    step_lo, step_hi = one_gpu_ms + best + (reserve_ms if n > 1 else 0.0), one_gpu_ms + worst + (reserve_ms if n > 1 else 0.0)
+    return {"allreduce_mb_per_step": round(cfg_blocks * bucket_mb, 1), "buckets_per_step": cfg_blocks,
+            "mb_on_a_ranks_links_per_bucket": round(per_bucket_link_mb, 1),
+            "bucket_issue_to_done_ms": [round(best, 2), round(worst, 2)], "bucket_issue_spacing_ms": round(spacing, 2),
+            "buckets_queue_behind_each_other": bool(worst > spacing),
+            "grad_sync_wait_ms": [round(best, 2), round(worst, 2)], "reserve_cost_ms": reserve_ms if n > 1 else 0.0,
+            "ms_per_step": [round(step_lo, 1), round(step_hi, 1)],
+            "images_per_s": [round(n * BATCH / step_hi * 1e3), round(n * BATCH / step_lo * 1e3)],
+            "speedup_over_one_gpu": [round(n * one_gpu_ms / step_hi, 2), round(n * one_gpu_ms / step_lo, 2)],
+            "one_gpu_ms_reference": one_gpu_ms,
+            "reading": "bucket_issue_to_done_ms >> the range: RCCL's kernels are starved behind the persistent GEMMs -> raise CLIPSELF_RCCL_CUS; "
+                       "growing from bucket to bucket: the links are the limit -> --bf16-grad-buckets halves the bytes"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,6 +332,10 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="report roofline.traffic from the tracked PMC summary (profiles/pmc_traffic.json) instead of two rocprofv3 counter passes "
                          "after the timed region (also: CLIPSELF_BENCH_NO_PMC=1)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the short runs of the other configurations (recipe shape, configs[3], configs[4]) that follow the timed region "
+                         "(the `also` key; also: CLIPSELF_BENCH_NO_ALSO=1)")
+    ap.add_argument("--also-steps", type=int, default=8)
     ap.add_argument("--teacher-chunk", type=int, default=2048,
                     help="crops per teacher launch; 2048 = the whole batch of configs[1] in one pass (~7 GB of live activations)")
     ap.add_argument("--full-last-block", action="store_true",
@@ -454,6 +510,15 @@ def main():
             # data-parallel diagnostics: bytes each rank hands to the all-reduce per step (a ring moves 2 (N-1)/N of them over every
             # xGMI link), buckets, the exposed wait in front of AdamW, CUs the persistent GEMMs leave to RCCL's kernels
             out["data_parallel"] = comm
+            out["data_parallel"]["expected"] = expected_data_parallel(world, cfg_blocks=cfg.layers)
+        if world == 1 and not a.no_also and not a.no_cpu_baseline and os.environ.get("CLIPSELF_BENCH_NO_ALSO") != "1":      # (quick --no-cpu-baseline runs skip it, like the PMC passes)
+            # free this process's towers and activations first: the other workloads get the device to themselves
+            del timer, model, dist_model, student, teacher, opt, batches, method, last
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            out["also"] = also_workloads(a.also_steps)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

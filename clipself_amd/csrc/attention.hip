@@ -892,6 +892,14 @@ __global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnA
             // zeros in the image (ZPAD), so their dS columns meet a zero K^T column.
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(fmaf(s[e], sl2, -lse2)) * fmaf(dp[e], p.scale, -dq_sum_s);
+            // ... but 0 * inf is NaN: a padding key's score is 0, so its "probability" is exp2(-lse2), which overflows for a query whose
+            // scaled scores are all below ~ -88 (lse < -88) and would poison the whole dQ row.  Only the sequence's ragged last tile holds
+            // padding keys (wave-uniform branch, as in attend_chunk): their dS is set to 0 there.
+            if (key0 + t * 32 + 32 > p.Ntok) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (key0 + t * 32 + mfma32_row(e, lane) >= p.Ntok) s[e] = 0.f;
+            }
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
                 const bf16x8 db = pack8(s, c2);
@@ -1252,9 +1260,10 @@ extern "C" int cs_attn_bwd(const void* qkv, const void* o, const void* dout, con
     constexpr int CH = 7;
     constexpr int CHK = CH * 32, VLD = CHK + 4;
     const int g = (int)(sqrtf((float)(Ntok - 1)) + 0.5f);
-    const bool v1 = getenv("CS_ATTN_BWD_V1") != nullptr;                 // A/B switch, read per launch: the round-1 kernels (transposed images, global RoPE tables)
+    // the round-1 kernels (transposed images, RoPE from the full global tables): the A/B switch, read per launch -- and the form that serves a
+    // token count that is not a square grid + 1 (the re-staged kernels read the tables separably, row part | column part)
+    const bool v1 = getenv("CS_ATTN_BWD_V1") != nullptr || g * g != Ntok - 1;
     if (!v1) {
-        CS_CHECK_ARG(g * g == Ntok - 1, "cs_attn_bwd: Ntok - 1 = %d is not a square token grid (the RoPE tables are read separably, as in cs_attn_fwd)", Ntok - 1);
         a.grid = g; a.inv_grid = 1.f / (float)g;
         const size_t rope = (size_t)4 * g * 32 * sizeof(float);
         const size_t lds_dq = (size_t)2 * CHK * 128 + rope, lds_dkv = (size_t)2 * CHK * 128 + (size_t)2 * CHK * sizeof(float) + rope;

@@ -673,22 +673,37 @@ class EvaEngine:
         return self._block_post(i, b, xc, att, B, lambda: (None, None), None, True)
 
     # ------------------------------------------------------------------------------------------ teacher
-    def fold_probe(self, crops: int = 16):
-        """The crops the guard is calibrated on: seeded N(0, 1) images at the tower's native size (numpy PCG64, version-stable) -- the same
-        on every rank, in every run and whatever the first batch holds, so that all ranks of a data-parallel job choose the same teacher
-        schedule and two runs of one checkpoint produce the same distillation targets.  (The statistic is a property of the weights --
-        massive-activation channels, bias-driven row means -- far more than of the pixels; oracle/stress_weights.py builds it from them.)"""
+    def fold_probe(self, crops: int = 16, kind: str = "white"):
+        """The crops the guard is calibrated on, seeded (numpy PCG64, version-stable) at the tower's native size -- the same on every rank, in
+        every run and whatever the first batch holds, so that all ranks of a data-parallel job choose the same teacher schedule and two runs of
+        one checkpoint produce the same distillation targets.  (The statistic is a property of the weights -- massive-activation channels,
+        bias-driven row means -- far more than of the pixels; oracle/stress_weights.py builds it from them.)  Two kinds (white
+        noise alone can under-estimate a common-mode row mean that real crops excite): "white" = N(0, 1) pixels; "natural" = what
+        normalised photographs look like to a patch embedding -- a 1/f amplitude spectrum (smooth regions, few edges) around a per-image,
+        per-channel mean of N(0, 1), i.e. crops that are mostly one colour.  The guard takes the larger statistic of the two."""
         import numpy as np
         S = self.cfg.image_size
-        g = np.random.Generator(np.random.PCG64(20250927))
-        return torch.from_numpy(g.standard_normal((crops, 3, S, S), dtype=np.float32)).to(self.device)
+        g = np.random.Generator(np.random.PCG64(20250927 if kind == "white" else 20251001))
+        x = g.standard_normal((crops, 3, S, S), dtype=np.float32)
+        if kind == "natural":
+            f = np.hypot(np.fft.fftfreq(S)[:, None], np.fft.rfftfreq(S)[None, :]).astype(np.float32)
+            f[0, 0] = 1.0
+            x = np.fft.irfft2(np.fft.rfft2(x) / f, s=(S, S)).astype(np.float32)
+            x -= x.mean(axis=(2, 3), keepdims=True)
+            x /= x.std(axis=(2, 3), keepdims=True) + 1e-6
+            x = 0.5 * x + g.standard_normal((crops, 3, 1, 1), dtype=np.float32)
+        elif kind != "white":
+            raise ValueError(kind)
+        return torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
 
     def block_fold_statistic(self, images=None, crops: int = 16):
         """max over blocks of mean over rows of |row mean| / row sigma of the residual stream entering the block, on `images[:crops]`
-        (default: fold_probe()) through the plain block schedule.  One-time calibration after a weight load (a few torch reductions and
-        one host read-back, not part of the step)."""
+        (default: the larger of the two fold_probe() kinds) through the plain block schedule.  One-time calibration after a weight load (a
+        few torch reductions and one host read-back per probe, not part of the step)."""
+        if images is None:
+            return max(self.block_fold_statistic(self.fold_probe(crops, kind), crops) for kind in ("white", "natural"))
         with torch.no_grad():
-            img = self.fold_probe(crops) if images is None else images[:crops]
+            img = images[:crops]
             B = img.shape[0]
             x, g = self._stem(img)
             N = g * g + 1
@@ -701,12 +716,45 @@ class EvaEngine:
                     self._block_fwd(i, xf, B, N, cos, sin, True, None, True)
             return float(worst)
 
+    @staticmethod
+    def _fold_group_active() -> bool:
+        import torch.distributed as dist
+        # (CLIPSELF_FORCE_DIST=1: the one-rank rehearsal of the N-rank path takes the collective too -- the only way to run this RCCL call on a one-GPU box)
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("CLIPSELF_FORCE_DIST") == "1")
+
+    def calibrate_block_folds(self, collective: bool = True) -> bool:
+        """Measure the guard's statistic of the current weights on the seeded probes and decide whether norm1 / norm2 are folded.  In a process
+        group (collective=True) every rank takes the MAX over ranks -- one scalar all-reduce --, so the ranks cannot disagree even if their
+        devices rounded differently.  That makes this a COLLECTIVE call: every rank must reach it at the same point of the program --
+        training.main does right after a frozen tower's weights are in place (FrozenDataParallel.__init__, and after the evaluation model's
+        load_state_dict), never from inside a forward pass that some rank might skip (an empty evaluation shard used to hang the
+        job there).  An error of the collective is an error of the job and propagates.  The statistic and the decision are logged once per
+        calibration."""
+        import logging
+        ratio = self.block_fold_statistic()
+        agreed = ""
+        if collective and self._fold_group_active():
+            import torch.distributed as dist
+            t = torch.tensor([ratio], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ratio = float(t[0])
+            agreed = f", MAX over {dist.get_world_size()} ranks"
+        self.block_fold_ratio = ratio
+        folded = ratio <= self.block_fold_limit
+        near = abs(ratio - self.block_fold_limit) <= 0.1 * self.block_fold_limit
+        logging.log(logging.WARNING if (near or not folded) else logging.INFO,
+                    "frozen tower: mean |row mean| / row sigma of the residual stream = %.3f on the seeded probes%s (limit %.1f%s) -- norm1 / norm2 %s",
+                    ratio, agreed, self.block_fold_limit, ", within 10 % of it" if near else "",
+                    "folded into the q|k|v and W1|W2 GEMMs" if folded else
+                    "stay LayerNorm kernels (the folded form would lose precision on these weights)")
+        return folded
+
     def block_folds_active(self, images=None) -> bool:
         """Whether encode_image() folds norm1 / norm2 into the q|k|v and W1|W2 GEMMs: the switch, and -- with the guard armed -- the
-        calibration of the current weights, measured on the fixed probe the first time a caller with data in hand asks (`images` only says
-        that the tower is about to run; its content does not enter the decision).  In a process group every rank takes the MAX over ranks
-        (one scalar all-reduce per weight load), so the ranks cannot disagree even if their devices rounded differently.  The statistic and
-        the decision are logged once per weight load."""
+        calibration of the current weights (calibrate_block_folds).  A caller with data in hand (`images` only says that the tower is about
+        to run; its content does not enter the decision) that finds the weights uncalibrated calibrates them on the spot WITHOUT the
+        collective: the probes are seeded, so ranks holding the same weights compute the same statistic up to device rounding; a job that
+        wants the agreed value calls calibrate_block_folds() at a point every rank reaches (a warning says so in a multi-rank group)."""
         if not self.fold_block_ln:
             return False
         if not self.block_fold_guard:
@@ -714,25 +762,11 @@ class EvaEngine:
         if self.block_fold_ratio is None:
             if images is None:
                 return True
-            import logging
-            ratio = self.block_fold_statistic()
-            try:
-                import torch.distributed as dist
-                # (CLIPSELF_FORCE_DIST=1: the one-rank rehearsal of the N-rank path takes the collective too -- the only way to run this RCCL call on a one-GPU box)
-                if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("CLIPSELF_FORCE_DIST") == "1"):
-                    t = torch.tensor([ratio], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    ratio = float(t[0])
-            except (RuntimeError, ValueError):                      # no usable process group: the local value stands
-                pass
-            self.block_fold_ratio = ratio
-            folded = ratio <= self.block_fold_limit
-            near = abs(ratio - self.block_fold_limit) <= 0.1 * self.block_fold_limit
-            logging.log(logging.WARNING if (near or not folded) else logging.INFO,
-                        "frozen tower: mean |row mean| / row sigma of the residual stream = %.3f on the seeded probe (limit %.1f%s) -- norm1 / norm2 %s",
-                        ratio, self.block_fold_limit, ", within 10 % of it" if near else "",
-                        "folded into the q|k|v and W1|W2 GEMMs" if folded else
-                        "stay LayerNorm kernels (the folded form would lose precision on these weights)")
+            if self._fold_group_active():
+                import logging
+                logging.warning("frozen tower: fold guard calibrated lazily inside a forward pass of a multi-rank job -- local value, no rank "
+                                "agreement; call engine.calibrate_block_folds() on every rank after the weight load")
+            self.calibrate_block_folds(collective=False)
         return self.block_fold_ratio <= self.block_fold_limit
 
     def _rccl_window_step(self, i, k0):

@@ -145,7 +145,11 @@ class HipOps:
         n = self._rccl_reserve + self._share
         if self._cap:
             n = max(n, self.num_cus - self._cap)
-        assert 0 <= n <= self.num_cus - 8 and n < 256, f"persistent GEMM grids keep at least 8 workgroups (asked to leave {n} of {self.num_cus} CUs free)"
+        # a ValueError, not an assert (python -O), and at the call that asked for it: the field of the GEMM flags has 8 bits, and a
+        # persistent grid keeps at least 8 workgroups (one per XCD)
+        if not (0 <= n <= self.num_cus - 8 and n < 256):
+            raise ValueError(f"persistent GEMM grids keep at least 8 workgroups and can leave at most 255 compute units free "
+                             f"(asked to leave {n} of {self.num_cus} CUs: RCCL reserve {self._rccl_reserve}, tower share {self._share}, cap {self._cap})")
         self.gemm_flags = (self.gemm_flags & ~(255 << 20)) | (int(n) << 20)
 
     def reserve_compute_units(self, n: int):

@@ -75,12 +75,31 @@ class CLIPSelf:
         # workgroups of the student's persistent GEMMs meanwhile (default: its share; CLIPSELF_PARTITION_CAP)
         cap = os.environ.get("CLIPSELF_PARTITION_CAP") if partition_cap is None else partition_cap
         self.partition_cap = int(cap) if cap not in (None, "") else self.partition_cus
+        # what can be checked without a device is checked here, the rest (against the device's CU count) when the towers' ops are first seen
+        if self.partition_cus < 0 or (self.partition_cus and (self.partition_cus < 8 or self.partition_cap < 8)):
+            raise ValueError(f"CLIPSELF_PARTITION_CUS / _CAP = {self.partition_cus} / {self.partition_cap}: a tower's share is 0 (off) or at least 8 compute units")
+        if self.partition_mask and self.partition_cus % 8:
+            raise ValueError(f"CLIPSELF_PARTITION_MASK=1 needs a share that is a multiple of 8 compute units (one slice per XCD), got {self.partition_cus}")
+        self._partition_checked = self.partition_cus == 0
         self._student_ops = None
         self._student_stream = None
+
+    def _check_partition(self, ops):
+        """The device-dependent half of the constructor's checks, once, before the first reservation is made (not an assert in
+        the middle of a step): both towers keep >= 8 workgroups and the reservation fits the 8-bit field of the GEMM flags."""
+        if self._partition_checked or ops is None or not hasattr(ops, "num_compute_units"):
+            return
+        n = ops.num_compute_units()
+        if not (8 <= self.partition_cus <= min(n - 8, 255)) or not (8 <= self.partition_cap <= n) or n - self.partition_cap > 255:
+            raise ValueError(f"tower partition {self.partition_cus} CUs (cap {self.partition_cap}) does not fit a device of {n} compute units: "
+                             f"share in [8, {min(n - 8, 255)}], cap in [{max(8, n - 255)}, {n}]")
+        self._partition_checked = True
 
     def _cap_student(self, on: bool):
         ops = self._student_ops
         if ops is not None and hasattr(ops, "cap_compute_units"):
+            if on:
+                self._check_partition(ops)
             ops.cap_compute_units(self.partition_cap if on else 0)
 
     def student_stream(self, ops):
@@ -120,6 +139,8 @@ class CLIPSelf:
         eng = getattr(getattr(dist_model, "visual", None), "engine", None)
         tops = getattr(eng, "ops", None)
         share = self.partition_cus if hasattr(tops, "share_compute_units") else 0
+        if share:
+            self._check_partition(tops)
         if self._side is None:
             if share and self.partition_mask:
                 self._side = tops.stream_create_cu_mask(0, tops.num_compute_units() - share)      # the teacher's CUs, enforced by the dispatcher

@@ -256,6 +256,9 @@ class FrozenDataParallel(torch.nn.Module):
         self.module = module
         dist.broadcast(module.visual.engine.master, src=0, group=process_group)
         module.visual.engine.sync_shadow()
+        # the frozen schedule's fold guard is decided HERE, where every rank is (a MAX all-reduce of one scalar), not inside the first forward
+        if hasattr(module.visual.engine, "calibrate_block_folds") and module.visual.engine.block_fold_guard and module.visual.engine.fold_block_ln:
+            module.visual.engine.calibrate_block_folds()
         self.prefetch_window = (rccl_teacher_window(), rccl_reserved_cus()) if _data_parallel_active() else (0, 0)
 
     def forward(self, *a, **k):

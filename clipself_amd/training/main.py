@@ -50,6 +50,13 @@ def build_scheduler(optimizer, args, num_batches):
     raise ValueError(f"Unknown scheduler, {args.lr_scheduler}. Available options are: cosine, const, const-cooldown.")
 
 
+def _calibrate_frozen(m):
+    """Frozen-schedule fold guard of a tower whose weights were just loaded (EvaEngine.calibrate_block_folds: collective in a process group)."""
+    eng = getattr(getattr(m, "visual", None), "engine", None)
+    if eng is not None and getattr(eng, "block_fold_guard", False) and getattr(eng, "fold_block_ln", False):
+        eng.calibrate_block_folds()
+
+
 def main(argv):
     args = parse_args(argv)
     device = init_distributed_device(args)
@@ -164,6 +171,7 @@ def main(argv):
             test_model = create_model(args.model, args.pretrained, device=device, precision=args.precision, cache_dir=None,
                                       trainable=False)
             test_model.load_state_dict(target_sd)
+            _calibrate_frozen(test_model)                       # every rank is here: the fold guard's collective belongs here, not inside evaluate()
             evaluate(test_model, data, completed_epoch, args)
             del test_model
         if is_master(args):

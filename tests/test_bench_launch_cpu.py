@@ -29,3 +29,21 @@ def test_single_process_default_and_world_mismatch():
     bad = _run(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "4", "RANK": "0"})
     assert bad.returncode != 0 and "WORLD_SIZE=4" in bad.stderr
     assert _run(["--gpus", "0"]).returncode != 0
+
+
+def test_expected_data_parallel_fields_follow_the_design_table():
+    """DESIGN.md section 5's prediction table as a function of the world size (bench.py attaches it to `data_parallel` so that the first multi-GPU
+    line is self-judging): 8 ranks -> 12 buckets of 28.3 MB, 49.5 MB per bucket on a rank's links, 0.2-0.8 ms per bucket, no queueing behind
+    the 0.83 ms issue spacing, >= 7.8 x one GPU; one rank -> nothing on the links."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    e8 = bench.expected_data_parallel(8)
+    assert e8["buckets_per_step"] == 12 and abs(e8["allreduce_mb_per_step"] - 339.6) < 0.5 and abs(e8["mb_on_a_ranks_links_per_bucket"] - 49.5) < 0.1
+    lo, hi = e8["bucket_issue_to_done_ms"]
+    assert 0.15 < lo < 0.3 and 0.6 < hi < 0.9 and not e8["buckets_queue_behind_each_other"]
+    assert 7.5 < e8["speedup_over_one_gpu"][0] <= e8["speedup_over_one_gpu"][1] < 8.0
+    assert e8["images_per_s"][0] == round(8 * 64 / e8["ms_per_step"][1] * 1e3) or abs(e8["images_per_s"][0] - 8 * 64 / e8["ms_per_step"][1] * 1e3) < 10
+    e1 = bench.expected_data_parallel(1)
+    assert e1["mb_on_a_ranks_links_per_bucket"] == 0.0 and e1["reserve_cost_ms"] == 0.0 and e1["speedup_over_one_gpu"] == [1.0, 1.0]
+    e2, e4 = bench.expected_data_parallel(2), bench.expected_data_parallel(4)
+    assert e2["speedup_over_one_gpu"][0] > 1.9 and e4["speedup_over_one_gpu"][0] > 3.8

@@ -96,5 +96,32 @@ def test_compute_unit_reservations_compose():
     ops.cap_compute_units(0)
     assert ops.persistent_grid() == 240
     ops.reserve_compute_units(0)
-    with pytest.raises(AssertionError):
+    with pytest.raises(ValueError):
         ops.cap_compute_units(4)                     # fewer than 8 workgroups: cs_persistent_cap() would ignore it
+    ops._cap = 0
+    ops.num_cus = 304                                # a 304-CU part (MI300X): the flags field has 8 bits
+    ops.cap_compute_units(56)                        # would leave 248 CUs free: encodable
+    assert ops.persistent_grid() == 56
+    with pytest.raises(ValueError):
+        ops.cap_compute_units(48)                    # would leave 256: not encodable -- a ValueError at the call, not an assert inside a step
+
+
+def test_tower_partition_arguments_are_validated_at_construction(monkeypatch):
+    """bad CLIPSELF_PARTITION_* values surface when the method is built (or when the device's CU count is first known), as ValueError."""
+    from types import SimpleNamespace
+    from clipself_amd.training.clipself import CLIPSelf
+    CLIPSelf()                                       # off by default
+    CLIPSelf(partition_cus=48)
+    for kw in (dict(partition_cus=4), dict(partition_cus=-8), dict(partition_cus=44, partition_mask=True), dict(partition_cus=48, partition_cap=4)):
+        with pytest.raises(ValueError):
+            CLIPSelf(**kw)
+    monkeypatch.setenv("CLIPSELF_PARTITION_CUS", "5")
+    with pytest.raises(ValueError):
+        CLIPSelf()
+    monkeypatch.delenv("CLIPSELF_PARTITION_CUS")
+    m = CLIPSelf(partition_cus=48)
+    with pytest.raises(ValueError):
+        m._check_partition(SimpleNamespace(num_compute_units=lambda: 304))     # the student's cap of 48 would leave 256 CUs free
+    m = CLIPSelf(partition_cus=48, partition_cap=64)
+    m._check_partition(SimpleNamespace(num_compute_units=lambda: 304))
+    assert m._partition_checked

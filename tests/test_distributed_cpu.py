@@ -190,3 +190,57 @@ def test_stats_are_not_collected_unless_asked(tmp_path):
     finally:
         dist.destroy_process_group()
         os.environ.pop("CLIPSELF_FORCE_DIST", None)
+
+
+def _fold_worker(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    from clipself_amd.init import synthetic_batch
+    from clipself_amd.open_clip.model import CustomCLIP
+    from clipself_amd.training.distributed import FrozenDataParallel
+    from oracle.ops_ref import RefOps
+    from oracle.stress_weights import trained_statistics_state
+    torch.set_num_threads(2)
+    cfg = _cfg("eva02")
+    teacher = CustomCLIP(cfg, ops=RefOps(), trainable=False)
+    eng = teacher.visual.engine
+    eng.load_state(trained_statistics_state(cfg, 2, row_offset_sigmas=2.0))
+    local = eng.block_fold_statistic()
+    # rank 1's device "rounds differently": its own statistic is pushed over the limit, rank 0's stays under it
+    eng.block_fold_limit = local * 1.01
+    if rank == 1:
+        stat = eng.block_fold_statistic
+        eng.block_fold_statistic = lambda *a, **k: stat(*a, **k) * (1.0 if a or k else 1.05)       # (the per-probe calls pass through)
+    wrapped = FrozenDataParallel(teacher)                           # calibrates here: the agreed value is rank 1's
+    agreed, decision = eng.block_fold_ratio, eng.block_folds_active()
+    # ... and a forward pass issues no collective: rank 1 skips it (an empty evaluation shard), rank 0 must not hang
+    if rank == 0:
+        _, _, crops = synthetic_batch(2, 3, cfg.image_size, cfg.image_size, seed=3)
+        with torch.no_grad():
+            wrapped.module.encode_image(crops.flatten(0, 1))
+    # a weight load inside the job re-arms the guard; the lazy path then calibrates locally, still without a collective
+    eng.sync_shadow()
+    lazy = None
+    if rank == 0:
+        with torch.no_grad():
+            wrapped.module.encode_image(crops.flatten(0, 1))
+        lazy = eng.block_fold_ratio
+    torch.save({"local": local, "agreed": agreed, "decision": decision, "lazy": lazy}, os.path.join(out_dir, f"fold{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fold_guard_is_agreed_at_wrapper_construction_and_forward_passes_issue_no_collective(tmp_path):
+    """the frozen schedule's fold guard took its MAX all-reduce lazily inside encode_image(), so a rank that never ran the
+    teacher (an empty evaluation shard) left the others hanging in the collective, and a swallowed error left the ranks with different
+    schedules.  Now FrozenDataParallel.__init__ -- a point every rank reaches -- calibrates (both ranks hold the MAX, hence the same
+    decision), and a forward pass never issues a collective (one rank skips it here; a hang would hit the 60 s group timeout)."""
+    port = _free_port()
+    mp.spawn(_fold_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"fold{r}.pt") for r in (0, 1))
+    assert r0["local"] == r1["local"]                               # same weights, same seeded probes
+    assert r0["agreed"] == r1["agreed"] == r1["local"] * 1.05       # the MAX over ranks, on both
+    assert r0["decision"] is False and r1["decision"] is False      # rank 0 alone would have folded (limit = 1.01 x its statistic)
+    assert r0["lazy"] == r0["local"]                                # the lazy path: local value, no collective

@@ -300,7 +300,10 @@ def _rope(Ntok, seed):
 
 
 @pytest.mark.parametrize("B,Ntok,H,qscale", [(2, 197, 12, 1.0), (3, 17, 2, 3.0), (2, 65, 2, 2.0), (1, 577, 3, 1.5), (2, 197, 2, 6.0), (2, 226, 2, 1.0), (1, 257, 3, 2.0),
-                                              (1, 401, 2, 1.0)])      # 226 / 257 / 401: one key / 33 keys / a ragged chunk past the first 224-key image (multiscale grids)
+                                              (1, 401, 2, 1.0),       # 226 / 257 / 401: one key / 33 keys / a ragged chunk past the first 224-key image (multiscale grids)
+                                              (1, 785, 2, 1.0), (1, 785, 2, 4.0), (1, 4097, 2, 1.0), (1, 4097, 2, 3.0), (2, 1025, 3, 1.0)])
+                                              # round 6: the 224-key-chunk kernels at 4 / 5 / 19 chunks (448^2, 512^2 and the recipe's 1024^2 student), flat and peaky
+                                              # softmax, dQ / dK / dV against RefOps.attn_bwd -- until round 5 these lengths were only compared with the round-1 kernels
 def test_attention_fwd_bwd(hip, ref, B, Ntok, H, qscale):
     C = H * 64
     qkv = rnd((B * Ntok, 3 * C), F32, 1.0, seed=30)
@@ -333,16 +336,57 @@ def test_attention_fwd_bwd(hip, ref, B, Ntok, H, qscale):
     check(tag + ".dv", dq_d[:, 2 * C:], dq_r[:, 2 * C:], 1.5e-2)
 
 
+@pytest.mark.parametrize("Ntok", [197, 401])
+def test_attention_bwd_padding_keys_cannot_poison_a_row_with_a_very_negative_lse(hip, ref, Ntok):
+    """the dQ kernel keeps no per-element key mask -- a padding key's K row is zero in the LDS image, its score 0 and its
+    "probability" exp2(-lse2).  For a query whose scaled scores are ALL below ~ -88 that overflows to +inf, and inf x 0 (the zero K^T
+    column) would be NaN for the whole dQ row.  Here every score is ~ -128 (q = +16, k = -16 on the two lowest-frequency rotary pairs of
+    each half, where the rotation is ~ identity): lse ~ -123.  The ragged last tile zeroes the padding keys' dS (wave-uniform branch)."""
+    B, H = 1, 2
+    C = H * 64
+    qkv = rnd((B * Ntok, 3 * C), F32, 0.02, seed=41)
+    for h in range(H):
+        for d in (30, 31, 62, 63):
+            qkv[:, h * 64 + d] += 16.0
+            qkv[:, C + h * 64 + d] -= 16.0
+    qkv = qkv.to(BF)
+    cos, sin = _rope(Ntok, 0)
+    scale = 64 ** -0.5
+    dout = rnd((B * Ntok, C), BF, seed=42)
+    o_r, lse_r = torch.empty(B * Ntok, C, dtype=BF), torch.empty(B * H, Ntok)
+    ref.attn_fwd(qkv, cos, sin, o_r, lse_r, B, Ntok, H, scale)
+    assert float(lse_r.max()) < -100, float(lse_r.max())
+    dq_r = torch.zeros(B * Ntok, 3 * C, dtype=BF)
+    ref.attn_bwd(qkv, o_r, dout, lse_r, cos, sin, dq_r, None, B, Ntok, H, scale)
+    qd, cd, sd, dd = both([qkv, cos, sin, dout])
+    o_d = torch.full((B * Ntok, C), float("nan"), dtype=BF, device="cuda")
+    lse_d = torch.empty(B * H, Ntok, device="cuda")
+    hip.attn_fwd(qd, cd, sd, o_d, lse_d, B, Ntok, H, scale)
+    check(f"attn_neg_lse[{Ntok}].o", o_d, o_r, 6e-3)
+    check(f"attn_neg_lse[{Ntok}].lse", lse_d, lse_r, 1e-3)
+    ws = torch.empty(hip.attn_bwd_workspace(B, Ntok, H), dtype=torch.uint8, device="cuda")
+    dq_d = torch.full((B * Ntok, 3 * C), float("nan"), dtype=BF, device="cuda")
+    hip.attn_bwd(qd, o_r.cuda(), dd, lse_r.cuda(), cd, sd, dq_d, ws, B, Ntok, H, scale)
+    assert torch.isfinite(dq_d.float()).all(), "NaN / inf in the attention backward at lse << -88"
+    check(f"attn_neg_lse[{Ntok}].dv", dq_d[:, 2 * C:], dq_r[:, 2 * C:], 1.5e-2)
+    # dq / dk are differences of nearly equal probabilities here (all scores equal): compare on the scale of dv's magnitude
+    for name, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C))):
+        err = float((dq_d[:, sl].float().cpu() - dq_r[:, sl].float()).norm() / (dq_r[:, 2 * C:].float().norm() + 1e-30))
+        _metric(f"attn_neg_lse[{Ntok}].{name}: |diff| / |dv| = {err:.3e}")
+        assert err < 1.5e-2, (name, err)
+
+
 @pytest.mark.parametrize("B,Ntok,H,qscale", [(9, 197, 12, 1.0), (3, 17, 2, 3.0), (2, 65, 2, 2.0), (2, 577, 3, 1.5), (1, 785, 2, 4.0), (2, 4097, 3, 1.0),
                                               (2, 226, 2, 1.0), (1, 257, 3, 2.0), (1, 401, 2, 1.0)])
 def test_attention_bwd_restaged_kernels_against_the_round1_kernels(hip, B, Ntok, H, qscale):
     """Round 5 re-staged the attention backward (all rows of a chunk requested up front, next chunk prefetched into registers, RoPE from the
-    LDS tables, K^T / Q^T / dO^T read from the row-major images with ds_read_b64_tr_b16): the same products in the same order -- the first
-    form was bit-identical to the round-1 kernels (CS_ATTN_BWD_V1, read per launch) on all six shapes (profiles/r05_c_*).  The hot loop then
-    lost its masking (zero K rows / +inf lse for the padding), took the raw v_exp_f32 and folds the softmax scale into one FMA
-    (dS = P (dP * scale - D * scale)): fp32 roundings in front of the bf16 store differ, so the comparison is a distance now: rel-L2 <= 2e-3
-    per gradient (a 1-ulp flip of a bf16 value is 4e-3 of that value), no isolated outlier (worst |difference| <= 0.1 rms), and two launches
-    of the new kernels agree in every bit."""
+    LDS tables, K^T / Q^T / dO^T read from the row-major images with ds_read_b64_tr_b16) and trimmed its hot loop (no masks: zero K rows /
+    +inf lse for the padding; raw v_exp_f32; the softmax scale folded into one FMA: dS = P (dP * scale - D * scale)).  Same products in the
+    same order; the folded scale changes fp32 roundings in general, but NOT under this test's precondition: head width 64 makes the scale
+    2^-3, a multiplication by a power of two commutes with every rounding, and no probability here is denormal -- so the new kernels must
+    still produce the round-1 kernels' bits (CS_ATTN_BWD_V1, read per launch), and two launches must agree in every bit.  The distances are
+    logged as well.  (The comparison with the ORACLE at these lengths is test_attention_fwd_bwd, round 6.)  A scale that is not a power of
+    two would only satisfy the distance bound, not the bit equality."""
     import os
     C = H * 64
     qkv = rnd((B * Ntok, 3 * C), F32, 1.0, seed=36)
@@ -374,8 +418,7 @@ def test_attention_bwd_restaged_kernels_against_the_round1_kernels(hip, B, Ntok,
         worst = float((a - b).abs().max() / b.pow(2).mean().sqrt())
         _metric(f"attn_bwd v2 vs v1 [{B},{Ntok},{H},x{qscale}] {name}: rel-L2 {r:.2e}, worst |diff| / rms {worst:.2e}, differing {float((a != b).float().mean()):.2%}")
         assert r <= 2e-3 and worst <= 0.1, (name, r, worst)
-        # head width 64: the softmax scale is 2^-3, a multiplication by it commutes with every rounding, and no probability is denormal --
-        # the trimmed arithmetic then still produces the round-1 bits (measured on all six shapes: 0 elements differ)
+        assert scale == 2.0 ** -3                        # the precondition of the bit equality (docstring)
         assert torch.equal(got[:, sl], old[:, sl]), f"{name}: {int((a != b).sum())} elements differ from the round-1 kernel"
 
 

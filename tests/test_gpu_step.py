@@ -342,6 +342,8 @@ def test_bench_rccl_single_rank_path():
     # per-bucket issue -> completion (device events on an observer stream), reverse layer order, and the window the CUs are withheld in
     assert list(dp["bucket_issue_to_done_ms"]) == [str(i) for i in range(11, -1, -1)] and all(v >= 0 for v in dp["bucket_issue_to_done_ms"].values())
     assert dp["stats_collected"] and dp["rccl_reserved_window"].startswith("first bucket")
+    # round 6: the prediction the measured fields are to be read against travels in the same object (one rank: nothing on the links)
+    assert dp["expected"]["buckets_per_step"] == 12 and dp["expected"]["mb_on_a_ranks_links_per_bucket"] == 0.0
 
 
 def test_teacher_prefetch_on_side_stream_equals_inline():
