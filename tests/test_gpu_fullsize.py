@@ -231,7 +231,7 @@ def test_recipe_shape_1024px_student_4097_tokens():
         got = student.encode_pseudo_boxes(images.cuda(), [r.cuda() for r in rois])
     r, c = rel(got, want), one_minus_cos(got, want)
     _log(f"N1 recipe shape: B/16 student at 1024^2 (4097 tokens) RoI features vs oracle: rel-L2 {r:.3e}, max 1-cos {c:.2e}")
-    assert r < 2e-2 and c < 5e-4
+    assert r < 1e-2 and c < 5e-5                           # measured 4.0e-3 / 7.9e-6
     # round 6: the backward at 19 key chunks against autograd of the fp32 oracle -- gradient of sum(roi feats * w) w.r.t.
     # one early and one late parameter, as test_non_native_grid_multichunk_attention_matches_oracle does at 448^2
     names = ("visual.blocks.0.attn.q_bias", "visual.blocks.1.attn.v_proj.weight", "visual.blocks.10.mlp.w3.bias")
@@ -242,7 +242,7 @@ def test_recipe_shape_1024px_student_4097_tokens():
     for n in names:
         rg = rel(dict(student.named_parameters())[n].grad, ref[n].grad)
         _log(f"N1 recipe shape: gradient at 4097 tokens vs oracle autograd, {n}: rel-L2 {rg:.3e}")
-        assert rg < 2e-2, (n, rg)                         # measured: see profiles/r06_parity.md
+        assert rg < 1.2e-2, (n, rg)                       # measured 6.0e-3 / 5.1e-3 / 1.8e-3 (profiles/r06_parity.md)
     del ref                                                # train_step below starts with optimizer.zero_grad()
     batch = tuple(t.cuda() for t in synthetic_batch(2, 20, 1024, 224, seed=18))
     opt = FlatAdamW(student, lr=1e-5, weight_decay=0.1)

@@ -319,8 +319,8 @@ def test_attention_fwd_bwd(hip, ref, B, Ntok, H, qscale):
     lse_d = torch.empty(B * H, Ntok, device="cuda")
     hip.attn_fwd(qd, cd, sd, o_d, lse_d, B, Ntok, H, scale)
     tag = f"attn[{B},{Ntok},{H},x{qscale}]"
-    check(tag + ".o", o_d, o_r, 6e-3)
-    check(tag + ".lse", lse_d, lse_r, 1e-3)
+    check(tag + ".o", o_d, o_r, 4e-3)                  # measured <= 2.4e-3 (4097 tokens), round 6: profiles/r06_parity.md
+    check(tag + ".lse", lse_d, lse_r, 1e-4)            # measured <= 2.8e-6
     # inference variant (no lse)
     o_d2 = torch.empty_like(o_d)
     hip.attn_fwd(qd, cd, sd, o_d2, None, B, Ntok, H, scale)
@@ -331,9 +331,9 @@ def test_attention_fwd_bwd(hip, ref, B, Ntok, H, qscale):
     ws = torch.empty(hip.attn_bwd_workspace(B, Ntok, H), dtype=torch.uint8, device="cuda")
     dq_d = torch.full((B * Ntok, 3 * C), float("nan"), dtype=BF, device="cuda")
     hip.attn_bwd(qd, o_r.cuda(), dd, lse_r.cuda(), cd, sd, dq_d, ws, B, Ntok, H, scale)
-    check(tag + ".dq", dq_d[:, :C], dq_r[:, :C], 1.5e-2)
-    check(tag + ".dk", dq_d[:, C:2 * C], dq_r[:, C:2 * C], 1.5e-2)
-    check(tag + ".dv", dq_d[:, 2 * C:], dq_r[:, 2 * C:], 1.5e-2)
+    check(tag + ".dq", dq_d[:, :C], dq_r[:, :C], 1e-3)              # measured <= 2.4e-4 on all 13 shapes (bf16 outputs of fp32 accumulators)
+    check(tag + ".dk", dq_d[:, C:2 * C], dq_r[:, C:2 * C], 1e-3)
+    check(tag + ".dv", dq_d[:, 2 * C:], dq_r[:, 2 * C:], 1e-3)
 
 
 @pytest.mark.parametrize("Ntok", [197, 401])
