@@ -25,6 +25,10 @@ namespace {
 constexpr int HD = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 
+// (Round 6 measured hand-packed fp32 math -- v_pk_fma_f32 / v_pk_add_f32 on float2 values for the softmax's scale-and-subtract, the row sums
+// and the backward's exp2(fma) * fma -- against hipcc's own choice: 4-25 % SLOWER in the forward kernels, a tie in the backward; the packed
+// forms need aligned register pairs, i.e. more VGPRs and copies, and return no issue slots here.  profiles/r06_d_attn_ab.txt.)
+
 #define Z16 (f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f})
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -279,9 +283,23 @@ __device__ __forceinline__ void load_q_frags(const AttnArgs& p, const float* rt,
 // the absolute block index, so a chunk of a whole-sequence image cannot be addressed through an offset pointer)
 // VROW: Vt points at a ROW-MAJOR [keys][64] image in the k_off layout instead of the transposed one; the V^T fragments are then read with
 // ds_read_b64_tr_b16 (half hf supplies keys 8 hf .. 8 hf + 7 of the 16-key step, the conventional order pack8_swapped produces).
-template <int CH, bool TAIL, bool VROW = false>
+// VM, the V image (round 6):
+//   0  V^T [64][264], key blocks XOR-permuted (rounds 1-5).  Under ds_read_b128's lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31} per wave
+//      half: MI355X_MICROARCH.md "LDS") its fragment reads are 2-WAY bank-conflicted -- 8 instead of 4 LDS cycles each, and V^T reads are two
+//      thirds of the attend phase's LDS reads (SQ_LDS_BANK_CONFLICT = 33 % of SQ_LDS_IDX_ACTIVE in profiles/r05_e_pmc_attention_lds.md)
+//   1  row-major [keys][64] in the k_off layout, fragments through ds_read_b64_tr_b16 (VROW)
+//   3  V^T [64][200] for sequences of <= 200 keys (attn_fwd4_kernel): key block kb of dim row d sits at block (kb + (d >> 5)) mod 25 -- a ROTATION
+//      instead of the XOR: conflict-free fragment reads, 4-way conflicts on the 8 transposing writes per thread and unit (tools/lds_bank_model.py)
+//   (2 was a [64][224] image rotated by the dim chunk, (kb + (d >> 3 & 7)) mod 28: conflict-free reads AND writes in attn_fwd8_kernel -- built,
+//   bit-identical, `SQ_LDS_BANK_CONFLICT` 19.9 M -> 12 M per launch, and 1 % SLOWER (425-427 vs 419-422 us per 1024-crop launch: the wrap of the
+//   rotation costs a compare + subtract per fragment address and the LDS array was 34 % busy to begin with); removed.  profiles/r06_c_attention_pipes.md)
+// The same values reach the same MFMAs in every mode: bit-identical outputs.
+constexpr int VT4_LD = 200;
+
+template <int CH, bool TAIL, int VM = 0>
 __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, const bf16x8 (&qf)[4], int key0, int Ntok, float sl2,
                                              int lane, bool first, float& m, float& l, f32x16 (&o)[2], int t0 = 0) {
+    constexpr bool VROW = VM == 1;
     const int hf = lane >> 5, l31 = lane & 31;
     // fragment addressing (row = t*32 + l31): LDS row (row>>1), slot ((row&1)*8 | chunk) ^ ((row>>1)&15)
     const int k_base = (l31 >> 1) << 8, par8 = (l31 & 1) << 3, sw = l31 >> 1;
@@ -365,6 +383,11 @@ __device__ __forceinline__ void attend_chunk(const char* Kl, const __bf16* Vt, c
                 if constexpr (VROW) {
                     const char* Vl = (const char*)Vt + (t0 + t) * (16 * 256);
                     vfrag = tr_join2(tr_read4(Vl + tr_lane_off(c2 * 16 + 8 * hf, dt * 32, lane)), tr_read4(Vl + tr_lane_off(c2 * 16 + 8 * hf + 4, dt * 32, lane)));
+                } else if constexpr (VM == 3) {
+                    const int d = dt * 32 + l31;
+                    int pos = kb + dt;
+                    if ((t0 + t) * 4 + c2 * 2 + 2 >= 25) pos = pos >= 25 ? pos - 25 : pos;        // (compile-time condition: the last key tiles) blocks 25..27 = keys >= 200, p = 0: they wrap onto real, finite data
+                    vfrag = *(const bf16x8*)(Vt + d * VT4_LD + (pos << 3));
                 } else {
                     const int d = dt * 32 + l31;
                     vfrag = *(const bf16x8*)(Vt + d * VT_LD + ((kb ^ ((d >> 3) & 7)) << 3));
@@ -483,9 +506,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnArgs p) {
             vr.load(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0 + CHK, p.Ntok, tid);
         }
         if (!active) continue;
-        attend_chunk<CH1, false, true>(Kl, (const __bf16*)Vl, qf, key0, p.Ntok, sl2, lane, key0 == 0, m, l, o, 0);
+        attend_chunk<CH1, false, 1>(Kl, (const __bf16*)Vl, qf, key0, p.Ntok, sl2, lane, key0 == 0, m, l, o, 0);
         if (key0 + CH1 * 32 < p.Ntok)                     // (wave-uniform) the second step holds at least one real key
-            attend_chunk<CH - CH1, false, true>(Kl, (const __bf16*)Vl, qf, key0 + CH1 * 32, p.Ntok, sl2, lane, false, m, l, o, CH1);
+            attend_chunk<CH - CH1, false, 1>(Kl, (const __bf16*)Vl, qf, key0 + CH1 * 32, p.Ntok, sl2, lane, false, m, l, o, CH1);
     }
     if (active && q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
 }
@@ -499,9 +522,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnArgs p) {
 // VROW (round 5, CS_ATTN_FWD8_VROW=1; NOT the default -- measured 2 % slower): V stays row-major in LDS (staged like K, four 16-byte items per
 // thread on all 512 threads) and its transposed fragments come from ds_read_b64_tr_b16 -- no 8 x 8 in-register transposes on 224 of the 512
 // threads, 16 instead of 32 staging registers; same values into the same MFMAs: bit-identical outputs.
-template <bool TAIL, bool VROW>
+// VM: the V image, see attend_chunk -- 0: the XOR-permuted V^T [64][264]; 1: row-major + transposing reads.
+template <bool TAIL, int VM>
 __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
     constexpr int CH = 7, CHK = CH * 32, NT = 512;
+    constexpr bool VROW = VM == 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kl = smem;
     __bf16* Vt = (__bf16*)(smem + CHK * 128);
@@ -603,17 +628,146 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
     f32x16 o[2] = {zero16(), zero16()};
     if (ATT_ABL(p, 1)) { l = 1.f; m = 0.f; o[0][0] = bf2f(qf[0][0]); }
     else if (TAIL) {                       // 192 < Ntok <= 224 (the 14x14 + CLS grid): two full chunks and the ragged last tile
-        attend_chunk<3, false, VROW>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o, 0);
-        attend_chunk<3, false, VROW>(Kl, Vt, qf, 96, p.Ntok, sl2, lane, false, m, l, o, 3);
-        attend_chunk<1, true, VROW>(Kl, Vt, qf, 192, p.Ntok, sl2, lane, false, m, l, o, 6);
+        attend_chunk<3, false, VM>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o, 0);
+        attend_chunk<3, false, VM>(Kl, Vt, qf, 96, p.Ntok, sl2, lane, false, m, l, o, 3);
+        attend_chunk<1, true, VM>(Kl, Vt, qf, 192, p.Ntok, sl2, lane, false, m, l, o, 6);
     } else {
-        attend_chunk<3, false, VROW>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o, 0);
-        if (p.Ntok > 96) attend_chunk<3, false, VROW>(Kl, Vt, qf, 96, p.Ntok, sl2, lane, false, m, l, o, 3);
-        if (p.Ntok > 192) attend_chunk<1, false, VROW>(Kl, Vt, qf, 192, p.Ntok, sl2, lane, false, m, l, o, 6);
+        attend_chunk<3, false, VM>(Kl, Vt, qf, 0, p.Ntok, sl2, lane, true, m, l, o, 0);
+        if (p.Ntok > 96) attend_chunk<3, false, VM>(Kl, Vt, qf, 96, p.Ntok, sl2, lane, false, m, l, o, 3);
+        if (p.Ntok > 192) attend_chunk<1, false, VM>(Kl, Vt, qf, 192, p.Ntok, sl2, lane, false, m, l, o, 6);
     }
     ATT_TRACE(5);
     if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
     ATT_TRACE(6);
+}
+
+// Round 6: THREE (crop, head) units per CU -- built on VERDICT r5's lead, bit-identical, and a TIE with attn_fwd8_kernel (424-426 vs 419-422 us per
+// 1024-crop launch): the forward is no longer bound by units in flight, its VALU is busy 65-73 % of a launch (profiles/r06_c_attention_pipes.md).
+// NOT the default; CS_ATTN_FWD4=1 selects it (read per launch).  What it is:  attn_fwd8_kernel is bound by units in flight per CU x latency, not by a pipe: two units of 69 KB
+// alternate a 5.8 us load phase with a 4.5 us attend phase and for 29 % of a launch no unit of a CU is attending
+// (profiles/r04_t_attention_timeline.md).  A third resident unit needs <= 54.6 KB of LDS and, with eight waves per unit, <= 80 VGPRs -- the
+// attend phase holds 32 output + 16 query + 48 score registers.  So the unit shrinks instead: FOUR waves, each attending its query tiles one
+// after the other (tiles w and w + 4 of the seven; same attend_chunk, same 3 + 3 + 1 key chunks, hence the same bits), 12 waves per CU = three per
+// SIMD at <= 168 VGPRs, and LDS images sized for the sequence: K [200][64] (25.0 KB), V^T [64][200] (25.0 KB, layout 3 of attend_chunk) and
+// the RoPE tables stored ONCE: rope.py:118-142 builds the row part and the column part from the same `freqs` tensor and repeats every
+// frequency for the two dims of a pair, so cos_row[r][2j] == cos_row[r][2j+1] == cos_col[r][2j]: one [g][16] table each for cos and sin
+// (1.75 KB at g = 14 instead of 7 KB) -- a documented precondition of the C ABI (include/clipself_hip.h), checked by HipOps once per table.
+// 51.75 KB per unit.  For square grids up to 14 x 14 (Ntok <= 197).
+constexpr int K4_ROWS = 200;
+
+__device__ __forceinline__ void rope8c(U128& v, const float* rt, int g, float inv_g, int tok, int c8) {
+    const int t = tok - 1;
+    const int r = (int)(((float)t + 0.5f) * inv_g), c = t - r * g;
+    const float* cs = rt + ((c8 < 4 ? r : c) << 4) + (c8 & 3) * 4;
+    const float4 c4 = *(const float4*)cs, s4 = *(const float4*)(cs + (g << 4));
+    const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x0 = bf2f(v.e[2 * j]), x1 = bf2f(v.e[2 * j + 1]);
+        v.e[2 * j] = f2bf(x0 * cc[j] - x1 * ss[j]);
+        v.e[2 * j + 1] = f2bf(x1 * cc[j] + x0 * ss[j]);
+    }
+}
+
+template <int NW, bool TAIL>
+__global__ __launch_bounds__(NW * 64, 3) void attn_fwd4_kernel(AttnArgs p) {     // 3 units per CU: 12 waves = 3 per SIMD (five waves per unit at 128 VGPRs spilled 31-46 dwords: 699 us)
+    constexpr int NT = NW * 64, KI = (K4_ROWS * 8 + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kl = smem;
+    __bf16* Vt = (__bf16*)(smem + K4_ROWS * 128);
+    float* rt = (float*)(smem + K4_ROWS * 128 + HD * VT4_LD * 2);      // cos [g][16] | sin [g][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int C = p.H * HD;
+    const size_t rowbase = (size_t)b * p.Ntok;
+    const float sl2 = p.scale * LOG2E;
+    const int last = p.Ntok - 1;
+    // every global load of the workgroup ahead of the first dependent instruction: tables (oldest: vmcnt retires in order), K, V, Q of both tiles
+    float tab[2];
+    {
+        const int i = min(tid, p.grid * 16 - 1), r = i >> 4, j = i & 15;       // the column part of grid row 0: token r, dims 32 + 2j
+        tab[0] = p.cos_t[(size_t)r * HD + 32 + 2 * j];
+        tab[1] = p.sin_t[(size_t)r * HD + 32 + 2 * j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    U128 kr[KI], vin[8], qraw[2][4];
+    const __bf16* kbase = p.qkv + C + h * HD;
+    const __bf16* vbase = p.qkv + 2 * C + h * HD;
+    const int vkb = min(tid, K4_ROWS - 1) >> 3, vc = tid & 7;      // one (key block, dim chunk) item per thread, threads >= 200 repeat the last
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {          // branch-free: rows past the sequence re-read its last row (masked to p = 0 exactly)
+        const int idx = min(tid + it * NT, K4_ROWS * 8 - 1), tok = min(idx >> 3, last);
+        kr[it].u = *(const uint4*)(kbase + (rowbase + tok) * p.ldqkv + (idx & 7) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int tok = min(vkb * 8 + i, last);
+        vin[i].u = *(const uint4*)(vbase + (rowbase + tok) * p.ldqkv + vc * 8);
+    }
+    // the wave that owns a single query tile (seven tiles on NW waves) rotates with the unit index
+    int wq = wave + bh % NW;
+    wq = wq >= NW ? wq - NW : wq;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int qc = min((wq + ps * NW) * 32 + l31, last);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qraw[ps][ks].u = *(const uint4*)(p.qkv + (rowbase + qc) * p.ldqkv + h * HD + ks * 16 + hf * 8);
+    }
+    if (tid < p.grid * 16) {
+        rt[tid] = tab[0];
+        rt[(p.grid << 4) + tid] = tab[1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {          // K: rotate + swizzled LDS image
+        const int idx = tid + it * NT, r = idx >> 3, c = idx & 7;
+        if (idx < K4_ROWS * 8) {
+            if (r > 0 && r < p.Ntok) rope8c(kr[it], rt, p.grid, p.inv_grid, r, c);
+            *(uint4*)(Kl + k_off(r, c)) = kr[it].u;
+        }
+    }
+    if (tid < K4_ROWS) {                       // V: 8x8 in-register transpose -> V^T image, key block rotated by the dim chunk's upper bit
+        const int rot = vkb + (vc >> 2), pos = (rot >= 25 ? rot - 25 : rot) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            U128 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.e[i] = vin[i].e[j];
+            *(uint4*)(Vt + (vc * 8 + j) * VT4_LD + pos) = o.u;
+        }
+    }
+    __syncthreads();
+#pragma nounroll                               // one copy of the attend code: the second tile's rows are selected into the first's registers
+    for (int ps = 0; ps < 2; ++ps) {
+        const int q0 = (wq + ps * NW) * 32;
+        if (q0 >= p.Ntok) break;               // wave-uniform
+        // an opaque copy of the lane id: without it every lane mask and LDS address of the attend code is loop-invariant, gets hoisted in
+        // front of the loop and is spilled there (344 SGPRs in the first build)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int hf = ln >> 5, l31 = ln & 31;
+        const int q = q0 + l31, qc = min(q, last);
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            U128 t;
+            t.u = ps ? qraw[1][ks].u : qraw[0][ks].u;
+            if (qc > 0) rope8c(t, rt, p.grid, p.inv_grid, qc, ks * 2 + hf);
+            qf[ks] = t.h;
+        }
+        float m = -INFINITY, l = 0.f;
+        f32x16 o[2] = {zero16(), zero16()};
+        if (TAIL) {                            // 192 < Ntok <= 200 (the 14x14 + CLS grid): two full chunks and the ragged last tile
+            attend_chunk<3, false, 3>(Kl, Vt, qf, 0, p.Ntok, sl2, ln, true, m, l, o, 0);
+            attend_chunk<3, false, 3>(Kl, Vt, qf, 96, p.Ntok, sl2, ln, false, m, l, o, 3);
+            attend_chunk<1, true, 3>(Kl, Vt, qf, 192, p.Ntok, sl2, ln, false, m, l, o, 6);
+        } else {
+            attend_chunk<3, false, 3>(Kl, Vt, qf, 0, p.Ntok, sl2, ln, true, m, l, o, 0);
+            if (p.Ntok > 96) attend_chunk<3, false, 3>(Kl, Vt, qf, 96, p.Ntok, sl2, ln, false, m, l, o, 3);
+            if (p.Ntok > 192) attend_chunk<1, false, 3>(Kl, Vt, qf, 192, p.Ntok, sl2, ln, false, m, l, o, 6);
+        }
+        if (q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -1182,11 +1336,24 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
     static const size_t lds_pad = getenv("CS_ATTN_LDSPAD") ? (size_t)atoi(getenv("CS_ATTN_LDSPAD")) : 0;     // occupancy experiments
     const size_t lds = (size_t)CH * 32 * 128 + (size_t)HD * VT_LD * 2 + (size_t)4 * g * 32 * sizeof(float) + lds_pad;
     CS_CHECK_ARG(lds <= 160 * 1024, "cs_attn_fwd: token grid %d too large for the LDS RoPE tables", g);
-    if (Ntok <= CH * 32) {
+    // A/B switch, read per launch: CS_ATTN_FWD4=1 = four waves per unit, three units per CU (round 6: a tie, see attn_fwd4_kernel)
+    const char* f4 = getenv("CS_ATTN_FWD4");
+    if (f4 && f4[0] == '1' && Ntok <= K4_ROWS && g <= 14) {
+        static bool once4 = (set_lds(attn_fwd4_kernel<4, false>, 160 * 1024), set_lds(attn_fwd4_kernel<4, true>, 160 * 1024), true);
+        (void)once4;
+        const size_t lds4 = (size_t)K4_ROWS * 128 + (size_t)HD * VT4_LD * 2 + (size_t)2 * g * 16 * sizeof(float) + lds_pad;
+        if (getenv("CS_ATTN_DEBUG")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_fwd4_kernel<4, true>, 256, lds4);
+            fprintf(stderr, "[cs_attn] fwd4: %d resident workgroups per CU (lds %zu)\n", nb, lds4);
+        }
+        if (Ntok > 192) hipLaunchKernelGGL((attn_fwd4_kernel<4, true>), dim3(1, B * H), dim3(256), lds4, stream, a);
+        else hipLaunchKernelGGL((attn_fwd4_kernel<4, false>), dim3(1, B * H), dim3(256), lds4, stream, a);
+    } else if (Ntok <= CH * 32) {
         // whole sequence in one LDS image: eight waves, one query tile each, two workgroups (16 waves) per CU; when only the last key tile is
         // ragged (Ntok > 32 (CH - 1): the 14x14 grid), the variant whose ragged-tile code exists once
-        static bool once = (set_lds(attn_fwd8_kernel<false, false>, 160 * 1024), set_lds(attn_fwd8_kernel<true, false>, 160 * 1024),
-                            set_lds(attn_fwd8_kernel<false, true>, 160 * 1024), set_lds(attn_fwd8_kernel<true, true>, 160 * 1024), true);
+        static bool once = (set_lds(attn_fwd8_kernel<false, 0>, 160 * 1024), set_lds(attn_fwd8_kernel<true, 0>, 160 * 1024),
+                            set_lds(attn_fwd8_kernel<false, 1>, 160 * 1024), set_lds(attn_fwd8_kernel<true, 1>, 160 * 1024), true);
         (void)once;
         // A/B switch, read per launch.  Default: the transposed V image of rounds 1-4.  CS_ATTN_FWD8_VROW=1: V row-major + transposing reads --
         // bit-identical outputs, measured 2 % SLOWER per 2048-crop launch (811-816 -> 830-831 us, profiles/r05_h_fwd8_row_major_v.txt): the
@@ -1196,16 +1363,16 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
         const size_t lds8 = vt ? lds : (size_t)2 * CH * 32 * 128 + (size_t)4 * g * 32 * sizeof(float) + lds_pad;
         if (getenv("CS_ATTN_DEBUG")) {
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_fwd8_kernel<true, true>, 512, lds8);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, attn_fwd8_kernel<true, 0>, 512, lds8);
             fprintf(stderr, "[cs_attn] fwd8: %d resident workgroups per CU (lds %zu)\n", nb, lds8);
         }
         const bool tail = Ntok > (CH - 1) * 32;
         if (vt) {
-            if (tail) hipLaunchKernelGGL((attn_fwd8_kernel<true, false>), dim3(1, B * H), dim3(512), lds8, stream, a);
-            else hipLaunchKernelGGL((attn_fwd8_kernel<false, false>), dim3(1, B * H), dim3(512), lds8, stream, a);
+            if (tail) hipLaunchKernelGGL((attn_fwd8_kernel<true, 0>), dim3(1, B * H), dim3(512), lds8, stream, a);
+            else hipLaunchKernelGGL((attn_fwd8_kernel<false, 0>), dim3(1, B * H), dim3(512), lds8, stream, a);
         } else {
-            if (tail) hipLaunchKernelGGL((attn_fwd8_kernel<true, true>), dim3(1, B * H), dim3(512), lds8, stream, a);
-            else hipLaunchKernelGGL((attn_fwd8_kernel<false, true>), dim3(1, B * H), dim3(512), lds8, stream, a);
+            if (tail) hipLaunchKernelGGL((attn_fwd8_kernel<true, 1>), dim3(1, B * H), dim3(512), lds8, stream, a);
+            else hipLaunchKernelGGL((attn_fwd8_kernel<false, 1>), dim3(1, B * H), dim3(512), lds8, stream, a);
         }
     } else {
         static bool once = (set_lds(attn_fwd_kernel<CH>, 160 * 1024), set_lds(attn_fwd2_kernel<CH, 4>, 160 * 1024), true);

@@ -332,8 +332,33 @@ class HipOps:
         assert part.is_contiguous() and part.shape[2] == 2
         self._ok(self.lib.cs_ln_stats_finalize(_p(part), P, npp, C, M, eps, _p(mean), _p(rstd), self._stream()), "cs_ln_stats_finalize")
 
+    def _check_rope_tables(self, cos, sin, Ntok):
+        """The forward kernels read the rotary tables separably and (round 6, attn_fwd4_kernel) ONCE per frequency: for a g x g grid, dims
+        [0, 32) of token (r, c) depend on r only, dims [32, 64) on c only, the row part of grid row i equals the column part of grid column i,
+        and the two dims of a rotation pair share their entry -- exactly what rope.py:118-142 builds (one `freqs` tensor, repeated for the
+        pair, broadcast over rows and columns).  The C ABI documents this as a precondition (include/clipself_hip.h); this wrapper checks it
+        once per table tensor (a few reductions and one host read-back) and raises instead of letting a kernel return wrong numbers."""
+        key = (cos.data_ptr(), sin.data_ptr(), cos._version, sin._version, Ntok)
+        seen = self.__dict__.setdefault("_rope_ok", set())
+        if key in seen:
+            return
+        g = int(round((Ntok - 1) ** 0.5))
+        if g * g != Ntok - 1 or tuple(cos.shape) != (Ntok - 1, 64) or tuple(sin.shape) != (Ntok - 1, 64):
+            raise ValueError(f"rotary tables must be [g*g, 64] for a square token grid, got {tuple(cos.shape)} for {Ntok} tokens")
+        for t in (cos, sin):
+            v = t.view(g, g, 64)
+            ok = (torch.equal(v[:, :, :32], v[:, :1, :32].expand(g, g, 32)) and torch.equal(v[:, :, 32:], v[:1, :, 32:].expand(g, g, 32))
+                  and torch.equal(v[:, 0, :32], v[0, :, 32:]) and torch.equal(v[..., 0::2], v[..., 1::2]))
+            if not ok:
+                raise ValueError("rotary tables are not in the layout of rope.py:118-142 (separable, row part == column part, one entry per "
+                                 "rotation pair): the attention kernels cannot read them")
+        if len(seen) > 64:
+            seen.clear()
+        seen.add(key)
+
     def attn_fwd_stats(self, qkv, cos, sin, out, lse, stats_part, B, Ntok, H, scale):
         self._chk(qkv, cos, sin, out, lse, stats_part)
+        self._check_rope_tables(cos, sin, Ntok)
         assert stats_part.is_contiguous() and tuple(stats_part.shape) == (H, B * Ntok, 2)
         self._ok(self.lib.cs_attn_fwd_stats(_p(qkv), _p(cos), _p(sin), _p(out), _p(lse), _p(stats_part), B, Ntok, H, qkv.stride(0),
                                             out.stride(0), scale, self._stream()), "cs_attn_fwd_stats")
@@ -408,6 +433,7 @@ class HipOps:
 
     def attn_fwd(self, qkv, cos, sin, out, lse, B, Ntok, H, scale):
         self._chk(qkv, cos, sin, out, lse)
+        self._check_rope_tables(cos, sin, Ntok)
         self._ok(self.lib.cs_attn_fwd(_p(qkv), _p(cos), _p(sin), _p(out), _p(lse), B, Ntok, H, qkv.stride(0), out.stride(0),
                                       scale, self._stream()), "cs_attn_fwd")
 

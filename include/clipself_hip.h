@@ -130,7 +130,11 @@ int cs_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, void* 
  * qkv [B*Ntok, ldqkv] bf16 = q|k|v (bias added, not rotated); cos/sin [(Ntok-1),64] f32; out [B*Ntok, ldo] bf16;
  * lse [B*H, Ntok] f32 (nullable in inference).  The forward kernels read the tables separably, exactly as rope.py:118-142 builds
  * them (Ntok-1 = g*g; dims [0,32) depend on the grid row only, dims [32,64) on the grid column only): row r*g supplies the
- * row part, row c the column part. */
+ * row part, row c the column part.  Round 6: the short-sequence kernel (Ntok <= 197) keeps ONE entry per frequency in LDS, so the rest of
+ * that construction is a precondition too: the row part of grid row i equals the column part of grid column i (both come from the same
+ * `freqs` tensor, rope.py:134-138) and the two dims of a rotation pair share their entry (`repeat(..., r = 2)`, :137) -- i.e.
+ * cos_t[(i*g)*64 + 2j] == cos_t[(i*g)*64 + 2j+1] == cos_t[i*64 + 32 + 2j], same for sin_t.  Identity tables (cos 1, sin 0: the OpenAI-CLIP
+ * family) satisfy it.  The Python wrapper (clipself_amd/hip.py) verifies the tables once per tensor and raises otherwise. */
 int cs_attn_fwd(const void* qkv, const float* cos_t, const float* sin_t, void* out, float* lse, int B, int Ntok, int H,
                 int ldqkv, int ldo, float scale, cs_stream_t stream);
 /* CLS-query attention for the frozen teacher's last block: VisionTransformer.forward_features returns x[:, 0]

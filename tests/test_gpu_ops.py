@@ -422,33 +422,40 @@ def test_attention_bwd_restaged_kernels_against_the_round1_kernels(hip, B, Ntok,
         assert torch.equal(got[:, sl], old[:, sl]), f"{name}: {int((a != b).sum())} elements differ from the round-1 kernel"
 
 
-@pytest.mark.parametrize("B,Ntok,H", [(40, 197, 12), (9, 17, 2), (5, 65, 12), (3, 145, 4), (2, 197, 2)])
-def test_attention_forward_row_major_v_equals_the_transposed_image_bit_for_bit(hip, B, Ntok, H):
-    """Round 5 experiment, kept as a switch (CS_ATTN_FWD8_VROW=1, read per launch; measured 2 % slower, not the default): the short-sequence
-    forward with V row-major in LDS and its transposed fragments through ds_read_b64_tr_b16 instead of a V^T image built with in-register
-    transposes: the same values reach the same MFMAs, so outputs, lse and the statistics partials agree in every bit."""
+@pytest.mark.parametrize("B,Ntok,H", [(40, 197, 12), (9, 17, 2), (5, 65, 12), (3, 145, 4), (2, 197, 2), (7, 101, 3)])
+def test_attention_forward_kernel_variants_agree_bit_for_bit(hip, B, Ntok, H):
+    """The short-sequence forward exists in three forms that put the same values into the same MFMAs in the same order -- outputs, lse and
+    the statistics partials must agree in every bit:
+      * default: attn_fwd8_kernel, eight waves per (crop, head) unit, two units per CU, XOR-permuted V^T [64][264];
+      * CS_ATTN_FWD8_VROW=1 (round 5): V row-major + ds_read_b64_tr_b16 (measured 2 % slower);
+      * CS_ATTN_FWD4=1 (round 6): attn_fwd4_kernel, four waves per unit attending two query tiles one after the other, THREE units per CU,
+        K [200][64] + V^T [64][200] (rotated key blocks, conflict-free fragment reads) + RoPE tables stored once per frequency (measured: a
+        tie -- the kernel's VALU is busy 65-73 % of a launch, a third unit finds no idle pipe: profiles/r06_c_attention_pipes.md)."""
     import os
     if int(round((Ntok - 1) ** 0.5)) ** 2 != Ntok - 1:
         pytest.skip("square token grids only")
     C = H * 64
     qkv = rnd((B * Ntok, 3 * C), BF, 1.0, seed=38).cuda()
     cos, sin = (t.cuda() for t in _rope(Ntok, 0))
-    outs = []
-    for old in (False, True):
+    variants = {"fwd8 XOR V^T": {}, "fwd8 row-major V": {"CS_ATTN_FWD8_VROW": "1"}, "fwd4": {"CS_ATTN_FWD4": "1"}}
+    outs = {}
+    for name, env in variants.items():
         o = torch.full((B * Ntok, C), float("nan"), dtype=BF, device="cuda")
         lse = torch.full((B * H, Ntok), float("nan"), device="cuda")
         part = torch.full((H, B * Ntok, 2), float("nan"), device="cuda")
-        if not old:
-            os.environ["CS_ATTN_FWD8_VROW"] = "1"
+        os.environ.update(env)
         try:
             hip.attn_fwd_stats(qkv, cos, sin, o, lse, part, B, Ntok, H, 64 ** -0.5)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("CS_ATTN_FWD8_VROW", None)
-        assert torch.isfinite(o.float()).all()
-        outs.append((o, lse, part))
-    for a, b, name in zip(outs[0], outs[1], ("o", "lse", "statistics")):
-        assert torch.equal(a, b), f"{name}: {int((a != b).sum())} elements differ"
+            for k in env:
+                os.environ.pop(k, None)
+        assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all() and torch.isfinite(part).all(), name
+        outs[name] = (o, lse, part)
+    base = outs["fwd8 XOR V^T"]                       # the default kernel
+    for name, got in outs.items():
+        for a, b, what in zip(got, base, ("o", "lse", "statistics")):
+            assert torch.equal(a, b), f"{name}: {what}: {int((a != b).sum())} elements differ from the default kernel"
 
 
 @pytest.mark.parametrize("B,Ntok,H", [(120, 197, 12), (700, 17, 2), (90, 65, 12)])
