@@ -62,6 +62,33 @@ __device__ __forceinline__ void rope8_lds(U128& v, const float* rt, int g, float
     rope8(v, cs, cs + (g << 5));
 }
 
+// Round 6: the tables ONCE per frequency.  rope.py:118-142 builds the row part and the column part from the same `freqs` tensor and repeats
+// every frequency for the two dims of a pair: cos_row[r][2j] == cos_row[r][2j+1] == cos_col[r][2j].  rt = cos [g][16] | sin [g][16] (a quarter of
+// the [4][g][32] tables above: 8 KB instead of 32 KB at the recipe's 64 x 64 grid); same products, same bits as rope8_lds.  A documented
+// precondition of the C ABI (include/clipself_hip.h), verified by HipOps once per table tensor.
+__device__ __forceinline__ void rope8c(U128& v, const float* rt, int g, float inv_g, int tok, int c8) {
+    const int t = tok - 1;
+    const int r = (int)(((float)t + 0.5f) * inv_g), c = t - r * g;
+    const float* cs = rt + ((c8 < 4 ? r : c) << 4) + (c8 & 3) * 4;
+    const float4 c4 = *(const float4*)cs, s4 = *(const float4*)(cs + (g << 4));
+    const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float x0 = bf2f(v.e[2 * j]), x1 = bf2f(v.e[2 * j + 1]);
+        v.e[2 * j] = f2bf(x0 * cc[j] - x1 * ss[j]);
+        v.e[2 * j + 1] = f2bf(x1 * cc[j] + x0 * ss[j]);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_rope_tables_c(float* rt, const float* __restrict__ cos_t, const float* __restrict__ sin_t, int g, int tid) {
+    for (int i = tid; i < g * 16; i += NT) {               // the column part of grid row 0: token i >> 4, dims 32 + 2 (i & 15)
+        const int r = i >> 4, j = i & 15;
+        rt[i] = cos_t[(size_t)r * HD + 32 + 2 * j];
+        rt[(g << 4) + i] = sin_t[(size_t)r * HD + 32 + 2 * j];
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void load_rope_tables(float* rt, const float* __restrict__ cos_t, const float* __restrict__ sin_t, int g, int tid) {
     for (int i = tid; i < g * 32; i += NT) {
@@ -113,6 +140,10 @@ struct AttnArgs {
     float* lse_out;        // fwd (nullable)
     int Ntok, H, ldqkv, ldo;
     float scale;
+    // round 6, block schedule of the long-sequence kernels (set_schedule / map_block below); sch_on = 0: blockIdx.y = (image, head), blockIdx.x = row block
+    int sch_on, sch_f0, sch_r, sch_bh, sch_fb, sch_rem, sch_absorb;
+    const __bf16* qk;      // PRE kernels: rotated q | k, [B*N, ldqk] (rope_qk_kernel)
+    int ldqk;
 #ifdef CS_ABLATION_SWITCHES
     unsigned long long* trace;   // env CS_ATTN_TRACE=<file>: per workgroup 8 x u64 (HW_ID, XCC_ID, 100 MHz clock at entry / tables / images / attended / end)
 #endif
@@ -122,6 +153,35 @@ struct AttnArgs {
 #else
 #define ATT_TRACE(slot) do { } while (0)
 #endif
+
+// Round 6: the tail of a launch is split.  The long-sequence kernels run ONE 8-wave workgroup per CU (216-247 VGPRs), a workgroup = 8 row tiles of 32
+// (256 queries resp. keys) of one (image, head) against the whole sequence.  At the recipe's 2 x 12 x 4097 that is 16 x 24 = 384 equal workgroups
+// on 256 CUs: two rounds, the second half empty (+ 24 workgroups for token 4096 alone, each walking all keys with one active wave).  With F full
+// blocks, G CUs and R = F mod G blocks left for the last round, 2 R <= G: those R blocks are issued as 2 R half blocks of 4 tiles -- the last round
+// takes ~0.6 of a full one instead of 1 -- and a sequence's last tiles (<= 4) ride on the upper half of its last full block (a fifth ... eighth wave)
+// instead of walking the sequence on their own.  Ids are block-major over the (image, head) pairs, so the halves are the last blocks of every
+// pair and with B x H a multiple of 8 a pair's blocks land on one XCD, whose L2 then holds its K / V.  Every row is computed by the same code
+// on the same operands in the same order: bit-identical results (tests/test_gpu_ops.py).
+struct RowBlock { int bh, tile0, nt; };
+__device__ __forceinline__ RowBlock map_block(const AttnArgs& p, int waves) {
+    RowBlock r;
+    if (!p.sch_on) {
+        r.bh = blockIdx.y; r.tile0 = blockIdx.x * waves; r.nt = waves;
+        return r;
+    }
+    const int id = blockIdx.x;
+    if (id < p.sch_f0) {
+        const int qb = id / p.sch_bh;
+        r.bh = id - qb * p.sch_bh; r.tile0 = qb * 8; r.nt = 8;
+    } else if (id < p.sch_f0 + 2 * p.sch_r) {
+        const int j = id - p.sch_f0, k = p.sch_f0 + (j >> 1), half = j & 1, qb = k / p.sch_bh;
+        r.bh = k - qb * p.sch_bh; r.tile0 = qb * 8 + half * 4;
+        r.nt = 4 + ((p.sch_absorb && half && qb == p.sch_fb - 1) ? p.sch_rem : 0);
+    } else {
+        r.bh = id - p.sch_f0 - 2 * p.sch_r; r.tile0 = p.sch_fb * 8; r.nt = p.sch_rem;
+    }
+    return r;
+}
 
 // stage `rows` token rows (tok0..) of one head column block into a swizzled [rows][64] LDS tile (+ optional transposed copy)
 template <int CHK, bool ROPE, bool WITH_T>
@@ -222,28 +282,32 @@ __device__ __forceinline__ s16x4v tr_read4(const char* addr) {
 
 // rows tok0 .. tok0 + CHK - 1 of one head's 64 columns into registers (rows past the sequence repeat its last row: finite values that
 // only meet p = 0), and from registers into a row-major LDS image, rotated on the way (ROPE) from the LDS tables
-template <int CHK>
+template <int CHK, int NT = 512>
 struct RowRegs {
-    static constexpr int ITEMS = (CHK * 8 + 511) / 512;
+    static constexpr int ITEMS = (CHK * 8 + NT - 1) / NT;
     uint4 v[ITEMS];                 // plain vectors: a union that lives across the chunk loop is kept on the stack
     __device__ __forceinline__ void load(const __bf16* __restrict__ src, size_t rowbase, int ld, int coloff, int tok0, int Ntok, int tid) {
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
-            const int idx = min(tid + it * 512, CHK * 8 - 1), tok = min(tok0 + (idx >> 3), Ntok - 1);
+            const int idx = min(tid + it * NT, CHK * 8 - 1), tok = min(tok0 + (idx >> 3), Ntok - 1);
             v[it] = *(const uint4*)(src + (rowbase + tok) * ld + coloff + (idx & 7) * 8);
         }
     }
     // ZPAD: rows past the sequence are stored as zeros (the dQ kernel: a zero K row contributes nothing to dQ^T += K^T . dS^T whatever its
     // dS column holds, so the hot loop masks nothing)
-    template <bool ROPE, bool ZPAD = false>
+    // CT: rt holds the compact tables (one entry per frequency, rope8c)
+    template <bool ROPE, bool ZPAD = false, bool CT = false>
     __device__ __forceinline__ void store(char* tile, const float* rt, int g, float inv_g, int tok0, int Ntok, int tid) {
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
-            const int idx = tid + it * 512, r = idx >> 3, c = idx & 7, tok = tok0 + r;
+            const int idx = tid + it * NT, r = idx >> 3, c = idx & 7, tok = tok0 + r;
             if (idx < CHK * 8) {
                 U128 t;
                 t.u = v[it];
-                if (ROPE && tok > 0 && tok < Ntok) rope8_lds(t, rt, g, inv_g, tok, c);
+                if (ROPE && tok > 0 && tok < Ntok) {
+                    if constexpr (CT) rope8c(t, rt, g, inv_g, tok, c);
+                    else rope8_lds(t, rt, g, inv_g, tok, c);
+                }
                 if (ZPAD && tok >= Ntok) t.u = make_uint4(0, 0, 0, 0);
                 *(uint4*)(tile + k_off(r, c)) = t.u;
             }
@@ -267,13 +331,17 @@ __device__ __forceinline__ bf16x8 pack8_swapped(const f32x16& a, int c2) {
     return out.v;
 }
 
+template <bool CT = false>
 __device__ __forceinline__ void load_q_frags(const AttnArgs& p, const float* rt, size_t rowbase, int qc, int h, int hf, bf16x8 (&qf)[4]) {
     U128 t[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) t[ks].u = *(const uint4*)(p.qkv + (rowbase + qc) * p.ldqkv + h * HD + ks * 16 + hf * 8);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        if (qc > 0) rope8_lds(t[ks], rt, p.grid, p.inv_grid, qc, ks * 2 + hf);
+        if (qc > 0) {
+            if constexpr (CT) rope8c(t[ks], rt, p.grid, p.inv_grid, qc, ks * 2 + hf);
+            else rope8_lds(t[ks], rt, p.grid, p.inv_grid, qc, ks * 2 + hf);
+        }
         qf[ks] = t[ks].h;
     }
 }
@@ -481,12 +549,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnArgs p) {
     float* rt = (float*)(smem + 2 * CHK * 128);          // compact RoPE tables [4][g][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const RowBlock rb = map_block(p, 8);
+    const int bh = rb.bh, b = bh / p.H, h = bh - b * p.H;
     const int C = p.H * HD;
     const size_t rowbase = (size_t)b * p.Ntok;
     const float sl2 = p.scale * LOG2E;
-    const int q0 = blockIdx.x * 256 + wave * 32, q = q0 + l31, qc = min(q, p.Ntok - 1);
-    const bool active = q0 < p.Ntok;
+    const int q0 = (rb.tile0 + wave) * 32, q = q0 + l31, qc = min(q, p.Ntok - 1);
+    const bool active = wave < rb.nt && q0 < p.Ntok;
     RowRegs<CHK> kr, vr;
     kr.load(p.qkv, rowbase, p.ldqkv, C + h * HD, 0, p.Ntok, tid);
     vr.load(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, 0, p.Ntok, tid);
@@ -513,6 +582,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd2_kernel(AttnArgs p) {
     if (active && q < p.Ntok) store_o(p, rowbase, q, h, bh, hf, m, l, o);
 }
 
+// (Round 6 also built the opposite shape -- MANY SMALL workgroups: four waves = 128 queries (keys), 128-row chunks, compact RoPE tables, 40 KB of LDS,
+// three or four workgroups per CU so that their softmax, MFMA and load phases overlap and 768 workgroups spread evenly over one round.  Measured
+// (profiles/r06_e_long_sequence_ab.txt): forward 227-241 vs 200 us at 4097 tokens (60 vs 65 at 577), backward 985 vs 520 us -- every workgroup stages
+// and rotates ALL keys, so halving the queries per workgroup doubles that work, and these kernels are bound by instruction throughput at the
+// power-limited clock, not by occupancy or by the half-empty second round: removed.)
 // Eight waves, ONE 32-query tile per wave, whole sequence (<= 224 keys) staged once; the keys are consumed in chunks of three tiles with
 // the online softmax, so a wave needs 48 score registers instead of 112 and fits 128 VGPRs: two workgroups per CU are 16 waves = FOUR per
 // SIMD (the 4-wave / 2-tile form above: two per SIMD at 206 VGPRs).  The forward is bound by dependent latencies (S = K.Q^T -> max ->
@@ -655,20 +729,6 @@ __global__ __launch_bounds__(512, 4) void attn_fwd8_kernel(AttnArgs p) {
 // 51.75 KB per unit.  For square grids up to 14 x 14 (Ntok <= 197).
 constexpr int K4_ROWS = 200;
 
-__device__ __forceinline__ void rope8c(U128& v, const float* rt, int g, float inv_g, int tok, int c8) {
-    const int t = tok - 1;
-    const int r = (int)(((float)t + 0.5f) * inv_g), c = t - r * g;
-    const float* cs = rt + ((c8 < 4 ? r : c) << 4) + (c8 & 3) * 4;
-    const float4 c4 = *(const float4*)cs, s4 = *(const float4*)(cs + (g << 4));
-    const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float x0 = bf2f(v.e[2 * j]), x1 = bf2f(v.e[2 * j + 1]);
-        v.e[2 * j] = f2bf(x0 * cc[j] - x1 * ss[j]);
-        v.e[2 * j + 1] = f2bf(x1 * cc[j] + x0 * ss[j]);
-    }
-}
-
 template <int NW, bool TAIL>
 __global__ __launch_bounds__(NW * 64, 3) void attn_fwd4_kernel(AttnArgs p) {     // 3 units per CU: 12 waves = 3 per SIMD (five waves per unit at 128 VGPRs spilled 31-46 dwords: 699 us)
     constexpr int NT = NW * 64, KI = (K4_ROWS * 8 + NT - 1) / NT;
@@ -796,6 +856,21 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const __bf16* __rest
         const long b = row / Ntok, n = row - b * Ntok;
         dsum[((size_t)b * H + h) * Ntok + n] = s;
     }
+}
+
+// q | k of every (token, head), rotated once: out [B*N, 2C] bf16.  One thread per 8 head dims; token 0 (CLS) passes through.  The same rope8 on the
+// same table entries as the kernels' own staging (rope8_lds reads copies of these entries): the same bits.
+__global__ __launch_bounds__(256) void rope_qk_kernel(const __bf16* __restrict__ qkv, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                      __bf16* __restrict__ out, long rows, int Ntok, int C, int ldqkv) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (row, chunk of 8 over the 2C columns of q | k)
+    const int cpr = C >> 2;                                            // 2C / 8 chunks per row
+    if (idx >= rows * cpr) return;
+    const long row = idx / cpr;
+    const int c = (int)(idx - row * cpr), col = c * 8, tok = (int)(row % Ntok);
+    U128 v;
+    v.u = *(const uint4*)(qkv + row * ldqkv + col);
+    if (tok > 0) rope8(v, cos_t + (size_t)(tok - 1) * HD + (col & 63), sin_t + (size_t)(tok - 1) * HD + (col & 63));
+    *(uint4*)(out + row * (2 * C) + col) = v.u;
 }
 
 // inverse rotation of an accumulator tile pair (lane = token, registers = head-dim) + bf16 store, 8 bytes per 4 dims
@@ -980,30 +1055,42 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnArgs p) {
 // dQ: wave = 32 queries, loops over key chunks.  dS^T = P^T o (dP^T - D) * scale ; dQ^T += K^T . dS^T
 // SINGLE: the whole sequence is one chunk (Ntok <= CH * 32: the 14x14 grid) -- no chunk loop, no prefetch registers, 128 VGPRs: two
 // workgroups per CU
-template <int CH, bool SINGLE>
+// PRE (round 6): q and k come ROTATED from p.qk ([B*N, ldqk] bf16 = q | k, written once per launch by rope_qk_kernel): a workgroup of these
+// kernels walks the whole sequence, so the K rows (dQ kernel) and the Q rows (dK/dV kernel) of an (image, head) pair were rotated again by
+// every one of its 17 row blocks at the recipe's 4097 tokens -- a fifth of the kernels' VALU instructions.  Same rotation arithmetic, same bits.
+template <int CH, bool SINGLE, bool PRE = false>
 __global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnArgs p) {
-    constexpr int CHK = CH * 32;
+    constexpr int CHK = CH * 32, NT = 512, NW = 8;
+    constexpr bool CT = false, PF = true;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Kl = smem;
     char* Vl = smem + CHK * 128;
     float* rt = (float*)(smem + 2 * CHK * 128);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const RowBlock rb = map_block(p, NW);
+    const int bh = rb.bh, b = bh / p.H, h = bh - b * p.H;
     const int C = p.H * HD;
     const size_t rowbase = (size_t)b * p.Ntok;
-    const int q = blockIdx.x * 256 + wave * 32 + l31;
+    const int q = (rb.tile0 + wave) * 32 + l31;
     const int qc = min(q, p.Ntok - 1);
-    const bool wave_active = (blockIdx.x * 256 + wave * 32) < p.Ntok;
+    const bool wave_active = wave < rb.nt && (rb.tile0 + wave) * 32 < p.Ntok;
     const float sl2 = p.scale * LOG2E;
 
-    RowRegs<CHK> kr, vr;
-    kr.load(p.qkv, rowbase, p.ldqkv, C + h * HD, 0, p.Ntok, tid);
+    const __bf16* ksrc = PRE ? p.qk : p.qkv;
+    const int kld = PRE ? p.ldqk : p.ldqkv;
+    RowRegs<CHK, NT> kr, vr;
+    kr.load(ksrc, rowbase, kld, C + h * HD, 0, p.Ntok, tid);
     vr.load(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, 0, p.Ntok, tid);
-    load_rope_tables<512>(rt, p.cos_t, p.sin_t, p.grid, tid);
-    __syncthreads();
     bf16x8 qf[4], dof[4];
-    load_q_frags(p, rt, rowbase, qc, h, hf, qf);
+    if constexpr (PRE) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(p.qk + (rowbase + qc) * p.ldqk + h * HD + ks * 16 + hf * 8);
+    } else {
+        load_rope_tables<NT>(rt, p.cos_t, p.sin_t, p.grid, tid);
+        __syncthreads();
+        load_q_frags<CT>(p, rt, rowbase, qc, h, hf, qf);
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) dof[ks] = *(const bf16x8*)(p.dout + (rowbase + qc) * p.ldo + h * HD + ks * 16 + hf * 8);
     const float lse2 = p.lse_in[(size_t)bh * p.Ntok + qc] * LOG2E;
@@ -1023,14 +1110,14 @@ __global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnA
 
     for (int key0 = 0; key0 < (SINGLE ? 1 : p.Ntok); key0 += CHK) {
         if (key0) __syncthreads();                     // every wave is done with the previous chunk's images
-        kr.template store<true, true>(Kl, rt, p.grid, p.inv_grid, key0, p.Ntok, tid);
+        kr.template store<!PRE, true, CT>(Kl, rt, p.grid, p.inv_grid, key0, p.Ntok, tid);
         vr.template store<false>(Vl, rt, p.grid, p.inv_grid, key0, p.Ntok, tid);
         __syncthreads();
-        if (!SINGLE && key0 + CHK < p.Ntok) {          // the next chunk's rows travel while this one is consumed
-            kr.load(p.qkv, rowbase, p.ldqkv, C + h * HD, key0 + CHK, p.Ntok, tid);
+        if (!SINGLE && PF && key0 + CHK < p.Ntok) {    // the next chunk's rows travel while this one is consumed
+            kr.load(ksrc, rowbase, kld, C + h * HD, key0 + CHK, p.Ntok, tid);
             vr.load(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0 + CHK, p.Ntok, tid);
         }
-        if (!wave_active) continue;
+        if (wave_active) {
 #pragma unroll                                         // t * 4096 becomes the immediate offset of every LDS read
         for (int t = 0; t < CH; ++t) {
             if (key0 + t * 32 >= p.Ntok) break;        // wave-uniform: a tile of padding keys only (p = 0 everywhere)
@@ -1064,6 +1151,7 @@ __global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnA
                 }
             }
         }
+        }
     }
     if (wave_active && q < p.Ntok) {
         const size_t pos = (size_t)(q > 0 ? q - 1 : 0) * HD;
@@ -1072,9 +1160,10 @@ __global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnA
 }
 
 // dK, dV: wave = 32 keys, loops over query chunks.  S = Q K^T (lane = key, registers = queries);  dV^T += dO^T . P ;  dK^T += Q^T . dS
-template <int CH, bool SINGLE>
+template <int CH, bool SINGLE, bool PRE = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {       // 64 + 32 + 32 accumulator / operand registers: no 128-register form
-    constexpr int CHQ = CH * 32;
+    constexpr int CHQ = CH * 32, NT = 512, NW = 8;
+    constexpr bool CT = false, PF = true;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ql = smem;
     char* Gl = smem + CHQ * 128;
@@ -1083,16 +1172,19 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {    
     float* rt = dsum_s + CHQ;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5, l31 = lane & 31;
-    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const RowBlock rb = map_block(p, NW);
+    const int bh = rb.bh, b = bh / p.H, h = bh - b * p.H;
     const int C = p.H * HD;
     const size_t rowbase = (size_t)b * p.Ntok;
-    const int key = blockIdx.x * 256 + wave * 32 + l31;
+    const int key = (rb.tile0 + wave) * 32 + l31;
     const int kc = min(key, p.Ntok - 1);
-    const bool wave_active = (blockIdx.x * 256 + wave * 32) < p.Ntok;
+    const bool wave_active = wave < rb.nt && (rb.tile0 + wave) * 32 < p.Ntok;
     const float sl2 = p.scale * LOG2E;
 
-    RowRegs<CHQ> qr, gr;
-    qr.load(p.qkv, rowbase, p.ldqkv, h * HD, 0, p.Ntok, tid);
+    const __bf16* qsrc = PRE ? p.qk : p.qkv;
+    const int qld = PRE ? p.ldqk : p.ldqkv;
+    RowRegs<CHQ, NT> qr, gr;
+    qr.load(qsrc, rowbase, qld, h * HD, 0, p.Ntok, tid);
     gr.load(p.dout, rowbase, p.ldo, h * HD, 0, p.Ntok, tid);
     float lse_r = 0.f, dsum_r = 0.f;                   // thread i < CHQ carries query q0 + i's statistics
     auto load_stats = [&](int q0) {
@@ -1103,19 +1195,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {    
         }
     };
     load_stats(0);
-    load_rope_tables<512>(rt, p.cos_t, p.sin_t, p.grid, tid);
-    __syncthreads();
+    if constexpr (!PRE) {
+        load_rope_tables<NT>(rt, p.cos_t, p.sin_t, p.grid, tid);
+        __syncthreads();
+    }
     bf16x8 kf[4], vf[4];
     {
         U128 t[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            t[ks].u = *(const uint4*)(p.qkv + (rowbase + kc) * p.ldqkv + C + h * HD + ks * 16 + hf * 8);
+            t[ks].u = PRE ? *(const uint4*)(p.qk + (rowbase + kc) * p.ldqk + C + h * HD + ks * 16 + hf * 8)
+                          : *(const uint4*)(p.qkv + (rowbase + kc) * p.ldqkv + C + h * HD + ks * 16 + hf * 8);
             vf[ks] = *(const bf16x8*)(p.qkv + (rowbase + kc) * p.ldqkv + 2 * C + h * HD + ks * 16 + hf * 8);
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (kc > 0) rope8_lds(t[ks], rt, p.grid, p.inv_grid, kc, ks * 2 + hf);
+            if (!PRE && kc > 0) rope8_lds(t[ks], rt, p.grid, p.inv_grid, kc, ks * 2 + hf);
             kf[ks] = t[ks].h;
         }
     }
@@ -1132,16 +1227,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {    
 
     for (int q0 = 0; q0 < (SINGLE ? 1 : p.Ntok); q0 += CHQ) {
         if (q0) __syncthreads();
-        qr.template store<true>(Ql, rt, p.grid, p.inv_grid, q0, p.Ntok, tid);
+        qr.template store<!PRE, false, CT>(Ql, rt, p.grid, p.inv_grid, q0, p.Ntok, tid);
         gr.template store<false>(Gl, rt, p.grid, p.inv_grid, q0, p.Ntok, tid);
         if (tid < CHQ) { lse_s[tid] = lse_r; dsum_s[tid] = dsum_r; }
         __syncthreads();
-        if (!SINGLE && q0 + CHQ < p.Ntok) {
-            qr.load(p.qkv, rowbase, p.ldqkv, h * HD, q0 + CHQ, p.Ntok, tid);
+        if (!SINGLE && PF && q0 + CHQ < p.Ntok) {
+            qr.load(qsrc, rowbase, qld, h * HD, q0 + CHQ, p.Ntok, tid);
             gr.load(p.dout, rowbase, p.ldo, h * HD, q0 + CHQ, p.Ntok, tid);
             load_stats(q0 + CHQ);
         }
-        if (!wave_active) continue;
+        if (wave_active) {
 #pragma unroll
         for (int t = 0; t < CH; ++t) {
             if (q0 + t * 32 >= p.Ntok) break;          // a tile of padding queries only: P = 0
@@ -1177,6 +1272,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {    
                 }
             }
         }
+        }
     }
     if (wave_active && key < p.Ntok) {
         const size_t pos = (size_t)(key > 0 ? key - 1 : 0) * HD;
@@ -1184,6 +1280,31 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {    
         store_grad_tile(dk, row + C, key > 0, p.cos_t + pos, p.sin_t + pos, hf);
         store_grad_tile(dv, row + 2 * C, false, nullptr, nullptr, hf);
     }
+}
+
+// Block schedule of the 8-wave long-sequence kernels (map_block): returns the 1-D grid size.  CS_ATTN_NOSPLIT=1 (read per launch): the
+// rectangular grid of round 5.
+int att_num_cus() {                    // compute units of the current device, read once per process (one 8-wave workgroup of these kernels per CU)
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+int set_schedule(AttnArgs& a, int B, int Ntok, int H, dim3& grid) {
+    const int nt = (Ntok + 31) / 32, fb = nt / 8, rem = nt % 8, BH = B * H, F = fb * BH, G = att_num_cus();
+    int R = F % G;
+    if (getenv("CS_ATTN_NOSPLIT") || fb == 0 || 2 * R > G) R = 0;
+    if (R == 0) {                                                       // nothing to split: the rectangular grid
+        a.sch_on = 0;
+        grid = dim3((Ntok + 255) / 256, BH);
+        return 0;
+    }
+    a.sch_on = 1; a.sch_f0 = F - R; a.sch_r = R; a.sch_bh = BH; a.sch_fb = fb; a.sch_rem = rem;
+    a.sch_absorb = rem > 0 && rem <= 4 && R >= BH;                      // every pair's last full block is among the split ones
+    grid = dim3(F + R + ((rem > 0 && !a.sch_absorb) ? BH : 0), 1);
+    return 1;
 }
 
 template <typename K>
@@ -1381,7 +1502,9 @@ static int attn_fwd_impl(const void* qkv, const float* cos_t, const float* sin_t
             hipLaunchKernelGGL((attn_fwd_kernel<CH>), dim3((Ntok + 255) / 256, B * H), dim3(512), lds, stream, a);
         } else {
             const size_t lds2 = (size_t)2 * CH * 32 * 128 + (size_t)4 * g * 32 * sizeof(float);
-            hipLaunchKernelGGL((attn_fwd2_kernel<CH, 4>), dim3((Ntok + 255) / 256, B * H), dim3(512), lds2, stream, a);
+            dim3 grid2;
+            set_schedule(a, B, Ntok, H, grid2);
+            hipLaunchKernelGGL((attn_fwd2_kernel<CH, 4>), grid2, dim3(512), lds2, stream, a);
         }
     }
     CS_LAUNCH_CHECK();
@@ -1409,7 +1532,11 @@ extern "C" int cs_attn_fwd_stats(const void* qkv, const float* cos_t, const floa
     return attn_fwd_impl(qkv, cos_t, sin_t, out, lse, stats_part, B, Ntok, H, ldqkv, ldo, scale, stream);
 }
 
-extern "C" size_t cs_attn_bwd_workspace(int B, int Ntok, int H) { return (size_t)B * H * Ntok * sizeof(float); }
+// dsum [B*H, Ntok] f32, and for sequences of more than one key chunk the rotated q | k of the launch ([B*Ntok, 2C] bf16, 256-byte aligned)
+static size_t bwd_dsum_bytes(int B, int Ntok, int H) { return (((size_t)B * H * Ntok * sizeof(float)) + 255) & ~(size_t)255; }
+extern "C" size_t cs_attn_bwd_workspace(int B, int Ntok, int H) {
+    return bwd_dsum_bytes(B, Ntok, H) + (Ntok > 7 * 32 ? (size_t)B * Ntok * 2 * H * HD * sizeof(__bf16) : 0);
+}
 
 // o, dout [B*N, ldo] bf16; lse from the forward; dqkv [B*N, ldqkv] bf16 receives d(q|k|v) w.r.t. the *un-rotated* q,k.
 extern "C" int cs_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, const float* cos_t, const float* sin_t,
@@ -1436,16 +1563,32 @@ extern "C" int cs_attn_bwd(const void* qkv, const void* o, const void* dout, con
         const size_t lds_dq = (size_t)2 * CHK * 128 + rope, lds_dkv = (size_t)2 * CHK * 128 + (size_t)2 * CHK * sizeof(float) + rope;
         CS_CHECK_ARG(lds_dkv <= 160 * 1024, "cs_attn_bwd: token grid %d too large for the LDS RoPE tables", g);
         static bool once = (set_lds(attn_bwd_dq2_kernel<CH, false>, 160 * 1024), set_lds(attn_bwd_dkv2_kernel<CH, false>, 160 * 1024),
-                            set_lds(attn_bwd_dq2_kernel<CH, true>, 160 * 1024), set_lds(attn_bwd_dkv2_kernel<CH, true>, 160 * 1024), true);
+                            set_lds(attn_bwd_dq2_kernel<CH, true>, 160 * 1024), set_lds(attn_bwd_dkv2_kernel<CH, true>, 160 * 1024),
+                            set_lds(attn_bwd_dq2_kernel<CH, false, true>, 160 * 1024), set_lds(attn_bwd_dkv2_kernel<CH, false, true>, 160 * 1024), true);
         (void)once;
         if (Ntok <= CHK) {
             hipLaunchKernelGGL((attn_bwd_dq2_kernel<CH, true>), grid, block, lds_dq, stream, a);
             CS_LAUNCH_CHECK();
             hipLaunchKernelGGL((attn_bwd_dkv2_kernel<CH, true>), grid, block, lds_dkv, stream, a);
         } else {
-            hipLaunchKernelGGL((attn_bwd_dq2_kernel<CH, false>), grid, block, lds_dq, stream, a);
-            CS_LAUNCH_CHECK();
-            hipLaunchKernelGGL((attn_bwd_dkv2_kernel<CH, false>), grid, block, lds_dkv, stream, a);
+            dim3 grid2;
+            set_schedule(a, B, Ntok, H, grid2);
+            if (getenv("CS_ATTN_NOPRE")) {                 // A/B switch, read per launch: every row block rotates its operands itself (round 5)
+                hipLaunchKernelGGL((attn_bwd_dq2_kernel<CH, false>), grid2, block, lds_dq, stream, a);
+                CS_LAUNCH_CHECK();
+                hipLaunchKernelGGL((attn_bwd_dkv2_kernel<CH, false>), grid2, block, lds_dkv, stream, a);
+            } else {
+                const int C2 = 2 * H * HD;
+                __bf16* qk = (__bf16*)((char*)workspace + bwd_dsum_bytes(B, Ntok, H));
+                const long items = (long)B * Ntok * (C2 / 8);
+                hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, (const __bf16*)qkv, cos_t, sin_t, qk,
+                                   (long)B * Ntok, Ntok, H * HD, ldqkv);
+                CS_LAUNCH_CHECK();
+                a.qk = qk; a.ldqk = C2;
+                hipLaunchKernelGGL((attn_bwd_dq2_kernel<CH, false, true>), grid2, block, lds_dq - rope, stream, a);
+                CS_LAUNCH_CHECK();
+                hipLaunchKernelGGL((attn_bwd_dkv2_kernel<CH, false, true>), grid2, block, lds_dkv - rope, stream, a);
+            }
         }
         CS_LAUNCH_CHECK();
         return 0;

@@ -458,6 +458,40 @@ def test_attention_forward_kernel_variants_agree_bit_for_bit(hip, B, Ntok, H):
             assert torch.equal(a, b), f"{name}: {what}: {int((a != b).sum())} elements differ from the default kernel"
 
 
+@pytest.mark.parametrize("B,Ntok,H", [(2, 4097, 12), (1, 4097, 3), (2, 577, 3), (1, 785, 2), (3, 1025, 2), (1, 401, 2), (5, 2305, 4)])
+def test_long_sequence_tail_split_schedule_is_bit_identical_to_the_rectangular_grid(hip, B, Ntok, H):
+    """Round 6: the 8-wave long-sequence kernels (forward, dQ, dK/dV) issue the blocks of a launch's last, partly filled round as half blocks
+    of four row tiles, and a sequence's last tiles ride on the upper half of its last full block (map_block / set_schedule in attention.hip;
+    the recipe's 2 x 12 x 4097: 384 + 24 workgroups -> 256 full + 256 half blocks).  Which workgroup computes a row does not enter its
+    arithmetic: outputs, lse and all three gradients equal the rectangular grid's (CS_ATTN_NOSPLIT=1, read per launch) in every bit."""
+    import os
+    C = H * 64
+    qkv = rnd((B * Ntok, 3 * C), BF, 1.0, seed=39).cuda()
+    cos, sin = (t.cuda() for t in _rope(Ntok, 0))
+    dout = rnd((B * Ntok, C), BF, seed=40).cuda()
+    scale = 64 ** -0.5
+    outs = []
+    for nosplit in (False, True):
+        o = torch.full((B * Ntok, C), float("nan"), dtype=BF, device="cuda")
+        lse = torch.full((B * H, Ntok), float("nan"), device="cuda")
+        part = torch.full((H, B * Ntok, 2), float("nan"), device="cuda")
+        dq = torch.full((B * Ntok, 3 * C), float("nan"), dtype=BF, device="cuda")
+        ws = torch.empty(hip.attn_bwd_workspace(B, Ntok, H), dtype=torch.uint8, device="cuda")
+        if nosplit:
+            os.environ["CS_ATTN_NOSPLIT"] = "1"
+        try:
+            hip.attn_fwd_stats(qkv, cos, sin, o, lse, part, B, Ntok, H, scale)
+            hip.attn_bwd(qkv, o, dout, lse, cos, sin, dq, ws, B, Ntok, H, scale)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("CS_ATTN_NOSPLIT", None)
+        for t in (o, lse, part, dq):
+            assert torch.isfinite(t.float()).all()
+        outs.append((o, lse, part, dq))
+    for a, b, name in zip(outs[0], outs[1], ("o", "lse", "statistics", "dqkv")):
+        assert torch.equal(a, b), f"{name}: {int((a != b).sum())} elements differ between the split and the rectangular schedule"
+
+
 @pytest.mark.parametrize("B,Ntok,H", [(120, 197, 12), (700, 17, 2), (90, 65, 12)])
 def test_attention_units_are_launch_size_invariant(hip, B, Ntok, H):
     """A (crop, head) unit's result must not depend on the size of the launch it is part of (more units than resident workgroups: 12
