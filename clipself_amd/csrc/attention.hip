@@ -43,11 +43,14 @@ __device__ __forceinline__ void rope8(U128& v, const float* __restrict__ cs, con
     const float4 s0 = *(const float4*)sn, s1 = *(const float4*)(sn + 4);
     const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     const float s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    // The contraction is written out (one product rounded to fp32, then one FMA): left to hipcc's -ffp-contract=fast, WHICH of the two products is
+    // fused depends on the surrounding code, and the same source then rounds differently in two kernels (round 6: one dQ element in 4 M differed
+    // between the prepass kernel's rotation and the staging loop's).
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float x0 = bf2f(v.e[2 * j]), x1 = bf2f(v.e[2 * j + 1]);
-        v.e[2 * j] = f2bf(x0 * c[2 * j] - x1 * s[2 * j]);
-        v.e[2 * j + 1] = f2bf(x1 * c[2 * j + 1] + x0 * s[2 * j + 1]);
+        v.e[2 * j] = f2bf(__builtin_fmaf(x0, c[2 * j], -(x1 * s[2 * j])));
+        v.e[2 * j + 1] = f2bf(__builtin_fmaf(x1, c[2 * j + 1], x0 * s[2 * j + 1]));
     }
 }
 
@@ -73,10 +76,10 @@ __device__ __forceinline__ void rope8c(U128& v, const float* rt, int g, float in
     const float4 c4 = *(const float4*)cs, s4 = *(const float4*)(cs + (g << 4));
     const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4; ++j) {              // the written-out contraction of rope8
         const float x0 = bf2f(v.e[2 * j]), x1 = bf2f(v.e[2 * j + 1]);
-        v.e[2 * j] = f2bf(x0 * cc[j] - x1 * ss[j]);
-        v.e[2 * j + 1] = f2bf(x1 * cc[j] + x0 * ss[j]);
+        v.e[2 * j] = f2bf(__builtin_fmaf(x0, cc[j], -(x1 * ss[j])));
+        v.e[2 * j + 1] = f2bf(__builtin_fmaf(x1, cc[j], x0 * ss[j]));
     }
 }
 
@@ -883,8 +886,9 @@ __device__ __forceinline__ void store_grad_tile(const f32x16 (&g)[2], __bf16* ds
             float v[4] = {g[dt][g4 * 4], g[dt][g4 * 4 + 1], g[dt][g4 * 4 + 2], g[dt][g4 * 4 + 3]};
             if (rope) {
                 const float4 c = *(const float4*)(cs + d), s = *(const float4*)(sn + d);
-                const float a0 = v[0] * c.x + v[1] * s.y, a1 = v[1] * c.y - v[0] * s.x;
-                const float a2 = v[2] * c.z + v[3] * s.w, a3 = v[3] * c.w - v[2] * s.z;
+                // (contraction written out, as in rope8: the same bits in every kernel that inlines this)
+                const float a0 = __builtin_fmaf(v[0], c.x, v[1] * s.y), a1 = __builtin_fmaf(v[1], c.y, -(v[0] * s.x));
+                const float a2 = __builtin_fmaf(v[2], c.z, v[3] * s.w), a3 = __builtin_fmaf(v[3], c.w, -(v[2] * s.z));
                 v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
             }
             U64 t;
