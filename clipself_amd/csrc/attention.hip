@@ -15,6 +15,7 @@
 //     (conflict-free ds_read_b128), V as V^T [64][keys+4] (8-byte reads, odd dword stride -> conflict free).
 //   * keys are consumed in chunks of CH*32 with an online softmax, so any sequence length works; for the
 //     14x14(+CLS) grid a single chunk of 224 covers all 197 keys and no rescale is ever taken.
+#include <type_traits>
 #include <vector>
 #include "cs_common.h"
 #include <cstdio>
@@ -1121,14 +1122,13 @@ __global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnA
             kr.load(ksrc, rowbase, kld, C + h * HD, key0 + CHK, p.Ntok, tid);
             vr.load(p.qkv, rowbase, p.ldqkv, 2 * C + h * HD, key0 + CHK, p.Ntok, tid);
         }
-        if (wave_active) {
-#pragma unroll                                         // t * 4096 becomes the immediate offset of every LDS read
-        for (int t = 0; t < CH; ++t) {
-            if (key0 + t * 32 >= p.Ntok) break;        // wave-uniform: a tile of padding keys only (p = 0 everywhere)
+        // one key tile: RAGGED = the tile may hold padding keys (only in the sequence's last chunk)
+        auto tile = [&](int t, auto ragged) {          // (t is a constant after unrolling)
+            constexpr bool RAGGED = decltype(ragged)::value;
             f32x16 s, dp;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int off = t * (16 * 256) + k_base + (((par8 | (ks * 2 + hf)) ^ sw) << 4);
+                const int off = t * (16 * 256) + k_base + (((par8 | (ks * 2 + hf)) ^ sw) << 4);       // t * 4096 becomes the immediate offset of every LDS read
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Kl + off), qf[ks], ks ? s : Z16, 0, 0, 0);       // first step onto the inline 0
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Vl + off), dof[ks], ks ? dp : Z16, 0, 0, 0);
             }
@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnA
             // ... but 0 * inf is NaN: a padding key's score is 0, so its "probability" is exp2(-lse2), which overflows for a query whose
             // scaled scores are all below ~ -88 (lse < -88) and would poison the whole dQ row.  Only the sequence's ragged last tile holds
             // padding keys (wave-uniform branch, as in attend_chunk): their dS is set to 0 there.
-            if (key0 + t * 32 + 32 > p.Ntok) {
+            if (RAGGED && key0 + t * 32 + 32 > p.Ntok) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     if (key0 + t * 32 + mfma32_row(e, lane) >= p.Ntok) s[e] = 0.f;
@@ -1154,7 +1154,17 @@ __global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnA
                     dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, db, dq[dt], 0, 0, 0);
                 }
             }
-        }
+        };
+        if (wave_active) {
+            // (Round 6 tried a branch-free path for the chunks that lie inside the sequence -- CH tiles as ONE basic block, no per-tile exit, no
+            // padding mask -- so that hipcc's scheduler could put tile t + 1's S / dP MFMAs beside tile t's softmax arithmetic: it interleaves
+            // until the registers run out (dK/dV: 35-42 dwords spilled at 256 VGPRs) and the pair of kernels got 8.6 % SLOWER at 4097 tokens
+            // (522 vs 480 us, profiles/r06_g_full_chunk_path.txt).  The per-tile exits stay.)
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                if (key0 + t * 32 >= p.Ntok) break;        // wave-uniform: a tile of padding keys only (p = 0 everywhere)
+                tile(t, std::true_type{});
+            }
         }
     }
     if (wave_active && q < p.Ntok) {
@@ -1240,10 +1250,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {    
             gr.load(p.dout, rowbase, p.ldo, h * HD, q0 + CHQ, p.Ntok, tid);
             load_stats(q0 + CHQ);
         }
-        if (wave_active) {
-#pragma unroll
-        for (int t = 0; t < CH; ++t) {
-            if (q0 + t * 32 >= p.Ntok) break;          // a tile of padding queries only: P = 0
+        auto tile = [&](int t) {
             f32x16 s, dp;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -1275,7 +1282,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {    
                     dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join2(tr_read4(Ql + o0), tr_read4(Ql + o1)), db, dk[dt], 0, 0, 0);
                 }
             }
-        }
+        };
+        if (wave_active) {
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                if (q0 + t * 32 >= p.Ntok) break;          // a tile of padding queries only: P = 0
+                tile(t);
+            }
         }
     }
     if (wave_active && key < p.Ntok) {
