@@ -1159,7 +1159,7 @@ __global__ __launch_bounds__(512, SINGLE ? 4 : 2) void attn_bwd_dq2_kernel(AttnA
             // (Round 6 tried a branch-free path for the chunks that lie inside the sequence -- CH tiles as ONE basic block, no per-tile exit, no
             // padding mask -- so that hipcc's scheduler could put tile t + 1's S / dP MFMAs beside tile t's softmax arithmetic: it interleaves
             // until the registers run out (dK/dV: 35-42 dwords spilled at 256 VGPRs) and the pair of kernels got 8.6 % SLOWER at 4097 tokens
-            // (522 vs 480 us, profiles/r06_g_full_chunk_path.txt).  The per-tile exits stay.)
+            // (522 vs 480 us; the dQ kernel alone, which does not spill: 219 vs 213 us -- profiles/r06_g_full_chunk_path.txt).  The per-tile exits stay.)
 #pragma unroll
             for (int t = 0; t < CH; ++t) {
                 if (key0 + t * 32 >= p.Ntok) break;        // wave-uniform: a tile of padding keys only (p = 0 everywhere)
