@@ -190,8 +190,9 @@ def test_b16_cfg1_end_to_end_against_fp32_bf16_and_kernel_rounding_oracles():
          f"kernel-points {l_k:.6f} ({abs(l_hip - l_k) / l_k:.1e})")
     assert noise > 2e-3, "the chaos yardstick itself: a bf16 12-block tower is not reproducible to 2e-3 under a 1e-7 perturbation"
     # end to end every bf16 implementation sits within ~1.5x of the oracle's own fp32-vs-fp64-accumulation distance
-    assert rel(_nrm(t), _nrm(t_k)) < max(1.5e-2, 2 * noise) and rel(_nrm(s), _nrm(s_k)) < max(1.5e-2, 2 * noise)
-    assert one_minus_cos(t, t_k) < 2e-4 and one_minus_cos(s, s_k) < 2e-4
+    # (round 6: bounds cut to ~1.8x the measured 5.6e-3 / 3.6e-3 and 2.3e-5 of profiles/r06_parity.md; they were 1.5e-2 / 2e-4 since round 3)
+    assert rel(_nrm(t), _nrm(t_k)) < max(1.0e-2, 1.4 * noise) and rel(_nrm(s), _nrm(s_k)) < max(1.0e-2, 1.4 * noise)
+    assert one_minus_cos(t, t_k) < 6e-5 and one_minus_cos(s, s_k) < 6e-5
     for ref in (l_f, l_g, l_k):
         assert abs(l_hip - ref) / ref < 1e-3, (l_hip, ref)
 
@@ -215,7 +216,7 @@ def test_full_size_teacher_pass_sampled_against_the_frozen_schedule_oracle():
     got = got_all[idx.cuda()]
     _log(f"cfg1 full-size teacher pass, {len(idx)} sampled crops, normalised features rel-L2: vs fp32 oracle {rel(_nrm(got), _nrm(want_f)):.3e} | "
          f"vs frozen-schedule bf16 oracle {rel(_nrm(got), _nrm(want_k)):.3e}; max 1-cos {one_minus_cos(got, want_k):.1e}")
-    assert rel(_nrm(got), _nrm(want_k)) < 1.5e-2 and one_minus_cos(got, want_k) < 2e-4
+    assert rel(_nrm(got), _nrm(want_k)) < 1.0e-2 and one_minus_cos(got, want_k) < 6e-5      # measured 5.3e-3 / 2.2e-5 (profiles/r06_parity.md)
 
 
 def test_b16_block_backward_teacher_forced_against_the_kernel_rounding_oracle():

@@ -667,9 +667,10 @@ def test_vitb16_openai_cfg1_matches_reference_goldens(golden_dir):
             cos = torch.nn.functional.cosine_similarity(t, s, dim=-1).cpu()
             _log(f"vitb16 teacher_slice rel={rel(t[:4, :16], g['teacher_slice']):.3e} roi_slice rel={rel(s[:4, :16], g['student_roi_slice']):.3e} "
                  f"cos maxabs={float((cos - torch.from_numpy(g['cos'])).abs().max()):.3e}")
-            assert rel(t[:4, :16], g["teacher_slice"]) < 2.8e-2 and rel(s[:4, :16], g["student_roi_slice"]) < 1.3e-2     # measured 1.4e-2 / 6.3e-3
-            assert rel(t.norm(dim=-1), g["teacher_rownorm"]) < 1e-3 and rel(s.norm(dim=-1), g["student_rownorm"]) < 4e-4     # 4.7e-4 / 1.8e-4
-            assert float((cos - torch.from_numpy(g["cos"])).abs().max()) < 3.4e-3                                       # 1.7e-3
+            # round 6: this family's own measurements (profiles/r06_parity.md: 4.5e-3 / 6.1e-3 / 8.5e-4), not the EVA02 test's bounds
+            assert rel(t[:4, :16], g["teacher_slice"]) < 1.0e-2 and rel(s[:4, :16], g["student_roi_slice"]) < 1.3e-2
+            assert rel(t.norm(dim=-1), g["teacher_rownorm"]) < 1e-3 and rel(s.norm(dim=-1), g["student_rownorm"]) < 4e-4
+            assert float((cos - torch.from_numpy(g["cos"])).abs().max()) < 2e-3
         out, bs, _ = train_step(student, CLIPSelf(), batch, opt, sched, step, teacher, _args())
         losses.append(float(out["loss"].detach()))
         if step == 0:
@@ -685,7 +686,7 @@ def test_vitb16_openai_cfg1_matches_reference_goldens(golden_dir):
                       "visual.transformer.resblocks.5.attn.in_proj_bias", "visual.transformer.resblocks.11.attn.in_proj_bias"):
                 r = rel(dict(student.named_parameters())[n].grad, g["grad/" + n])
                 _log(f"vitb16 grad {n} rel={r:.3e}")
-                assert r < 3e-2, n                                  # measured worst 1.41e-2
+                assert r < 1.3e-2, n                                # measured worst 6.4e-3
             _log(f"vitb16 worst grad-norm rel {worst}")
     _log(f"vitb16 losses {losses} vs {g['losses'].tolist()}")
     assert abs(losses[0] - g["losses"][0]) / g["losses"][0] < 1e-3
