@@ -47,3 +47,19 @@ def test_expected_data_parallel_fields_follow_the_design_table():
     assert e1["mb_on_a_ranks_links_per_bucket"] == 0.0 and e1["reserve_cost_ms"] == 0.0 and e1["speedup_over_one_gpu"] == [1.0, 1.0]
     e2, e4 = bench.expected_data_parallel(2), bench.expected_data_parallel(4)
     assert e2["speedup_over_one_gpu"][0] > 1.9 and e4["speedup_over_one_gpu"][0] > 3.8
+
+
+def test_floor_table_reproduces_from_the_tracked_launch_sequence():
+    """profiles/r06_floor.md is generated, not typed: tools/floor_table.py on the tracked launch sequence of the profiled step gives the same table -- every
+    launch is assigned to a class (the classes' measured times add up to the step's kernel time) and the design floor is below the measurement."""
+    import re
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "floor_table.py"), str(ROOT / "profiles" / "r06_m_sequence_inline.txt")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"\| \*\*step\*\* \| (\d+) \| \*\*([\d.]+)\*\* \| \*\*([\d.]+)\*\* \|", r.stdout)
+    assert m, r.stdout[-500:]
+    launches, measured, floor = int(m.group(1)), float(m.group(2)), float(m.group(3))
+    head = re.search(r"(\d+) launches, ([\d.]+) ms of kernel time", r.stdout)
+    assert launches == int(head.group(1)) == 599 and abs(measured - float(head.group(2))) < 0.05       # nothing dropped, nothing counted twice
+    assert 70.0 < floor < measured < 95.0
+    tracked = (ROOT / "profiles" / "r06_floor.md").read_text()
+    assert f"**{floor:.2f}**" in tracked and f"**{measured:.2f}**" in tracked
