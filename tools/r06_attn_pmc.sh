@@ -11,7 +11,7 @@ run() {  # tag, env..., counters
   python $root/tools/rocprof_pmc.py "$out/p_$tag/r_results.db" | grep -v "at::native" > "$out/pmc_$tag.md"
   rm -rf "$out/p_$tag"
 }
-for v in "fwd4:CS_ATTN_X=0" "fwd8:CS_ATTN_FWD4=0"; do
+for v in "fwd4:CS_ATTN_FWD4=1" "fwd8:CS_ATTN_FWD4=0"; do
   name=${v%%:*}; e=${v#*:}
   run ${name}_busy "$e" SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_BUSY_CYCLES
   run ${name}_insts "$e" SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAVES
