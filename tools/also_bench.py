@@ -3,11 +3,12 @@
 process: a fresh allocator, and a fault here cannot take the headline line with it) after its timed region and attaches the lines as the
 `also` key (the other BASELINE configurations and the reference's own recipe shape should be driver-observed).
 
-    python tools/also_bench.py recipe_b16 | recipe_l14 | cfg3 | cfg4_bf16 | cfg4_fp8 | openai_b16   [steps]
+    python tools/also_bench.py recipe_b16 | recipe_l14 | cfg2 | cfg3 | cfg4_bf16 | cfg4_fp8 | openai_b16   [steps]
 
   recipe_b16  the reference's shipped recipe on one GPU (scripts/train_clipself_coco_image_patches_eva_vitb16.sh:1-8): EVA02-CLIP-B-16, 2 images
               per GPU, student at 1024^2 = 4097 tokens, <= 20 grid crops at 224^2 (13 valid on average)
   recipe_l14  the same recipe for EVA02-CLIP-L-14-336 (scripts/train_clipself_coco_image_patches_eva_vitl14.sh): student at 896^2, crops at 336^2
+  cfg2        BASELINE configs[2] shapes on one GPU: EVA02-CLIP-B-16 CLIPSelf region proposals, 64 images x 20 box slots (70 % valid: ragged batch), 224^2
   cfg3        BASELINE configs[3] shapes on one GPU: EVA02-CLIP-L-14-336 CLIPSelf, 16 images x 32 crops at 336^2
   cfg4_bf16   BASELINE configs[4] shapes on one GPU: EVA02-CLIP-L-14-336 RegionCLIP, 32 images x <= 20 boxes, 4764 nouns, bf16
   cfg4_fp8    ... with e4m3 forward and dgrad operands (precision amp_fp8_dgrad: "fp8 MFMA weights")
@@ -25,7 +26,7 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 PEAK = 2500.0
-WORKLOADS = ("recipe_b16", "recipe_l14", "cfg3", "cfg4_bf16", "cfg4_fp8", "openai_b16")
+WORKLOADS = ("recipe_b16", "recipe_l14", "cfg2", "cfg3", "cfg4_bf16", "cfg4_fp8", "openai_b16")
 
 
 def _flops(cfg, n_student, n_teacher, teacher_crops, images):
@@ -113,6 +114,9 @@ def run(which, steps):
     elif which == "recipe_l14":
         cfg, dt, loss, F, crops = clipself_workload("EVA02-CLIP-L-14-336", "eva", 2, 20, 896, 0.65, steps)
         n, name = 2, f"EVA02-CLIP-L-14-336 CLIPSelf, the reference's recipe shape: 2 images at 896^2 (4097 student tokens) x <= 20 grid crops at 336^2 ({crops:.1f} valid per step)"
+    elif which == "cfg2":
+        cfg, dt, loss, F, crops = clipself_workload("EVA02-CLIP-B-16", "eva", 64, 20, 224, 0.7, steps)
+        n, name = 64, f"EVA02-CLIP-B-16 CLIPSelf region-proposals step, 64 images x 20 box slots ({crops:.0f} valid crops per step: ragged), 224^2 (BASELINE configs[2] shapes, one GPU)"
     elif which == "cfg3":
         cfg, dt, loss, F, crops = clipself_workload("EVA02-CLIP-L-14-336", "eva", 16, 32, 336, 1.0, steps, warm=2)
         n, name = 16, "EVA02-CLIP-L-14-336 CLIPSelf image-patches step, 16 images x 32 crops, 336^2 (BASELINE configs[3] shapes, one GPU)"
