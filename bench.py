@@ -271,14 +271,14 @@ def measure_traffic_live(chunk_crops, timeout_s=150):
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, rec
 
 
-ALSO_WORKLOADS = ("recipe_b16", "recipe_l14", "cfg2", "cfg3", "cfg4_bf16", "cfg4_fp8")
+ALSO_WORKLOADS = ("recipe_b16", "recipe_l14", "cfg2", "cfg3", "cfg4_bf16", "cfg4_fp8", "openai_b16")
 # one-GPU step time the multi-GPU expectation is built on (ms; the driver's BENCH_r05 run of this workload) -- refreshed at the end of a round
 ONE_GPU_MS_REFERENCE = 87.3
 
 
 def also_workloads(steps=8, timeout_s=240):
     """The configurations beside the headline one, driver-observed: the reference's own recipe shape for both towers,
-    BASELINE configs[2], configs[3] and configs[4] (bf16 and fp8) at one GPU's share, a few steps each in a process of their own
+    BASELINE configs[2], configs[3] and configs[4] (bf16 and fp8) at one GPU's share, the headline workload on the OpenAI-CLIP ViT-B/16 towers; a few steps each in a process of their own
     (tools/also_bench.py) after the timed region.  A workload that fails or times out is reported as such; the headline fields are not touched."""
     import subprocess
     res = []

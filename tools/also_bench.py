@@ -31,8 +31,9 @@ WORKLOADS = ("recipe_b16", "recipe_l14", "cfg2", "cfg3", "cfg4_bf16", "cfg4_fp8"
 
 def _flops(cfg, n_student, n_teacher, teacher_crops, images):
     C, Hd, E, L, p = cfg.width, cfg.hidden, cfg.embed_dim, cfg.layers, cfg.patch_size
-    blk = lambda n: 8 * n * C * C + 4 * n * n * C + 6 * n * C * Hd
-    blk_na = lambda n: 4 * n * C * C + 6 * n * C * Hd
+    mlp = 4 if getattr(cfg, "arch", "eva02") == "openai" else 6          # c_fc + c_proj (GELU MLP) vs w1 | w2 | w3 (SwiGLU): 2 MACs per weight
+    blk = lambda n: 8 * n * C * C + 4 * n * n * C + mlp * n * C * Hd
+    blk_na = lambda n: 4 * n * C * C + mlp * n * C * Hd
     pe = lambda n: 2 * (n - 1) * 3 * p * p * C
     T = pe(n_teacher) + L * blk(n_teacher) + 2 * C * E
     Sf = pe(n_student) + (L - 1) * blk(n_student) + blk_na(n_student) + 2 * (n_student - 1) * C * E
