@@ -338,7 +338,12 @@ class HipOps:
         and the two dims of a rotation pair share their entry -- exactly what rope.py:118-142 builds (one `freqs` tensor, repeated for the
         pair, broadcast over rows and columns).  The C ABI documents this as a precondition (include/clipself_hip.h); this wrapper checks it
         once per table tensor (a few reductions and one host read-back) and raises instead of letting a kernel return wrong numbers."""
-        key = (cos.data_ptr(), sin.data_ptr(), cos._version, sin._version, Ntok)
+        def ver(t):
+            try:
+                return t._version
+            except RuntimeError:               # inference tensors carry no version counter
+                return -1
+        key = (cos.data_ptr(), sin.data_ptr(), ver(cos), ver(sin), Ntok)
         seen = self.__dict__.setdefault("_rope_ok", set())
         if key in seen:
             return
