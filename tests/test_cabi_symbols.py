@@ -125,3 +125,33 @@ def test_tower_partition_arguments_are_validated_at_construction(monkeypatch):
     m = CLIPSelf(partition_cus=48, partition_cap=64)
     m._check_partition(SimpleNamespace(num_compute_units=lambda: 304))
     assert m._partition_checked
+
+
+def test_rotary_table_layout_is_checked_by_the_wrapper():
+    """Round 6: the attention kernels read the rotary tables separably and (attn_fwd4_kernel) once per frequency -- the layout rope.py:118-142 builds
+    is a documented precondition of the C ABI.  HipOps verifies it once per table tensor: the oracle's tables and identity tables (the OpenAI-CLIP
+    family) pass, also as inference tensors; a table whose row part differs from its column part, whose pair entries differ, or that is not
+    separable raises instead of letting a kernel return wrong numbers.  (No GPU: the object is built around the logic.)"""
+    import torch
+    from clipself_amd import hip
+    from oracle.eva_ref import rope_tables
+    ops = hip.HipOps.__new__(hip.HipOps)
+    cos, sin = rope_tables(14, 64)
+    ops._check_rope_tables(cos, sin, 197)
+    ops._check_rope_tables(cos, sin, 197)                          # cached
+    ops._check_rope_tables(torch.ones(196, 64), torch.zeros(196, 64), 197)
+    with torch.inference_mode():
+        c2, s2 = cos.clone(), sin.clone()
+    ops._check_rope_tables(c2, s2, 197)
+    for poke in ((5, 3), (5, 40), (17, 2)):                          # pair partner / column part of one token / row part of one token
+        bad = cos.clone()
+        bad[poke] += 0.25
+        with pytest.raises(ValueError):
+            ops._check_rope_tables(bad, sin, 197)
+    with pytest.raises(ValueError):
+        ops._check_rope_tables(cos[:195], sin[:195], 196)          # not a square grid
+    c3, s3 = rope_tables(14, 64)
+    c3 = c3.view(14, 14, 64).clone()
+    c3[:, :, 32:] = c3[:, :, 32:].flip(1)                          # separable, pairs intact, but column part != row part
+    with pytest.raises(ValueError):
+        ops._check_rope_tables(c3.view(196, 64), s3, 197)
